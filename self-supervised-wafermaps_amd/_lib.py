@@ -1,0 +1,140 @@
+"""ctypes binding of libwafer_hip.so (the C ABI declared in include/wafer_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call fails, this
+module raises.  torch is used here only for device memory (`tensor.data_ptr()`) and the current
+HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+from pathlib import Path
+
+_HERE = Path(__file__).resolve().parent
+LIB_PATH = _HERE / "libwafer_hip.so"
+
+WM_F32, WM_BF16 = 0, 1
+WM_AUG_NONE, WM_AUG_DIENOISE, WM_AUG_DPW, WM_AUG_MEDIAN3 = 0, 1, 2, 3
+WM_IMG_NCHW_F32, WM_IMG_NHWC_BF16, WM_IMG_HW_U8 = 0, 1, 2
+
+
+class WaferHipError(RuntimeError):
+    pass
+
+
+class WmViewParams(ctypes.Structure):
+    """Mirror of `struct WmViewParams` (include/wafer_hip.h); 64 bytes."""
+
+    _fields_ = [
+        ("sample", c_int32),
+        ("out_slot", c_int32),
+        ("op", c_int32),
+        ("noise_seed", c_uint32),
+        ("noise_p", c_float),
+        ("dpw_h", c_int32),
+        ("dpw_w", c_int32),
+        ("rot90", c_int32),
+        ("vflip", c_int32),
+        ("hflip", c_int32),
+        ("crop", c_int32),
+        ("crop_i", c_int32),
+        ("crop_j", c_int32),
+        ("crop_h", c_int32),
+        ("crop_w", c_int32),
+        ("reserved", c_int32),
+    ]
+
+
+# name -> (restype, argtypes); kept in one table so tests can check it against the header.
+SIGNATURES = {
+    "wm_version": (c_int, []),
+    "wm_error_string": (c_char_p, [c_int]),
+    "wm_augment_views": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_int, c_int, c_int,
+         c_int, c_float, c_float, c_void_p, c_void_p],
+    ),
+    "wm_knn_topk_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "wm_knn_topk": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+         c_size_t, c_void_p],
+    ),
+    "wm_knn_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "wm_knn_vote": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    ),
+    "wm_l2_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
+    "wm_l2_normalize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "wm_ntxent_fwd": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
+    ),
+    "wm_ntxent_bwd": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
+    ),
+}
+
+_lib = None
+
+
+def load(path: os.PathLike | None = None) -> ctypes.CDLL:
+    """Load (once) and type the shared library.  Raises WaferHipError when it is not built."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = Path(path) if path else LIB_PATH
+    if not p.exists():
+        raise WaferHipError(
+            f"{p} not found: build it with `python self-supervised-wafermaps_amd/build.py` "
+            "(there is no CPU fallback for the HIP path)"
+        )
+    lib = ctypes.CDLL(str(p))
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # header/library drift must be loud
+            raise WaferHipError(f"{p} does not export {name}") from e
+        fn.restype = res
+        fn.argtypes = args
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load().wm_error_string(rc)
+        raise WaferHipError(f"{what} failed with code {rc}: {msg.decode() if msg else '?'}")
+
+
+def stream_ptr() -> int:
+    """Raw hipStream_t of torch's current stream (0 = the null stream)."""
+    import torch
+
+    return int(torch.cuda.current_stream().cuda_stream)
+
+
+def ptr(t) -> int:
+    return 0 if t is None else int(t.data_ptr())
+
+
+def require_gpu(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise WaferHipError("wafer_hip kernels need device tensors (no CPU fallback)")
+        if t is not None and not t.is_contiguous():
+            raise WaferHipError("wafer_hip kernels need contiguous tensors")
+
+
+def dtype_code(t) -> int:
+    import torch
+
+    if t.dtype == torch.float32:
+        return WM_F32
+    if t.dtype == torch.bfloat16:
+        return WM_BF16
+    raise WaferHipError(f"unsupported dtype {t.dtype}")

@@ -1,0 +1,97 @@
+"""Build libwafer_hip.so (every HIP kernel + the C ABI) for gfx950 with hipcc, in-tree.
+
+    python self-supervised-wafermaps_amd/build.py [--force] [--jobs N]
+
+Objects are cached per source under csrc/_build/ and rebuilt when the source, a header or the
+flags change.  The .so travels to the GPU box with the repo snapshot (git-ignored, not
+gpurun-ignored).
+"""
+from __future__ import annotations
+
+import argparse
+import hashlib
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+from pathlib import Path
+
+HERE = Path(__file__).resolve().parent
+CSRC = HERE / "csrc"
+ROOT = HERE.parent
+LIB = HERE / "libwafer_hip.so"
+ARCH = "gfx950"
+FLAGS = [
+    f"--offload-arch={ARCH}",
+    "-O3",
+    "-std=c++17",
+    "-fPIC",
+    "-fno-gpu-rdc",
+    "-Wall",
+    "-Wno-unused-function",
+    "-Wno-pass-failed",
+]
+
+
+def _hipcc() -> str:
+    for cand in (os.environ.get("HIPCC"), "/opt/rocm/bin/hipcc", "hipcc"):
+        if cand and (os.path.isabs(cand) and os.path.exists(cand) or not os.path.isabs(cand)):
+            return cand
+    raise RuntimeError("hipcc not found")
+
+
+def _digest(src: Path, headers: list[Path]) -> str:
+    h = hashlib.sha256()
+    h.update(" ".join(FLAGS).encode())
+    for p in [src, *headers]:
+        h.update(p.read_bytes())
+    return h.hexdigest()[:16]
+
+
+def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> Path:
+    srcs = sorted(CSRC.glob("*.hip"))
+    headers = sorted(CSRC.glob("*.h")) + sorted((ROOT / "include").glob("*.h"))
+    out = CSRC / "_build"
+    out.mkdir(exist_ok=True)
+    hipcc = _hipcc()
+    todo, objs = [], []
+    for s in srcs:
+        tag = _digest(s, headers)
+        obj = out / f"{s.stem}.{tag}.o"
+        objs.append(obj)
+        if force or not obj.exists():
+            for old in out.glob(f"{s.stem}.*.o"):
+                old.unlink()
+            todo.append((s, obj))
+
+    def compile_one(item):
+        s, obj = item
+        cmd = [hipcc, *FLAGS, "-c", str(s), "-o", str(obj)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {s.name}:\n{r.stdout}\n{r.stderr}")
+        if verbose and r.stderr.strip():
+            print(r.stderr, file=sys.stderr)
+        return s.name
+
+    if todo:
+        with ThreadPoolExecutor(max_workers=max(1, jobs)) as ex:
+            for name in ex.map(compile_one, todo):
+                if verbose:
+                    print(f"[wafer_hip] compiled {name}")
+    if todo or not LIB.exists():
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")
+        if verbose:
+            print(f"[wafer_hip] linked {LIB}")
+    return LIB
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--force", action="store_true")
+    ap.add_argument("--jobs", type=int, default=4)
+    a = ap.parse_args()
+    build(force=a.force, jobs=a.jobs)

@@ -1,0 +1,51 @@
+// Shared device/host helpers for the wafer_hip kernels (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/wafer_hip.h"
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4_t;
+typedef __attribute__((ext_vector_type(8))) short s16x8_t;
+
+#define WM_WAVE 64
+
+// Launch-error check used by every entry point: returns the hipError_t (positive) to the caller.
+#define WM_LAUNCH_CHECK()                              \
+  do {                                                 \
+    hipError_t _e = hipGetLastError();                 \
+    if (_e != hipSuccess) return (int)_e;              \
+  } while (0)
+
+#define WM_REQUIRE(cond, code) \
+  do {                         \
+    if (!(cond)) return (code); \
+  } while (0)
+
+// f32 -> bf16 bits, round-to-nearest-even (a plain cast lowers to v_cvt_pk_bf16_f32 on gfx950 and
+// keeps NaNs NaN; see MI355X_MICROARCH "Correctness boundaries").
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf2f(uint16_t u) {
+  return __builtin_bit_cast(float, ((uint32_t)u) << 16);
+}
+__device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+static inline int wm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

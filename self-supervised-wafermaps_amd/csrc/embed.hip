@@ -1,0 +1,326 @@
+// Embedding-space kernels: row L2-normalisation (fwd/bwd) and NT-Xent (fwd/bwd).
+//
+// NT-Xent replaces lightly.loss.NTXentLoss()(z0, z1) as called at
+// scripts/WM811k_benchmark.py:234,246 (T = 0.5, no memory bank).  The reference builds four
+// [B,B] logit blocks, masks two diagonals, concatenates to [2B, 2B-1] and calls CrossEntropyLoss;
+// here one pass over column tiles keeps an online log-sum-exp per row, so no logits reach HBM.
+// All arithmetic is float32 (the loss tolerance is 1e-4 relative); the work is 2*(2B)^2*d FLOP,
+// i.e. microseconds at B = 256, so the kernels are laid out for clarity and LDS-conflict freedom
+// rather than MFMA.
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------ L2 normalise: one wave / row
+template <typename TIn, typename TOut>
+__global__ __launch_bounds__(256) void l2norm_fwd(const TIn* __restrict__ x, int rows, int d,
+                                                  float eps, TOut* __restrict__ y,
+                                                  float* __restrict__ inv_norm) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const TIn* xr = x + (size_t)row * d;
+  float ss = 0.f;
+  for (int c = lane; c < d; c += 64) {
+    float v;
+    if constexpr (sizeof(TIn) == 2) v = bf2f(xr[c]); else v = xr[c];
+    ss += v * v;
+  }
+  ss = wave_sum(ss);
+  const float denom = fmaxf(sqrtf(ss), eps);  // F.normalize: x / max(||x||_2, eps)
+  for (int c = lane; c < d; c += 64) {
+    float v;
+    if constexpr (sizeof(TIn) == 2) v = bf2f(xr[c]); else v = xr[c];
+    const float o = v / denom;
+    if constexpr (sizeof(TOut) == 2) y[(size_t)row * d + c] = f2bf(o); else y[(size_t)row * d + c] = o;
+  }
+  if (inv_norm && lane == 0) inv_norm[row] = 1.0f / denom;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd(const float* __restrict__ dy,
+                                                  const float* __restrict__ y,
+                                                  const float* __restrict__ inv_norm, int rows,
+                                                  int d, float* __restrict__ dx) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (row >= rows) return;
+  const float* dyr = dy + (size_t)row * d;
+  const float* yr = y + (size_t)row * d;
+  float dot = 0.f;
+  for (int c = lane; c < d; c += 64) dot += dyr[c] * yr[c];
+  dot = wave_sum(dot);
+  const float s = inv_norm[row];
+  for (int c = lane; c < d; c += 64) dx[(size_t)row * d + c] = (dyr[c] - yr[c] * dot) * s;
+}
+
+// ------------------------------------------------------------------ NT-Xent
+constexpr int NX_RT = 32;   // local rows per block (8 per wave)
+constexpr int NX_CT = 64;   // global rows per column tile (one per lane)
+constexpr int NX_PAD = 4;   // floats of padding per column-tile row: 16-B slots rotate by 1 per row
+
+struct NxIds {
+  int self_g, pos_g;
+};
+
+__device__ __forceinline__ NxIds nx_ids(int local_row, int b_local, int b_global, int rank_offset) {
+  const int v = local_row / b_local, i = local_row - v * b_local;
+  NxIds r;
+  r.self_g = v * b_global + rank_offset + i;
+  r.pos_g = (1 - v) * b_global + rank_offset + i;
+  return r;
+}
+
+__device__ __forceinline__ void nx_load_rows(const float* __restrict__ src, int first, int count,
+                                             int limit, int d, int stride, float* dst, int tid) {
+  const int d4 = d >> 2;
+  const int total = count * d4;
+  for (int p = tid; p < total; p += 256) {
+    const int row = p / d4, c4 = p - row * d4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (first + row < limit) v = *reinterpret_cast<const float4*>(src + (size_t)(first + row) * d + c4 * 4);
+    *reinterpret_cast<float4*>(dst + (size_t)row * stride + c4 * 4) = v;
+  }
+}
+
+// dots of this wave's 8 rows against column `lane` of the staged tile
+__device__ __forceinline__ void nx_dots(const float* rowt, const float* colt, int d, int cstride,
+                                        int wave, int lane, float (&acc)[8]) {
+#pragma unroll
+  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+  const float* cp = colt + (size_t)lane * cstride;
+  const float* rp = rowt + (size_t)(wave * 8) * d;
+  for (int kk = 0; kk < d; kk += 4) {
+    const float4 c = *reinterpret_cast<const float4*>(cp + kk);
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float4 a = *reinterpret_cast<const float4*>(rp + (size_t)r * d + kk);
+      acc[r] = fmaf(a.x, c.x, acc[r]);
+      acc[r] = fmaf(a.y, c.y, acc[r]);
+      acc[r] = fmaf(a.z, c.z, acc[r]);
+      acc[r] = fmaf(a.w, c.w, acc[r]);
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ntxent_fwd_kernel(const float* __restrict__ zn,
+                                                         const float* __restrict__ zall,
+                                                         int b_local, int b_global,
+                                                         int rank_offset, int d, float temp,
+                                                         float* __restrict__ lse_out,
+                                                         float* __restrict__ loss_rows) {
+  extern __shared__ __attribute__((aligned(16))) float nx_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nlocal = 2 * b_local, nglobal = 2 * b_global;
+  const int row0 = blockIdx.x * NX_RT;
+  const int cstride = d + NX_PAD;
+  float* rowt = nx_smem;                 // [NX_RT][d]
+  float* colt = nx_smem + NX_RT * d;     // [NX_CT][d + pad]
+
+  nx_load_rows(zn, row0, NX_RT, nlocal, d, d, rowt, tid);
+
+  float m[8], l[8], pos[8];
+  int self_g[8], pos_g[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    m[r] = -INFINITY;
+    l[r] = 0.f;
+    pos[r] = 0.f;
+    const int lr = row0 + wave * 8 + r;
+    const NxIds ids = nx_ids(lr < nlocal ? lr : 0, b_local, b_global, rank_offset);
+    self_g[r] = ids.self_g;
+    pos_g[r] = ids.pos_g;
+  }
+
+  for (int j0 = 0; j0 < nglobal; j0 += NX_CT) {
+    __syncthreads();  // previous tile fully consumed (and rowt visible on the first pass)
+    nx_load_rows(zall, j0, NX_CT, nglobal, d, cstride, colt, tid);
+    __syncthreads();
+    float acc[8];
+    nx_dots(rowt, colt, d, cstride, wave, lane, acc);
+    const int g = j0 + lane;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float s = acc[r] / temp;
+      if (g == pos_g[r]) pos[r] = s;
+      if (g < nglobal && g != self_g[r]) {
+        const float mn = fmaxf(m[r], s);
+        l[r] = l[r] * __expf(m[r] - mn) + __expf(s - mn);
+        m[r] = mn;
+      }
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const float mm = wave_max(m[r]);
+    const float part = (m[r] == -INFINITY) ? 0.f : l[r] * expf(m[r] - mm);
+    const float ll = wave_sum(part);
+    const float pp = wave_sum(pos[r]);
+    const int lr = row0 + wave * 8 + r;
+    if (lane == 0 && lr < nlocal) {
+      const float lse = mm + logf(ll);
+      lse_out[lr] = lse;
+      loss_rows[lr] = lse - pp;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void ntxent_bwd_kernel(
+    const float* __restrict__ zn, const float* __restrict__ zall,
+    const float* __restrict__ lse_all, int b_local, int b_global, int rank_offset, int d,
+    float temp, float grad_scale, float* __restrict__ dzn) {
+  extern __shared__ __attribute__((aligned(16))) float nx_smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nlocal = 2 * b_local, nglobal = 2 * b_global;
+  const int row0 = blockIdx.x * NX_RT;
+  const int cstride = d + NX_PAD;
+  constexpr int MS = NX_CT + 1;
+  float* rowt = nx_smem;
+  float* colt = rowt + NX_RT * d;
+  float* mt = colt + NX_CT * cstride;  // [NX_RT][NX_CT + 1]
+
+  nx_load_rows(zn, row0, NX_RT, nlocal, d, d, rowt, tid);
+
+  float lse_i[8];
+  int self_g[8], pos_g[8];
+#pragma unroll
+  for (int r = 0; r < 8; ++r) {
+    const int lr = row0 + wave * 8 + r;
+    const NxIds ids = nx_ids(lr < nlocal ? lr : 0, b_local, b_global, rank_offset);
+    self_g[r] = ids.self_g;
+    pos_g[r] = ids.pos_g;
+    lse_i[r] = lse_all[ids.self_g];
+  }
+
+  // phase-2 ownership: row rr, float4 granules (tid&7) + 8u
+  const int rr = tid >> 3, gsel = tid & 7;
+  const int nu = d >> 5;  // float4 granules per thread (d/32)
+  float4 out[8];          // d <= 256
+#pragma unroll
+  for (int u = 0; u < 8; ++u) out[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+
+  for (int j0 = 0; j0 < nglobal; j0 += NX_CT) {
+    __syncthreads();
+    nx_load_rows(zall, j0, NX_CT, nglobal, d, cstride, colt, tid);
+    __syncthreads();
+    float acc[8];
+    nx_dots(rowt, colt, d, cstride, wave, lane, acc);
+    const int g = j0 + lane;
+    const float lse_j = g < nglobal ? lse_all[g] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const float s = acc[r] / temp;
+      float mv = 0.f;
+      if (g < nglobal && g != self_g[r]) {
+        mv = __expf(s - lse_i[r]) + __expf(s - lse_j);
+        if (g == pos_g[r]) mv -= 2.f;
+      }
+      mt[(wave * 8 + r) * MS + lane] = mv;
+    }
+    __syncthreads();
+    for (int j = 0; j < NX_CT; ++j) {
+      const float w = mt[rr * MS + j];
+      const float* cz = colt + (size_t)j * cstride + gsel * 4;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (u < nu) {
+          const float4 c = *reinterpret_cast<const float4*>(cz + u * 32);
+          out[u].x = fmaf(w, c.x, out[u].x);
+          out[u].y = fmaf(w, c.y, out[u].y);
+          out[u].z = fmaf(w, c.z, out[u].z);
+          out[u].w = fmaf(w, c.w, out[u].w);
+        }
+      }
+    }
+  }
+  const int lr = row0 + rr;
+  if (lr < nlocal) {
+    const float sc = grad_scale / temp;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      if (u < nu) {
+        float4 o = out[u];
+        o.x *= sc; o.y *= sc; o.z *= sc; o.w *= sc;
+        *reinterpret_cast<float4*>(dzn + (size_t)lr * d + gsel * 4 + u * 32) = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int wm_l2_normalize(const void* x, int in_dtype, int rows, int d, float eps, void* y,
+                               int out_dtype, float* inv_norm, void* stream) {
+  WM_REQUIRE(x && y, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && d > 0, WM_EINVAL);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int grid = wm_cdiv(rows, 4);
+  if (in_dtype == WM_F32 && out_dtype == WM_F32)
+    l2norm_fwd<float, float><<<grid, 256, 0, st>>>((const float*)x, rows, d, eps, (float*)y, inv_norm);
+  else if (in_dtype == WM_F32 && out_dtype == WM_BF16)
+    l2norm_fwd<float, uint16_t><<<grid, 256, 0, st>>>((const float*)x, rows, d, eps, (uint16_t*)y, inv_norm);
+  else if (in_dtype == WM_BF16 && out_dtype == WM_F32)
+    l2norm_fwd<uint16_t, float><<<grid, 256, 0, st>>>((const uint16_t*)x, rows, d, eps, (float*)y, inv_norm);
+  else if (in_dtype == WM_BF16 && out_dtype == WM_BF16)
+    l2norm_fwd<uint16_t, uint16_t><<<grid, 256, 0, st>>>((const uint16_t*)x, rows, d, eps, (uint16_t*)y, inv_norm);
+  else
+    return WM_EUNSUPPORTED;
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_l2_normalize_bwd(const float* dy, const float* y, const float* inv_norm, int rows,
+                                   int d, float* dx, void* stream) {
+  WM_REQUIRE(dy && y && inv_norm && dx, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && d > 0, WM_EINVAL);
+  l2norm_bwd<<<wm_cdiv(rows, 4), 256, 0, static_cast<hipStream_t>(stream)>>>(dy, y, inv_norm, rows, d, dx);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+static int nx_check(const void* a, const void* b, const void* c, const void* e, int b_local,
+                    int b_global, int rank_offset, int d, float temperature) {
+  WM_REQUIRE(a && b && c && e, WM_EINVAL);
+  WM_REQUIRE(b_local > 0 && b_global >= b_local && d > 0 && temperature > 0.f, WM_EINVAL);
+  WM_REQUIRE(rank_offset >= 0 && rank_offset + b_local <= b_global, WM_EINVAL);
+  WM_REQUIRE(d % 32 == 0 && d <= 256, WM_EUNSUPPORTED);
+  return WM_OK;
+}
+
+extern "C" int wm_ntxent_fwd(const float* zn, const float* zall, int b_local, int b_global,
+                             int rank_offset, int d, float temperature, float* lse,
+                             float* loss_rows, void* stream) {
+  const int rc = nx_check(zn, zall, lse, loss_rows, b_local, b_global, rank_offset, d, temperature);
+  if (rc != WM_OK) return rc;
+  const size_t lds = ((size_t)NX_RT * d + (size_t)NX_CT * (d + NX_PAD)) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntxent_fwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  ntxent_fwd_kernel<<<wm_cdiv(2 * b_local, NX_RT), 256, lds, static_cast<hipStream_t>(stream)>>>(
+      zn, zall, b_local, b_global, rank_offset, d, temperature, lse, loss_rows);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_ntxent_bwd(const float* zn, const float* zall, const float* lse_all, int b_local,
+                             int b_global, int rank_offset, int d, float temperature,
+                             float grad_scale, float* dzn, void* stream) {
+  const int rc = nx_check(zn, zall, lse_all, dzn, b_local, b_global, rank_offset, d, temperature);
+  if (rc != WM_OK) return rc;
+  const size_t lds =
+      ((size_t)NX_RT * d + (size_t)NX_CT * (d + NX_PAD) + (size_t)NX_RT * (NX_CT + 1)) * sizeof(float);
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntxent_bwd_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 147456);
+    if (e != hipSuccess) return (int)e;
+    attr = true;
+  }
+  ntxent_bwd_kernel<<<wm_cdiv(2 * b_local, NX_RT), 256, lds, static_cast<hipStream_t>(stream)>>>(
+      zn, zall, lse_all, b_local, b_global, rank_offset, d, temperature, grad_scale, dzn);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
