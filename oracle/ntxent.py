@@ -1,0 +1,48 @@
+"""CPU oracle for NT-Xent.  TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).
+
+Restates lightly.loss.NTXentLoss (third-party `lightly`, UNPINNED, not installed here) from its
+published algorithm (SimCLR, Chen et al. 2020, arXiv:2002.05709, with lightly's logits layout, see
+SURVEY.md Appendix A.1), anchored on the reference call site scripts/WM811k_benchmark.py:234,246.
+Parity status: PARITY UNPINNED upstream; cross-checked against a float64 closed form (tests/).
+"""
+import torch
+import torch.nn.functional as F
+
+
+def ntxent_lightly(out0, out1, temperature=0.5, out0_large=None, out1_large=None, rank=0):
+    """The [2B, 2B-1] logits construction, step by step as lightly does it.  With *_large given
+    (all-gathered, rank-major) this is the gather_distributed=True branch for `rank`."""
+    batch_size = out0.shape[0]
+    out0 = F.normalize(out0, dim=1)
+    out1 = F.normalize(out1, dim=1)
+    if out0_large is None:
+        out0_large, out1_large = out0, out1
+        diag_mask = torch.eye(batch_size, dtype=torch.bool)
+    else:
+        out0_large = F.normalize(out0_large, dim=1)
+        out1_large = F.normalize(out1_large, dim=1)
+        world = out0_large.shape[0] // batch_size
+        diag_mask = torch.zeros(batch_size, batch_size * world, dtype=torch.bool)
+        diag_mask[:, rank * batch_size : (rank + 1) * batch_size] = torch.eye(batch_size, dtype=torch.bool)
+    logits_00 = torch.einsum("nc,mc->nm", out0, out0_large) / temperature
+    logits_01 = torch.einsum("nc,mc->nm", out0, out1_large) / temperature
+    logits_10 = torch.einsum("nc,mc->nm", out1, out0_large) / temperature
+    logits_11 = torch.einsum("nc,mc->nm", out1, out1_large) / temperature
+    logits_00 = logits_00[~diag_mask].view(batch_size, -1)
+    logits_11 = logits_11[~diag_mask].view(batch_size, -1)
+    logits_0100 = torch.cat([logits_01, logits_00], dim=1)
+    logits_1011 = torch.cat([logits_10, logits_11], dim=1)
+    logits = torch.cat([logits_0100, logits_1011], dim=0)
+    labels = torch.arange(batch_size, dtype=torch.long) + rank * batch_size
+    labels = labels.repeat(2)
+    return F.cross_entropy(logits, labels, reduction="mean")
+
+
+def ntxent_closed_form_f64(out0, out1, temperature=0.5):
+    z = F.normalize(torch.cat([out0, out1]).double(), dim=1)
+    n = z.shape[0]
+    b = n // 2
+    s = z @ z.t() / temperature
+    s.fill_diagonal_(float("-inf"))
+    pos = torch.cat([torch.arange(b, n), torch.arange(0, b)])
+    return (torch.logsumexp(s, dim=1) - s[torch.arange(n), pos]).mean()

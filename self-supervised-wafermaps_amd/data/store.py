@@ -1,0 +1,53 @@
+"""WaferStore: the ragged wafer-map collection as flat, HBM-resident arrays.
+
+The reference keeps a Python list of variable-size uint8 tensors (src/ssl_wafermap/data/dataset.py:
+18-21) and augments one item at a time in DataLoader workers.  Here the whole collection is one
+uint8 byte string + offsets/heights/widths on the device (all of WM-811K is ~1.2 GB, a rounding
+error in 288 GB of HBM), which the augmentation kernel indexes directly.
+"""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import numpy as np
+import torch
+
+
+class WaferStore:
+    def __init__(self, wafers: Sequence, device: Optional[torch.device] = None):
+        arrays = [np.ascontiguousarray(np.asarray(w), dtype=np.uint8) for w in wafers]
+        if not arrays:
+            raise ValueError("WaferStore: empty collection")
+        for a in arrays:
+            if a.ndim != 2 or a.shape[0] < 1 or a.shape[1] < 1 or max(a.shape) > 256:
+                raise ValueError(f"WaferStore: wafer maps must be 2-D with sides in [1, 256], got {a.shape}")
+        self.heights_np = np.array([a.shape[0] for a in arrays], dtype=np.int32)
+        self.widths_np = np.array([a.shape[1] for a in arrays], dtype=np.int32)
+        sizes = self.heights_np.astype(np.int64) * self.widths_np.astype(np.int64)
+        self.offsets_np = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        self.bytes_np = np.concatenate([a.reshape(-1) for a in arrays])
+        self.max_elems = int(sizes.max())
+        self.n = len(arrays)
+        self.device = None
+        self.bytes = self.offsets = self.heights = self.widths = None
+        if device is not None:
+            self.to(device)
+
+    def to(self, device) -> "WaferStore":
+        device = torch.device(device)
+        self.bytes = torch.from_numpy(self.bytes_np).to(device)
+        self.offsets = torch.from_numpy(self.offsets_np).to(device)
+        self.heights = torch.from_numpy(self.heights_np).to(device)
+        self.widths = torch.from_numpy(self.widths_np).to(device)
+        self.device = device
+        return self
+
+    def __len__(self) -> int:
+        return self.n
+
+    def wafer(self, i: int) -> np.ndarray:
+        h, w, o = int(self.heights_np[i]), int(self.widths_np[i]), int(self.offsets_np[i])
+        return self.bytes_np[o : o + h * w].reshape(h, w)
+
+    def nbytes(self) -> int:
+        return int(self.bytes_np.nbytes)

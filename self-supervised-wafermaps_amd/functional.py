@@ -1,0 +1,147 @@
+"""Tensor-level entry points over the wafer_hip C ABI (include/wafer_hip.h).
+
+Each function checks shapes on the host (a faulting kernel can take the whole node down), passes
+raw device pointers + the current HIP stream to the library and raises on any non-zero return.
+There is no CPU fallback.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib
+from ._lib import check, dtype_code, ptr, require_gpu, stream_ptr
+
+# --------------------------------------------------------------------------------------- kNN
+
+
+def knn_topk(query: torch.Tensor, bank: torch.Tensor, k: int, index_base: int = 0,
+             workspace: Optional[torch.Tensor] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Top-k inner products of every query row against every bank row.
+
+    query [nq, d], bank [n, d] (both float32 or both bfloat16, row-major, d*itemsize % 256 == 0).
+    Returns (sim [nq, k] float32 descending, idx [nq, k] int32).  Replaces the
+    `torch.mm(feature, feature_bank)` + `.topk(k)` pair inside lightly's knn_predict
+    (reference call site src/ssl_wafermap/models/knn.py:91-98)."""
+    require_gpu(query, bank)
+    if query.dim() != 2 or bank.dim() != 2 or query.shape[1] != bank.shape[1]:
+        raise ValueError(f"knn_topk: query {tuple(query.shape)} vs bank {tuple(bank.shape)}")
+    if query.dtype != bank.dtype:
+        raise ValueError("knn_topk: query and bank must share a dtype")
+    nq, d = query.shape
+    n = bank.shape[0]
+    lib = _lib.load()
+    need = lib.wm_knn_topk_workspace_bytes(nq, n, d, k)
+    if need == 0:
+        raise ValueError(f"knn_topk: unsupported sizes nq={nq} n={n} d={d} k={k}")
+    if workspace is None or workspace.numel() * workspace.element_size() < need:
+        workspace = torch.empty(need, dtype=torch.uint8, device=query.device)
+    sim = torch.empty((nq, k), dtype=torch.float32, device=query.device)
+    idx = torch.empty((nq, k), dtype=torch.int32, device=query.device)
+    check(lib.wm_knn_topk(ptr(query), ptr(bank), nq, n, d, dtype_code(query), k, index_base, ptr(sim),
+                          ptr(idx), ptr(workspace), workspace.numel() * workspace.element_size(),
+                          stream_ptr()), "wm_knn_topk")
+    return sim, idx
+
+
+def knn_merge(sim_parts: torch.Tensor, idx_parts: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Merge [parts, nq, k] candidate lists (e.g. all-gathered shard results) into [nq, k]."""
+    require_gpu(sim_parts, idx_parts)
+    parts, nq, k = sim_parts.shape
+    if idx_parts.shape != sim_parts.shape or sim_parts.dtype != torch.float32 or idx_parts.dtype != torch.int32:
+        raise ValueError("knn_merge: need float32 sims and int32 indices of equal shape")
+    sim = torch.empty((nq, k), dtype=torch.float32, device=sim_parts.device)
+    idx = torch.empty((nq, k), dtype=torch.int32, device=sim_parts.device)
+    check(_lib.load().wm_knn_merge(ptr(sim_parts), ptr(idx_parts), parts, nq, k, ptr(sim), ptr(idx),
+                                   stream_ptr()), "wm_knn_merge")
+    return sim, idx
+
+
+def knn_vote(sim: torch.Tensor, idx: torch.Tensor, bank_labels: torch.Tensor, num_classes: int,
+             knn_t: float, return_scores: bool = False):
+    """exp(sim/t)-weighted class vote; returns pred_labels [nq, num_classes] int64 (classes by
+    descending score), as lightly's knn_predict does."""
+    require_gpu(sim, idx, bank_labels)
+    if bank_labels.dtype != torch.int64:
+        raise ValueError("knn_vote: bank_labels must be int64")
+    nq, k = sim.shape
+    pred = torch.empty((nq, num_classes), dtype=torch.int64, device=sim.device)
+    scores = torch.empty((nq, num_classes), dtype=torch.float32, device=sim.device) if return_scores else None
+    check(_lib.load().wm_knn_vote(ptr(sim), ptr(idx), ptr(bank_labels), nq, k, num_classes, float(knn_t),
+                                  ptr(pred), ptr(scores), stream_ptr()), "wm_knn_vote")
+    return (pred, scores) if return_scores else pred
+
+
+# --------------------------------------------------------------------------------------- L2 norm
+
+
+class _L2Normalize(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, eps):
+        require_gpu(x)
+        rows, d = x.shape
+        y = torch.empty((rows, d), dtype=torch.float32, device=x.device)
+        inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
+        check(_lib.load().wm_l2_normalize(ptr(x), dtype_code(x), rows, d, float(eps), ptr(y), _lib.WM_F32,
+                                          ptr(inv), stream_ptr()), "wm_l2_normalize")
+        ctx.save_for_backward(y, inv)
+        ctx.in_dtype = x.dtype
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dy = dy.contiguous().float()
+        dx = torch.empty_like(y)
+        check(_lib.load().wm_l2_normalize_bwd(ptr(dy), ptr(y), ptr(inv), y.shape[0], y.shape[1], ptr(dx),
+                                              stream_ptr()), "wm_l2_normalize_bwd")
+        return dx.to(ctx.in_dtype), None
+
+
+def l2_normalize(x: torch.Tensor, eps: float = 1e-12, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """torch.nn.functional.normalize(x, dim=1) for a 2-D tensor.  With out_dtype=None the result is
+    float32 and differentiable; with out_dtype=torch.bfloat16 it is an inference-only cast (the
+    kNN bank build, reference src/ssl_wafermap/models/knn.py:76-80)."""
+    if x.dim() != 2:
+        raise ValueError("l2_normalize expects [rows, d]")
+    x = x.contiguous()
+    if out_dtype is None or out_dtype == torch.float32:
+        return _L2Normalize.apply(x, eps)
+    require_gpu(x)
+    rows, d = x.shape
+    y = torch.empty((rows, d), dtype=out_dtype, device=x.device)
+    check(_lib.load().wm_l2_normalize(ptr(x), dtype_code(x), rows, d, float(eps), ptr(y), dtype_code(y), 0,
+                                      stream_ptr()), "wm_l2_normalize")
+    return y
+
+
+# --------------------------------------------------------------------------------------- NT-Xent
+
+
+def ntxent_forward(zn: torch.Tensor, zall: torch.Tensor, b_local: int, b_global: int, rank_offset: int,
+                   temperature: float):
+    """zn [2*b_local, d], zall [2*b_global, d] float32 L2-normalised rows (view-major).
+    Returns (lse [2*b_local], loss_rows [2*b_local])."""
+    require_gpu(zn, zall)
+    d = zn.shape[1]
+    if zn.shape != (2 * b_local, d) or zall.shape != (2 * b_global, d) or zn.dtype != torch.float32 \
+            or zall.dtype != torch.float32:
+        raise ValueError("ntxent_forward: shape/dtype mismatch")
+    lse = torch.empty((2 * b_local,), dtype=torch.float32, device=zn.device)
+    rows = torch.empty_like(lse)
+    check(_lib.load().wm_ntxent_fwd(ptr(zn), ptr(zall), b_local, b_global, rank_offset, d, float(temperature),
+                                    ptr(lse), ptr(rows), stream_ptr()), "wm_ntxent_fwd")
+    return lse, rows
+
+
+def ntxent_backward(zn: torch.Tensor, zall: torch.Tensor, lse_all: torch.Tensor, b_local: int, b_global: int,
+                    rank_offset: int, temperature: float, grad_scale: float) -> torch.Tensor:
+    require_gpu(zn, zall, lse_all)
+    d = zn.shape[1]
+    if lse_all.shape != (2 * b_global,) or lse_all.dtype != torch.float32:
+        raise ValueError("ntxent_backward: lse_all must be float32 [2*b_global]")
+    dzn = torch.empty_like(zn)
+    check(_lib.load().wm_ntxent_bwd(ptr(zn), ptr(zall), ptr(lse_all), b_local, b_global, rank_offset, d,
+                                    float(temperature), float(grad_scale), ptr(dzn), stream_ptr()), "wm_ntxent_bwd")
+    return dzn

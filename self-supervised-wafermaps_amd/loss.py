@@ -1,0 +1,75 @@
+"""Losses with lightly's call signatures, computed by the wafer_hip kernels.
+
+NTXentLoss mirrors lightly.loss.NTXentLoss as the reference constructs and calls it
+(scripts/WM811k_benchmark.py:234,246: `NTXentLoss()` -> temperature 0.5, no memory bank,
+gather_distributed False; `loss = criterion(z0, z1)`)."""
+from __future__ import annotations
+
+import torch
+import torch.distributed as dist
+import torch.nn as nn
+
+from . import functional as F_hip
+
+
+def _world():
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def _all_gather_rows(x: torch.Tensor) -> torch.Tensor:
+    """[r, ...] per rank -> [world*r, ...] (rank-major), no gradient (the kernels provide the
+    GatherLayer gradient analytically)."""
+    out = [torch.empty_like(x) for _ in range(_world())]
+    dist.all_gather(out, x.contiguous())
+    return torch.cat(out, dim=0)
+
+
+class _NTXentCore(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, zn, b_local, temperature, gather):
+        world = _world() if gather else 1
+        rank = dist.get_rank() if world > 1 else 0
+        b_global = b_local * world
+        if world > 1:
+            zall = torch.cat([_all_gather_rows(zn[:b_local]), _all_gather_rows(zn[b_local:])], dim=0)
+        else:
+            zall = zn
+        lse, rows = F_hip.ntxent_forward(zn, zall, b_local, b_global, rank * b_local, temperature)
+        if world > 1:
+            lse_all = torch.cat([_all_gather_rows(lse[:b_local]), _all_gather_rows(lse[b_local:])], dim=0)
+        else:
+            lse_all = lse
+        ctx.save_for_backward(zn, zall, lse_all)
+        ctx.meta = (b_local, b_global, rank * b_local, temperature)
+        return rows.mean()
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        zn, zall, lse_all = ctx.saved_tensors
+        b_local, b_global, off, temperature = ctx.meta
+        dzn = F_hip.ntxent_backward(zn, zall, lse_all, b_local, b_global, off, temperature, 1.0 / (2 * b_local))
+        return dzn * grad_out, None, None, None
+
+
+class NTXentLoss(nn.Module):
+    """Contrastive cross-entropy over all pairs of the two views' batches (SimCLR).
+
+    Same constructor and call as lightly.loss.NTXentLoss.  The MoCo memory-bank variant
+    (memory_bank_size > 0) is not built yet and fails loudly."""
+
+    def __init__(self, temperature: float = 0.5, memory_bank_size: int = 0, gather_distributed: bool = False):
+        super().__init__()
+        if abs(temperature) < 1e-8:
+            raise ValueError(f"Illegal temperature: abs({temperature}) < 1e-8")
+        if memory_bank_size:
+            raise NotImplementedError("NTXentLoss with a memory bank (MoCo) has no HIP path yet")
+        self.temperature = float(temperature)
+        self.gather_distributed = bool(gather_distributed)
+
+    def forward(self, out0: torch.Tensor, out1: torch.Tensor) -> torch.Tensor:
+        if out0.shape != out1.shape or out0.dim() != 2:
+            raise ValueError("NTXentLoss expects two [batch, dim] tensors of equal shape")
+        b = out0.shape[0]
+        z = torch.cat([out0, out1], dim=0).float().contiguous()
+        zn = F_hip.l2_normalize(z)
+        return _NTXentCore.apply(zn, b, self.temperature, self.gather_distributed)

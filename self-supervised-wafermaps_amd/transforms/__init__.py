@@ -1,0 +1,5 @@
+from .augmentations import (  # noqa: F401
+    DieNoise, DPWTransform, MedianFilter, RandomOneOf, ViewSpec, augment_views, get_base_transforms,
+    get_inference_transforms, multicrop_view, sample_view_params,
+)
+from .utils import NORMALIZE_STATS  # noqa: F401

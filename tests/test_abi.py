@@ -1,0 +1,94 @@
+"""CPU checks of the drop-in boundary: libwafer_hip.so loads and exports exactly what
+include/wafer_hip.h declares; the ctypes table matches the header; no compute is launched."""
+import ctypes
+import re
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+HEADER = ROOT / "include" / "wafer_hip.h"
+
+
+def _declared():
+    text = re.sub(r"/\*.*?\*/", "", HEADER.read_text(), flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|size_t|const char\s*\*)\s+(wm_\w+)\s*\(([^;]*?)\)\s*;", text, flags=re.S):
+        args = [a.strip() for a in m.group(2).split(",") if a.strip() and a.strip() != "void"]
+        decls[m.group(1)] = len(args)
+    return decls
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from ssl_wafermap_amd import _lib
+
+    if not _lib.LIB_PATH.exists():
+        from importlib import import_module
+
+        import_module("ssl_wafermap_amd.build").build(verbose=False)
+    return _lib.load()
+
+
+def test_header_declares_entry_points():
+    d = _declared()
+    for name in ("wm_version", "wm_augment_views", "wm_knn_topk", "wm_ntxent_fwd", "wm_ntxent_bwd"):
+        assert name in d
+
+
+def test_library_exports_every_declared_symbol(lib):
+    for name in _declared():
+        assert hasattr(lib, name), f"libwafer_hip.so does not export {name}"
+
+
+def test_ctypes_table_matches_header(lib):
+    from ssl_wafermap_amd import _lib
+
+    d = _declared()
+    assert set(d) == set(_lib.SIGNATURES), set(d) ^ set(_lib.SIGNATURES)
+    for name, nargs in d.items():
+        assert len(_lib.SIGNATURES[name][1]) == nargs, name
+
+
+def test_version_and_error_strings(lib):
+    from ssl_wafermap_amd import _lib
+
+    assert lib.wm_version() == 1
+    assert b"unsupported" in lib.wm_error_string(-2)
+    with pytest.raises(_lib.WaferHipError):
+        _lib.check(-1, "probe")
+
+
+def test_struct_layout_matches_header():
+    from ssl_wafermap_amd import _lib
+    from ssl_wafermap_amd.transforms.augmentations import PARAM_DTYPE
+
+    assert ctypes.sizeof(_lib.WmViewParams) == 64 == PARAM_DTYPE.itemsize
+    assert [f[0] for f in _lib.WmViewParams._fields_] == list(PARAM_DTYPE.names)
+    for name, _ in _lib.WmViewParams._fields_:
+        assert getattr(_lib.WmViewParams, name).offset == PARAM_DTYPE.fields[name][1]
+
+
+def test_argument_validation_needs_no_gpu(lib):
+    # null pointers / bad sizes are rejected before any launch
+    assert lib.wm_knn_topk(None, None, 1, 1, 128, 0, 1, 0, None, None, None, 0, None) == -1
+    assert lib.wm_knn_topk_workspace_bytes(64, 1000, 128, 99) == 0
+    assert lib.wm_knn_topk_workspace_bytes(64, 1000, 128, 5) > 0
+    assert lib.wm_ntxent_fwd(None, None, 4, 4, 0, 128, 0.5, None, None, None) == -1
+
+
+def test_product_path_fails_loudly_without_gpu_tensors():
+    import torch
+
+    from ssl_wafermap_amd import _lib
+    from ssl_wafermap_amd import functional as F
+
+    with pytest.raises(_lib.WaferHipError):
+        F.knn_topk(torch.zeros(4, 128), torch.zeros(16, 128), 2)
+
+
+def test_missing_library_is_an_error(tmp_path):
+    from ssl_wafermap_amd import _lib
+
+    with pytest.raises(_lib.WaferHipError):
+        _lib.load(tmp_path / "nope.so")

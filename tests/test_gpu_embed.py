@@ -1,0 +1,209 @@
+"""GPU parity: kNN top-k / vote, L2 normalise and NT-Xent HIP kernels against the CPU oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import knn as ok
+from oracle import ntxent as on
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+def _check_topk(sim, idx, sim_ref, idx_ref, full_sim_ref, tol):
+    """Indices must agree wherever the reference ranking is decided by more than `tol`."""
+    sim, idx = sim.cpu(), idx.cpu().long()
+    torch.testing.assert_close(sim, sim_ref, atol=tol, rtol=0)
+    # every returned index carries the similarity the reference assigns to it
+    got = torch.gather(full_sim_ref, 1, idx)
+    torch.testing.assert_close(got, sim_ref, atol=tol, rtol=0)
+    k = sim_ref.shape[1]
+    kth_gap = torch.ones(sim_ref.shape[0], dtype=torch.bool) if full_sim_ref.shape[1] == k else \
+        (sim_ref[:, -1] - full_sim_ref.topk(k + 1, dim=1).values[:, -1]) > 4 * tol
+    gaps = (sim_ref[:, :-1] - sim_ref[:, 1:]) > 4 * tol
+    decided = gaps.all(1) & kth_gap
+    assert decided.float().mean() > 0.5
+    assert torch.equal(idx[decided], idx_ref[decided])
+    assert (sim[:, :-1] >= sim[:, 1:]).all()
+
+
+@pytest.mark.parametrize("nq,n,d,k", [(64, 9959, 512, 5), (33, 129, 128, 8), (1, 5, 64, 5), (70, 4000, 128, 10)])
+def test_knn_topk_f32(nq, n, d, k):
+    from ssl_wafermap_amd import functional as F
+
+    g = torch.Generator().manual_seed(nq + n)
+    bank = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1)
+    full = q @ bank.t()
+    sim_ref, idx_ref = full.topk(k, dim=1)
+    sim, idx = F.knn_topk(q.to(_dev()), bank.to(_dev()), k)
+    _check_topk(sim, idx, sim_ref, idx_ref, full, 2e-6)
+
+
+@pytest.mark.parametrize("nq,n,d,k", [(256, 50000, 128, 8), (64, 12449, 512, 5), (100, 3000, 256, 16)])
+def test_knn_topk_bf16(nq, n, d, k):
+    from ssl_wafermap_amd import functional as F
+
+    g = torch.Generator().manual_seed(7)
+    bank = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).bfloat16()
+    q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1).bfloat16()
+    full = q.float() @ bank.float().t()  # exact products of the bf16 values, f32 accumulation
+    sim_ref, idx_ref = full.topk(k, dim=1)
+    sim, idx = F.knn_topk(q.to(_dev()), bank.to(_dev()), k)
+    _check_topk(sim, idx, sim_ref, idx_ref, full, 3e-6)
+    # and against the f32 features: within the north-star's 1e-3 cosine
+    assert (sim.cpu() - sim_ref).abs().max() < 1e-3
+
+
+def test_knn_duplicates_tie_break_lower_index():
+    from ssl_wafermap_amd import functional as F
+
+    g = torch.Generator().manual_seed(3)
+    base = torch.nn.functional.normalize(torch.randn(300, 128, generator=g), dim=1)
+    bank = torch.cat([base, base, base])  # every row appears three times
+    sim, idx = F.knn_topk(base[:40].contiguous().to(_dev()), bank.to(_dev()), 3)
+    idx = idx.cpu()
+    for i in range(40):
+        assert idx[i].tolist() == [i, i + 300, i + 600]
+
+
+def test_knn_sharded_merge_equals_unsharded():
+    from ssl_wafermap_amd import functional as F
+
+    g = torch.Generator().manual_seed(4)
+    bank = torch.nn.functional.normalize(torch.randn(4096 + 77, 128, generator=g), dim=1).to(_dev())
+    q = torch.nn.functional.normalize(torch.randn(48, 128, generator=g), dim=1).to(_dev())
+    sim, idx = F.knn_topk(q, bank, 5)
+    bounds = [0, 1000, 2048, 3000, bank.shape[0]]
+    parts = [F.knn_topk(q, bank[a:b].contiguous(), 5, index_base=a) for a, b in zip(bounds[:-1], bounds[1:])]
+    msim, midx = F.knn_merge(torch.stack([p[0] for p in parts]), torch.stack([p[1] for p in parts]))
+    assert torch.equal(midx, idx) and torch.equal(msim, sim)
+
+
+def test_knn_predict_matches_oracle():
+    from ssl_wafermap_amd.utils.benchmarking import knn_predict
+
+    g = torch.Generator().manual_seed(5)
+    feats = torch.randn(9959, 512, generator=g)
+    labels = torch.randint(0, 9, (9959,), generator=g)
+    # clustered features so that the vote is meaningful
+    feats += 3 * torch.nn.functional.one_hot(labels, 512).float()
+    bank = ok.build_bank(feats)  # [D, N]
+    q = torch.nn.functional.normalize(feats[:64] + 0.1 * torch.randn(64, 512, generator=g), dim=1)
+    ref = ok.knn_predict(q, bank, labels, 9, 5, 0.1)
+    bank_nd = bank.t().contiguous().to(_dev())
+    got = knn_predict(q.to(_dev()), bank_nd.t(), labels.to(_dev()), 9, 5, 0.1).cpu()
+    assert torch.equal(got[:, 0], ref[:, 0])
+    sim, idx = ok.knn_topk(q, bank, 5)
+    scores = ok.knn_scores(sim, idx, labels, 9, 0.1)
+    from ssl_wafermap_amd import functional as F
+
+    s2, i2 = F.knn_topk(q.to(_dev()), bank_nd, 5)
+    _, sc = F.knn_vote(s2, i2, labels.to(_dev()), 9, 0.1, return_scores=True)
+    torch.testing.assert_close(sc.cpu(), scores, rtol=2e-4, atol=1e-3)
+
+
+def test_knn_full_size_properties():
+    """BASELINE scale (811 457 x 128, bf16): self-retrieval, sortedness, spot check vs CPU."""
+    from ssl_wafermap_amd import functional as F
+
+    n, d = 811457, 128
+    g = torch.Generator(device="cuda").manual_seed(7)
+    bank = torch.nn.functional.normalize(torch.randn(n, d, generator=g, device=_dev()), dim=1).bfloat16()
+    rows = torch.tensor([0, 1, 127, 128, 4095, 400000, 811455, 811456], device=_dev())
+    q = torch.cat([bank[rows], bank[100000:100056]]).contiguous()
+    sim, idx = F.knn_topk(q, bank, 8)
+    assert torch.equal(idx[:8, 0].long(), rows)
+    assert (sim[:, 0] > 0.99).all() and (sim[:, :-1] >= sim[:, 1:]).all()
+    assert int(idx.min()) >= 0 and int(idx.max()) < n
+    full = (q[:4].float().cpu() @ bank.float().cpu().t())
+    sref, iref = full.topk(8, dim=1)
+    torch.testing.assert_close(sim[:4].cpu(), sref, atol=3e-6, rtol=0)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_l2_normalize(dtype):
+    from ssl_wafermap_amd import functional as F
+
+    g = torch.Generator().manual_seed(0)
+    x = (torch.randn(300, 512, generator=g) * 3).to(dtype)
+    x[7] = 0  # zero row: eps clamp
+    ref = torch.nn.functional.normalize(x.float(), dim=1)
+    y = F.l2_normalize(x.to(_dev()))
+    torch.testing.assert_close(y.cpu(), ref, atol=1e-6, rtol=1e-6)
+    yb = F.l2_normalize(x.to(_dev()), out_dtype=torch.bfloat16)
+    torch.testing.assert_close(yb.cpu().float(), ref.bfloat16().float(), atol=1e-2, rtol=0)
+
+
+def test_l2_normalize_backward():
+    from ssl_wafermap_amd import functional as F
+
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(64, 128, generator=g)
+    w = torch.randn(64, 128, generator=g)
+    xr = x.clone().requires_grad_(True)
+    (torch.nn.functional.normalize(xr, dim=1) * w).sum().backward()
+    xd = x.to(_dev()).requires_grad_(True)
+    (F.l2_normalize(xd) * w.to(_dev())).sum().backward()
+    torch.testing.assert_close(xd.grad.cpu(), xr.grad, atol=1e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("b,d,t", [(64, 128, 0.5), (256, 128, 0.5), (37, 64, 0.1), (8, 256, 0.07)])
+def test_ntxent_loss_and_grad(b, d, t):
+    from ssl_wafermap_amd.loss import NTXentLoss
+
+    g = torch.Generator().manual_seed(b)
+    z0, z1 = torch.randn(b, d, generator=g), torch.randn(b, d, generator=g)
+    r0, r1 = z0.clone().requires_grad_(True), z1.clone().requires_grad_(True)
+    ref = on.ntxent_lightly(r0, r1, t)
+    ref.backward()
+    d0, d1 = z0.to(_dev()).requires_grad_(True), z1.to(_dev()).requires_grad_(True)
+    loss = NTXentLoss(temperature=t)(d0, d1)
+    loss.backward()
+    assert abs(loss.item() - ref.item()) / abs(ref.item()) < 1e-5  # north-star: 1e-4 relative
+    c64 = on.ntxent_closed_form_f64(z0, z1, t).item()
+    assert abs(loss.item() - c64) / abs(c64) < 1e-5
+    scale = r0.grad.abs().max().item()
+    torch.testing.assert_close(d0.grad.cpu(), r0.grad, atol=2e-5 * scale, rtol=1e-4)
+    torch.testing.assert_close(d1.grad.cpu(), r1.grad, atol=2e-5 * scale, rtol=1e-4)
+
+
+def test_ntxent_gathered_semantics_single_process():
+    """Kernel with b_global > b_local == lightly's gather_distributed branch incl. GatherLayer grads."""
+    from ssl_wafermap_amd import functional as F
+
+    g = torch.Generator().manual_seed(9)
+    world, b, d, t = 2, 8, 64, 0.5
+    z0, z1 = torch.randn(world * b, d, generator=g), torch.randn(world * b, d, generator=g)
+    zr0, zr1 = z0.clone().requires_grad_(True), z1.clone().requires_grad_(True)
+    losses = [on.ntxent_lightly(zr0[r * b:(r + 1) * b], zr1[r * b:(r + 1) * b], t, zr0, zr1, rank=r) for r in range(world)]
+    torch.stack(losses).sum().backward()  # GatherLayer.backward all-reduces (sums) over ranks
+    zn_all = torch.nn.functional.normalize(torch.cat([z0, z1]), dim=1).to(_dev())  # [2][Bg]
+    zn_all.requires_grad_(False)
+    lse_parts, row_parts = [], []
+    for r in range(world):
+        zn_loc = torch.cat([zn_all[r * b:(r + 1) * b], zn_all[world * b + r * b: world * b + (r + 1) * b]]).contiguous()
+        lse, rows = F.ntxent_forward(zn_loc, zn_all, b, world * b, r * b, t)
+        assert abs(rows.mean().item() - losses[r].item()) / losses[r].item() < 1e-5
+        lse_parts.append(lse)
+    lse_all = torch.cat([torch.cat([p[:b] for p in lse_parts]), torch.cat([p[b:] for p in lse_parts])])
+    # reference gradient wrt the normalised rows of rank 1
+    zn_ref = torch.nn.functional.normalize(torch.cat([z0, z1]), dim=1).clone().requires_grad_(True)
+
+    def total(zn):
+        n0, n1 = zn[: world * b], zn[world * b:]
+        return sum(on.ntxent_lightly(n0[r * b:(r + 1) * b], n1[r * b:(r + 1) * b], t, n0, n1, rank=r) for r in range(world))
+
+    # normalising already-normalised rows is the identity up to rounding but its Jacobian projects;
+    # compare in the tangent space instead: project both gradients
+    total(zn_ref).backward()
+    r = 1
+    zn_loc = torch.cat([zn_all[r * b:(r + 1) * b], zn_all[world * b + r * b: world * b + (r + 1) * b]]).contiguous()
+    dzn = F.ntxent_backward(zn_loc, zn_all, lse_all, b, world * b, r * b, t, 1.0 / (2 * b)).cpu()
+    zl = zn_loc.cpu()
+    dzn_proj = dzn - zl * (dzn * zl).sum(1, keepdim=True)
+    gref = torch.cat([zn_ref.grad[r * b:(r + 1) * b], zn_ref.grad[world * b + r * b: world * b + (r + 1) * b]])
+    torch.testing.assert_close(dzn_proj, gref, atol=2e-6, rtol=1e-4)
