@@ -154,6 +154,78 @@ int wm_ntxent_bwd(const float* zn, const float* zall, const float* lse_all, int 
                   int b_global, int rank_offset, int d, float temperature, float grad_scale,
                   float* dzn, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * ResNet-18 / projection-head building blocks: bf16 NHWC activations, f32
+ * accumulation, f32 parameters.  They replace the cuDNN/ATen kernels behind
+ *   timm.create_model("resnet18", num_classes=0)      scripts/WM811k_benchmark.py:231
+ *   heads.SimCLRProjectionHead(512, 512, 128)          scripts/WM811k_benchmark.py:233
+ *   SimCLR.forward / training_step                     scripts/WM811k_benchmark.py:236-248
+ *   torch.optim.SGD(lr, momentum 0.9, wd 5e-4)         scripts/WM811k_benchmark.py:250-255
+ * Geometry arguments always describe the FORWARD convolution: input x [N][H][W][C], output
+ * y [N][P][Q][K], filter R x S, stride 1|2, zero padding `pad`.
+ * ------------------------------------------------------------------------------------------- */
+
+/* y = conv(x, w): w_krsc bf16 [K][R][S][C].  K % 64 == 0; C % 64 == 0, or C == 16 with S == 4
+ * (the space-to-depth stem).  A Linear layer is the 1x1 convolution with H = W = P = Q = 1. */
+int wm_conv2d_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
+                  int R, int S, int P, int Q, int stride, int pad, void* stream);
+/* dx = conv_transpose(dy, w): w_crsk bf16 [C][R][S][K]; C % 64 == 0. */
+int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W, int C, int K,
+                    int R, int S, int P, int Q, int stride, int pad, void* stream);
+/* dw_krsc (f32 [K][R][S][C]) += sum over pixels of dy (x) x; split-K partials are combined with
+ * f32 atomics, so the caller zeroes dw_krsc first and the low bits depend on arrival order. */
+int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_krsc, int N, int H, int W, int C, int K,
+                    int R, int S, int P, int Q, int stride, int pad, void* stream);
+
+/* f32 OIHW master weights -> bf16 [K][R][S][C] and/or [C][R][S][K] (either may be NULL). */
+int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int S, void* w_krsc, void* w_crsk,
+                       void* stream);
+/* wgrad accumulator [K][R][S][C] f32 -> OIHW gradient (= or +=). */
+int wm_wgrad_finalize(const float* dw_krsc, int K, int C, int R, int S, float* grad_oihw,
+                      int accumulate, void* stream);
+/* The 7x7/2 pad-3 stem on 3 channels run as a 4x4/1 pad-2 convolution over the 2x2 space-to-depth
+ * image [N][H/2][W/2][16] (channel (dh*2+dw)*3+c, 12 used): weights [K][3][7][7] f32 ->
+ * [K][4][4][16] bf16, its gradient back, and the image transform (fmt WM_IMG_NCHW_F32 or
+ * WM_IMG_NHWC_BF16 with 3 channels). */
+int wm_stem_weights_prepare(const float* w_oihw, int K, void* w_s2d, void* stream);
+int wm_stem_wgrad_finalize(const float* dw_s2d, int K, float* grad_oihw, int accumulate, void* stream);
+int wm_image_to_s2d(const void* img, int fmt, int N, int H, int W, void* out, void* stream);
+int wm_cast_f32_bf16(const float* x, long long n, void* y, void* stream);
+
+/* BatchNorm over a [rows][C] bf16 tensor cut into G equal row groups with independent statistics
+ * (G = 2 reproduces the reference's two separate forward(x0), forward(x1) calls on the
+ * concatenated batch).  out = relu?(bn(y) (+ residual)).  running_* are updated once per group in
+ * order (torch momentum convention, unbiased variance); save_mean/save_invstd are [G][C].
+ * C % 8 == 0, C <= 2048, rows % G == 0. */
+size_t wm_bn_workspace_bytes(long long rows, int C, int G);
+int wm_bn_train_fwd(const void* y, const void* residual, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, long long rows, int C, int G, float eps,
+                    float momentum, int relu, float* save_mean, float* save_invstd, void* out,
+                    void* workspace, size_t workspace_bytes, void* stream);
+int wm_bn_eval_fwd(const void* y, const void* residual, const float* gamma, const float* beta,
+                   const float* running_mean, const float* running_var, long long rows, int C, float eps,
+                   int relu, void* out, void* workspace, size_t workspace_bytes, void* stream);
+/* dz = dout * (out_relu > 0) (out_relu NULL: no ReLU); dy = dBN(dz); dgamma/dbeta (= or +=);
+ * dz is also written when non-NULL (the gradient of the residual branch). */
+int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, const float* gamma,
+                    const float* save_mean, const float* save_invstd, long long rows, int C, int G,
+                    float* dgamma, float* dbeta, int accumulate, void* dy, void* dz, void* workspace,
+                    size_t workspace_bytes, void* stream);
+int wm_add_bf16(const void* a, const void* b, long long n, void* out, void* stream);
+
+/* MaxPool2d(3, stride 2, padding 1) with recorded window positions (uint8, first maximum in scan
+ * order as torch does), and global average pooling [N][HW][C] -> [N][C]. */
+int wm_maxpool3x3s2_fwd(const void* x, int N, int H, int W, int C, void* y, void* idx, void* stream);
+int wm_maxpool3x3s2_bwd(const void* dy, const void* idx, int N, int H, int W, int C, void* dx, void* stream);
+int wm_gap_fwd(const void* x, int N, int HW, int C, void* y, void* stream);
+int wm_gap_bwd(const void* dy, int N, int HW, int C, void* dx, void* stream);
+
+/* torch.optim.SGD step over flat f32 arenas: d = g*hyper[3] + hyper[2]*p; buf = hyper[1]*buf + d;
+ * p -= hyper[0]*buf.  hyper is a 4-float DEVICE array {lr, momentum, weight_decay, grad_scale} so a
+ * captured graph picks up a new learning rate without re-capture. */
+int wm_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, const float* hyper,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,75 @@
+"""CPU oracle for the SimCLR ResNet-18 training step.  TEST INFRASTRUCTURE ONLY (oracle/__init__.py).
+
+torch-CPU float32 restatement of what the reference executes through third-party modules:
+  timm.create_model("resnet18", num_classes=0)       scripts/WM811k_benchmark.py:231  
+  heads.SimCLRProjectionHead(512, 512, 128)          scripts/WM811k_benchmark.py:233  
+  SimCLR.forward / training_step                     scripts/WM811k_benchmark.py:236-248
+  torch.optim.SGD(lr 6e-2*bs/256, m 0.9, wd 5e-4)    scripts/WM811k_benchmark.py:250-255
+timm (pinned 0.8.19.dev0) and lightly (unpinned) are not installed here and the reference holds no
+test or golden vector for them: PARITY UNPINNED upstream.  The functions below take a state_dict
+with timm's keys, so the HIP path and the oracle always run on identical weights.
+"""
+import torch
+import torch.nn.functional as F
+
+
+def _bn(x, sd, prefix, training, relu=False, residual=None, momentum=0.1, eps=1e-5):
+    y = F.batch_norm(x, sd[prefix + ".running_mean"], sd[prefix + ".running_var"], sd[prefix + ".weight"],
+                     sd[prefix + ".bias"], training, momentum, eps)
+    if residual is not None:
+        y = y + residual
+    return F.relu(y) if relu else y
+
+
+def _block(x, sd, p, stride, training):
+    out = F.conv2d(x, sd[p + ".conv1.weight"], None, stride, 1)
+    out = _bn(out, sd, p + ".bn1", training, relu=True)
+    out = F.conv2d(out, sd[p + ".conv2.weight"], None, 1, 1)
+    shortcut = x
+    if (p + ".downsample.0.weight") in sd:
+        shortcut = F.conv2d(x, sd[p + ".downsample.0.weight"], None, stride, 0)
+        shortcut = _bn(shortcut, sd, p + ".downsample.1", training)
+    return _bn(out, sd, p + ".bn2", training, relu=True, residual=shortcut)
+
+
+def resnet18_features(x, sd, training=True, prefix=""):
+    """x [N,3,H,W] float32 -> [N,512].  `sd` maps timm keys to tensors; running stats are updated
+    in place when training (as nn.BatchNorm2d does)."""
+    g = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    x = F.conv2d(x, g["conv1.weight"], None, 2, 3)
+    x = _bn(x, g, "bn1", training, relu=True)
+    x = F.max_pool2d(x, 3, 2, 1)
+    for li, stride in ((1, 1), (2, 2), (3, 2), (4, 2)):
+        x = _block(x, g, f"layer{li}.0", stride, training)
+        x = _block(x, g, f"layer{li}.1", 1, training)
+    return F.adaptive_avg_pool2d(x, 1).flatten(1)
+
+
+def simclr_head(f, sd, training=True, prefix="projection_head."):
+    g = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    h = F.linear(f, g["layers.0.weight"])
+    h = _bn(h, g, "layers.1", training, relu=True)
+    h = F.linear(h, g["layers.3.weight"])
+    return _bn(h, g, "layers.4", training)
+
+
+def simclr_loss(x0, x1, sd, temperature=0.5, training=True):
+    """training_step of the reference: two separate forwards, then NTXentLoss."""
+    from .ntxent import ntxent_lightly
+
+    f0 = resnet18_features(x0, sd, training, "backbone.")
+    z0 = simclr_head(f0, sd, training)
+    f1 = resnet18_features(x1, sd, training, "backbone.")
+    z1 = simclr_head(f1, sd, training)
+    return ntxent_lightly(z0, z1, temperature), (f0, f1, z0, z1)
+
+
+def sgd_step(params, grads, bufs, lr, momentum=0.9, weight_decay=5e-4):
+    """torch.optim.SGD.step (no dampening / nesterov): in place."""
+    for k in params:
+        d = grads[k] + weight_decay * params[k]
+        if bufs.get(k) is None:
+            bufs[k] = d.clone()
+        else:
+            bufs[k].mul_(momentum).add_(d)
+        params[k].sub_(lr * bufs[k])

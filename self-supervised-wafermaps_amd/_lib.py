@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_uint32, c_void_p
+from ctypes import c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_uint32, c_void_p
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
@@ -76,6 +76,37 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
     ),
+    "wm_conv2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wm_conv2d_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wm_conv2d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
+    "wm_weights_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "wm_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "wm_stem_weights_prepare": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
+    "wm_stem_wgrad_finalize": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "wm_image_to_s2d": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_cast_f32_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p]),
+    "wm_bn_workspace_bytes": (c_size_t, [c_longlong, c_int, c_int]),
+    "wm_bn_train_fwd": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_float,
+         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "wm_bn_eval_fwd": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_float, c_int, c_void_p,
+         c_void_p, c_size_t, c_void_p],
+    ),
+    "wm_bn_train_bwd": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p,
+         c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "wm_add_bf16": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),
+    "wm_maxpool3x3s2_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "wm_maxpool3x3s2_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_gap_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_gap_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),
 }
 
 _lib = None

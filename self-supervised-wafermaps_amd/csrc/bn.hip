@@ -1,0 +1,401 @@
+// Batch normalisation (training + eval), fused with ReLU and the residual add, on NHWC bf16.
+//
+// Replaces the BatchNorm2d / ReLU / residual-add chain of timm's ResNet-18 BasicBlocks and the
+// BatchNorm1d of lightly's SimCLRProjectionHead in the reference (scripts/WM811k_benchmark.py:
+// 231-240).  A tensor is viewed as [rows][C]; the batch may be cut into G equal row groups with
+// independent statistics: the reference runs forward(x0) and forward(x1) as two calls, so the two
+// views are normalised separately — one launch over the concatenated [2B] batch with G = 2
+// reproduces that exactly.
+//
+//   forward : partial sums (deterministic two-level reduction, no atomics) -> finalize
+//             (mean/invstd in double, running-stat update, per-channel scale/shift)
+//             -> apply: out = relu?(y*scale + shift (+ residual))
+//   backward: dz = dout * (out > 0);  s1 = sum dz, s2 = sum dz*xhat  ->  finalize (dgamma, dbeta,
+//             coefficients) -> apply: dy = gamma*invstd*(dz - s1/M - xhat*s2/M), optional dz copy
+//             (the gradient of the residual branch).
+//
+// Roofline: HBM.  Every pass moves 16 bytes per lane; a row is covered by C/8 adjacent lanes.
+#include "common.h"
+
+namespace {
+
+constexpr int BN_THREADS = 256;
+
+__device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
+  f[0] = bf2f((uint16_t)(v.x & 0xffff)); f[1] = bf2f((uint16_t)(v.x >> 16));
+  f[2] = bf2f((uint16_t)(v.y & 0xffff)); f[3] = bf2f((uint16_t)(v.y >> 16));
+  f[4] = bf2f((uint16_t)(v.z & 0xffff)); f[5] = bf2f((uint16_t)(v.z >> 16));
+  f[6] = bf2f((uint16_t)(v.w & 0xffff)); f[7] = bf2f((uint16_t)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+}
+
+// Two per-channel sums over a row range -> part[((g*nblk + blk)*2 + which)*C + c].
+// MODE 0: (sum y, sum y^2).  MODE 1: (sum dz, sum dz*xhat) with dz = dout*(out>0 | no mask).
+template <int MODE>
+__global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restrict__ y,
+                                                        const uint16_t* __restrict__ dout,
+                                                        const uint16_t* __restrict__ out,
+                                                        const float* __restrict__ mean,
+                                                        const float* __restrict__ invstd,
+                                                        int rows_per_group, int C, int rows_per_block,
+                                                        float* __restrict__ part) {
+  extern __shared__ float red[];  // [2][rpp][C]
+  const int tid = threadIdx.x;
+  const int tpr = C >> 3;  // threads per row
+  const int g = blockIdx.y, blk = blockIdx.x, nblk = gridDim.x;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+  const int r_begin = blk * rows_per_block;
+  int r_end = r_begin + rows_per_block;
+  if (r_end > rows_per_group) r_end = rows_per_group;
+  const size_t gbase = (size_t)g * rows_per_group;
+
+  if (tpr <= BN_THREADS) {
+    const int rpp = BN_THREADS / tpr;
+    const int cidx = tid % tpr, rr = tid / tpr;
+    float mu[8], is[8];
+    if (MODE == 1) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        mu[e] = mean[(size_t)g * C + cidx * 8 + e];
+        is[e] = invstd[(size_t)g * C + cidx * 8 + e];
+      }
+    }
+    if (rr < rpp) {
+      for (int r = r_begin + rr; r < r_end; r += rpp) {
+        const size_t off = (gbase + r) * C + cidx * 8;
+        float fy[8];
+        unpack8(*reinterpret_cast<const uint4*>(y + off), fy);
+        if (MODE == 0) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[e] += fy[e];
+            s2[e] = fmaf(fy[e], fy[e], s2[e]);
+          }
+        } else {
+          float fd[8];
+          unpack8(*reinterpret_cast<const uint4*>(dout + off), fd);
+          if (out) {
+            float fo[8];
+            unpack8(*reinterpret_cast<const uint4*>(out + off), fo);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fd[e] = fo[e] > 0.f ? fd[e] : 0.f;
+          }
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            s1[e] += fd[e];
+            s2[e] = fmaf(fd[e], (fy[e] - mu[e]) * is[e], s2[e]);
+          }
+        }
+      }
+    }
+    float* r1 = red;
+    float* r2 = red + rpp * C;
+    if (rr < rpp) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        r1[rr * C + cidx * 8 + e] = s1[e];
+        r2[rr * C + cidx * 8 + e] = s2[e];
+      }
+    }
+    __syncthreads();
+    for (int c = tid; c < C; c += BN_THREADS) {
+      float a = 0.f, b = 0.f;
+      for (int q = 0; q < rpp; ++q) {
+        a += r1[q * C + c];
+        b += r2[q * C + c];
+      }
+      part[((size_t)(g * nblk + blk) * 2 + 0) * C + c] = a;
+      part[((size_t)(g * nblk + blk) * 2 + 1) * C + c] = b;
+    }
+  }
+}
+
+// Forward finalize: one block; thread c handles channel c (loop if C > blockDim).
+__global__ void bn_fwd_finalize(const float* __restrict__ part, int nblk, int G, int C,
+                                int rows_per_group, const float* __restrict__ gamma,
+                                const float* __restrict__ beta, float eps, float momentum,
+                                float* __restrict__ running_mean, float* __restrict__ running_var,
+                                float* __restrict__ mean, float* __restrict__ invstd,
+                                float* __restrict__ scale, float* __restrict__ shift) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
+    for (int g = 0; g < G; ++g) {
+      double s = 0.0, ss = 0.0;
+      for (int b = 0; b < nblk; ++b) {
+        s += (double)part[((size_t)(g * nblk + b) * 2 + 0) * C + c];
+        ss += (double)part[((size_t)(g * nblk + b) * 2 + 1) * C + c];
+      }
+      const double m = s / rows_per_group;
+      double var = ss / rows_per_group - m * m;
+      if (var < 0.0) var = 0.0;
+      const float fm = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+      mean[(size_t)g * C + c] = fm;
+      invstd[(size_t)g * C + c] = is;
+      const float sc = (gamma ? gamma[c] : 1.f) * is;
+      scale[(size_t)g * C + c] = sc;
+      shift[(size_t)g * C + c] = (beta ? beta[c] : 0.f) - fm * sc;
+      // torch: running = (1-momentum)*running + momentum*stat, unbiased variance; the G groups
+      // are the reference's G consecutive forward calls
+      const double unb = rows_per_group > 1 ? var * rows_per_group / (rows_per_group - 1.0) : var;
+      rm = (1.f - momentum) * rm + momentum * fm;
+      rv = (1.f - momentum) * rv + momentum * (float)unb;
+    }
+    if (running_mean) running_mean[c] = rm;
+    if (running_var) running_var[c] = rv;
+  }
+}
+
+// Eval-mode scale/shift from running statistics.
+__global__ void bn_eval_params(const float* __restrict__ gamma, const float* __restrict__ beta,
+                               const float* __restrict__ running_mean,
+                               const float* __restrict__ running_var, float eps, int C,
+                               float* __restrict__ scale, float* __restrict__ shift) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    const float is = 1.0f / sqrtf(running_var[c] + eps);
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    scale[c] = sc;
+    shift[c] = (beta ? beta[c] : 0.f) - running_mean[c] * sc;
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_apply(const uint16_t* __restrict__ y,
+                                                       const uint16_t* __restrict__ residual,
+                                                       const float* __restrict__ scale,
+                                                       const float* __restrict__ shift,
+                                                       long long rows, int C, int rows_per_group,
+                                                       int relu, uint16_t* __restrict__ out) {
+  const int cpr = C >> 3;
+  const long long total = rows * cpr;
+  for (long long p = (long long)blockIdx.x * BN_THREADS + threadIdx.x; p < total;
+       p += (long long)gridDim.x * BN_THREADS) {
+    const long long row = p / cpr;
+    const int c0 = (int)(p - row * cpr) * 8;
+    const int g = (int)(row / rows_per_group);
+    float f[8];
+    unpack8(*reinterpret_cast<const uint4*>(y + row * C + c0), f);
+    const float4 sa = *reinterpret_cast<const float4*>(scale + (size_t)g * C + c0);
+    const float4 sb = *reinterpret_cast<const float4*>(scale + (size_t)g * C + c0 + 4);
+    const float4 ha = *reinterpret_cast<const float4*>(shift + (size_t)g * C + c0);
+    const float4 hb = *reinterpret_cast<const float4*>(shift + (size_t)g * C + c0 + 4);
+    const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
+    const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
+    if (residual) {
+      float r[8];
+      unpack8(*reinterpret_cast<const uint4*>(residual + row * C + c0), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += r[e];
+    }
+    if (relu) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
+    }
+    *reinterpret_cast<uint4*>(out + row * C + c0) = pack8(f);
+  }
+}
+
+// Backward finalize: dgamma/dbeta and the per-(group, channel) coefficients of the apply pass.
+// coef[(g*5 + t)*C + c]: t = 0 mean, 1 invstd, 2 gamma*invstd, 3 s1/M, 4 s2/M.
+__global__ void bn_bwd_finalize(const float* __restrict__ part, int nblk, int G, int C,
+                                int rows_per_group, const float* __restrict__ gamma,
+                                const float* __restrict__ mean, const float* __restrict__ invstd,
+                                float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                int accumulate, float* __restrict__ coef) {
+  for (int c = threadIdx.x; c < C; c += blockDim.x) {
+    double tg = 0.0, tb = 0.0;
+    for (int g = 0; g < G; ++g) {
+      double s1 = 0.0, s2 = 0.0;
+      for (int b = 0; b < nblk; ++b) {
+        s1 += (double)part[((size_t)(g * nblk + b) * 2 + 0) * C + c];
+        s2 += (double)part[((size_t)(g * nblk + b) * 2 + 1) * C + c];
+      }
+      tb += s1;
+      tg += s2;
+      const float is = invstd[(size_t)g * C + c];
+      coef[((size_t)g * 5 + 0) * C + c] = mean[(size_t)g * C + c];
+      coef[((size_t)g * 5 + 1) * C + c] = is;
+      coef[((size_t)g * 5 + 2) * C + c] = (gamma ? gamma[c] : 1.f) * is;
+      coef[((size_t)g * 5 + 3) * C + c] = (float)(s1 / rows_per_group);
+      coef[((size_t)g * 5 + 4) * C + c] = (float)(s2 / rows_per_group);
+    }
+    if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)tg;
+    if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)tb;
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __restrict__ y,
+                                                           const uint16_t* __restrict__ dout,
+                                                           const uint16_t* __restrict__ out,
+                                                           const float* __restrict__ coef,
+                                                           long long rows, int C, int rows_per_group,
+                                                           uint16_t* __restrict__ dy,
+                                                           uint16_t* __restrict__ dz) {
+  const int cpr = C >> 3;
+  const long long total = rows * cpr;
+  for (long long p = (long long)blockIdx.x * BN_THREADS + threadIdx.x; p < total;
+       p += (long long)gridDim.x * BN_THREADS) {
+    const long long row = p / cpr;
+    const int c0 = (int)(p - row * cpr) * 8;
+    const int g = (int)(row / rows_per_group);
+    const size_t off = row * C + c0;
+    float fy[8], fd[8];
+    unpack8(*reinterpret_cast<const uint4*>(y + off), fy);
+    unpack8(*reinterpret_cast<const uint4*>(dout + off), fd);
+    if (out) {
+      float fo[8];
+      unpack8(*reinterpret_cast<const uint4*>(out + off), fo);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fd[e] = fo[e] > 0.f ? fd[e] : 0.f;
+    }
+    if (dz) *reinterpret_cast<uint4*>(dz + off) = pack8(fd);
+    const float* cf = coef + (size_t)g * 5 * C + c0;
+    float r[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float xh = (fy[e] - cf[e]) * cf[C + e];
+      r[e] = cf[2 * C + e] * (fd[e] - cf[3 * C + e] - xh * cf[4 * C + e]);
+    }
+    *reinterpret_cast<uint4*>(dy + off) = pack8(r);
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void add_bf16_kernel(const uint16_t* __restrict__ a,
+                                                              const uint16_t* __restrict__ b,
+                                                              long long n8, uint16_t* __restrict__ o) {
+  for (long long p = (long long)blockIdx.x * BN_THREADS + threadIdx.x; p < n8;
+       p += (long long)gridDim.x * BN_THREADS) {
+    float fa[8], fb[8];
+    unpack8(reinterpret_cast<const uint4*>(a)[p], fa);
+    unpack8(reinterpret_cast<const uint4*>(b)[p], fb);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) fa[e] += fb[e];
+    reinterpret_cast<uint4*>(o)[p] = pack8(fa);
+  }
+}
+
+inline int reduce_blocks(int rows_per_group, int C) {
+  const int tpr = C >> 3;
+  const int rpp = BN_THREADS / tpr > 0 ? BN_THREADS / tpr : 1;
+  int nblk = wm_cdiv(rows_per_group, rpp * 16);
+  if (nblk > 512) nblk = 512;
+  if (nblk < 1) nblk = 1;
+  return nblk;
+}
+
+inline int stream_grid(long long items) {
+  long long b = (items + BN_THREADS - 1) / BN_THREADS;
+  if (b > 256 * 16) b = 256 * 16;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+int bn_shape_check(long long rows, int C, int G) {
+  WM_REQUIRE(rows > 0 && C > 0 && G > 0, WM_EINVAL);
+  WM_REQUIRE(C % 8 == 0 && C <= 2048, WM_EUNSUPPORTED);
+  WM_REQUIRE(rows % G == 0 && rows / G < (1ll << 31), WM_EUNSUPPORTED);
+  return WM_OK;
+}
+
+}  // namespace
+
+extern "C" size_t wm_bn_workspace_bytes(long long rows, int C, int G) {
+  if (rows <= 0 || C <= 0 || G <= 0 || C % 8) return 0;
+  const int nblk = reduce_blocks((int)(rows / G), C);
+  // partial sums + the 5 backward coefficient planes
+  return ((size_t)G * nblk * 2 * C + (size_t)G * 5 * C) * sizeof(float) + 256;
+}
+
+extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float* gamma,
+                               const float* beta, float* running_mean, float* running_var,
+                               long long rows, int C, int G, float eps, float momentum, int relu,
+                               float* save_mean, float* save_invstd, void* out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(y && out && save_mean && save_invstd && workspace, WM_EINVAL);
+  const int rc = bn_shape_check(rows, C, G);
+  if (rc != WM_OK) return rc;
+  WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rpg = (int)(rows / G);
+  const int nblk = reduce_blocks(rpg, C);
+  float* part = static_cast<float*>(workspace);
+  float* scale = part + (size_t)G * nblk * 2 * C;  // reuse the coefficient planes: scale, shift
+  float* shift = scale + (size_t)G * C;
+  const int tpr = C >> 3, rpp = BN_THREADS / tpr;
+  const size_t lds = (size_t)2 * rpp * C * sizeof(float);
+  bn_reduce<0><<<dim3(nblk, G), BN_THREADS, lds, st>>>(static_cast<const uint16_t*>(y), nullptr, nullptr,
+                                                       nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk), part);
+  WM_LAUNCH_CHECK();
+  bn_fwd_finalize<<<1, C < 1024 ? ((C + 63) / 64) * 64 : 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, beta, eps,
+                                                                      momentum, running_mean, running_var,
+                                                                      save_mean, save_invstd, scale, shift);
+  WM_LAUNCH_CHECK();
+  bn_apply<<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(static_cast<const uint16_t*>(y),
+                                                           static_cast<const uint16_t*>(residual), scale, shift,
+                                                           rows, C, rpg, relu, static_cast<uint16_t*>(out));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_bn_eval_fwd(const void* y, const void* residual, const float* gamma, const float* beta,
+                              const float* running_mean, const float* running_var, long long rows, int C,
+                              float eps, int relu, void* out, void* workspace, size_t workspace_bytes,
+                              void* stream) {
+  WM_REQUIRE(y && out && running_mean && running_var && workspace, WM_EINVAL);
+  const int rc = bn_shape_check(rows, C, 1);
+  if (rc != WM_OK) return rc;
+  WM_REQUIRE(workspace_bytes >= (size_t)2 * C * sizeof(float), WM_EWORKSPACE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* scale = static_cast<float*>(workspace);
+  float* shift = scale + C;
+  bn_eval_params<<<1, C < 1024 ? ((C + 63) / 64) * 64 : 1024, 0, st>>>(gamma, beta, running_mean, running_var, eps,
+                                                                     C, scale, shift);
+  WM_LAUNCH_CHECK();
+  bn_apply<<<stream_grid(rows * (C >> 3)), BN_THREADS, 0, st>>>(
+      static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(residual), scale, shift, rows, C,
+      (int)(rows < (1ll << 31) - 1 ? rows : (1ll << 31) - 1), relu, static_cast<uint16_t*>(out));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, const float* gamma,
+                               const float* save_mean, const float* save_invstd, long long rows, int C,
+                               int G, float* dgamma, float* dbeta, int accumulate, void* dy, void* dz,
+                               void* workspace, size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(y && dout && save_mean && save_invstd && dy && workspace, WM_EINVAL);
+  const int rc = bn_shape_check(rows, C, G);
+  if (rc != WM_OK) return rc;
+  WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rpg = (int)(rows / G);
+  const int nblk = reduce_blocks(rpg, C);
+  float* part = static_cast<float*>(workspace);
+  float* coef = part + (size_t)G * nblk * 2 * C;
+  const int tpr = C >> 3, rpp = BN_THREADS / tpr;
+  const size_t lds = (size_t)2 * rpp * C * sizeof(float);
+  bn_reduce<1><<<dim3(nblk, G), BN_THREADS, lds, st>>>(
+      static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
+      save_mean, save_invstd, rpg, C, wm_cdiv(rpg, nblk), part);
+  WM_LAUNCH_CHECK();
+  bn_bwd_finalize<<<1, C < 1024 ? ((C + 63) / 64) * 64 : 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, save_mean,
+                                                                      save_invstd, dgamma, dbeta, accumulate, coef);
+  WM_LAUNCH_CHECK();
+  bn_bwd_apply<<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+      static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
+      coef, rows, C, rpg, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_add_bf16(const void* a, const void* b, long long n, void* out, void* stream) {
+  WM_REQUIRE(a && b && out && n > 0, WM_EINVAL);
+  WM_REQUIRE(n % 8 == 0, WM_EUNSUPPORTED);
+  add_bf16_kernel<<<stream_grid(n / 8), BN_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(a), static_cast<const uint16_t*>(b), n / 8, static_cast<uint16_t*>(out));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

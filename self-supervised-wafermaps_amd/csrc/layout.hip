@@ -1,0 +1,198 @@
+// Weight / image layout transforms and the fused SGD step.
+//
+//  * f32 OIHW master weights (timm / torch state_dict layout, kept so that reference checkpoints
+//    load: SURVEY §5) -> bf16 [K][R][S][C] (forward, wgrad order) and [C][R][S][K] (dgrad);
+//  * wgrad's f32 [K][R][S][C] accumulator -> OIHW gradient;
+//  * the 7x7/2 stem as a 4x4/1 convolution over the 2x2 space-to-depth image: channel
+//    (dh*2+dw)*3 + c of pixel (h2, w2) is x[c][2*h2+dh][2*w2+dw]; kernel row/col r' = r + 1 = 2a+dh;
+//  * SGD with momentum and weight decay over flat f32 arenas, as torch.optim.SGD computes it for
+//    the reference's SimCLR (scripts/WM811k_benchmark.py:250-255).
+#include "common.h"
+
+namespace {
+
+constexpr int LT_THREADS = 256;
+
+__global__ void weights_prepare(const float* __restrict__ w, int K, int C, int R, int S,
+                                uint16_t* __restrict__ krsc, uint16_t* __restrict__ crsk) {
+  const long long total = (long long)K * C * R * S;
+  for (long long t = (long long)blockIdx.x * LT_THREADS + threadIdx.x; t < total;
+       t += (long long)gridDim.x * LT_THREADS) {
+    // t enumerates the KRSC order (coalesced writes of the forward layout)
+    const int c = (int)(t % C);
+    long long u = t / C;
+    const int s = (int)(u % S);
+    u /= S;
+    const int r = (int)(u % R), k = (int)(u / R);
+    const uint16_t v = f2bf(w[(((size_t)k * C + c) * R + r) * S + s]);
+    if (krsc) krsc[t] = v;
+    if (crsk) crsk[(((size_t)c * R + r) * S + s) * K + k] = v;
+  }
+}
+
+__global__ void wgrad_finalize(const float* __restrict__ ws, int K, int C, int R, int S,
+                               float* __restrict__ grad, int accumulate) {
+  const long long total = (long long)K * C * R * S;
+  for (long long t = (long long)blockIdx.x * LT_THREADS + threadIdx.x; t < total;
+       t += (long long)gridDim.x * LT_THREADS) {
+    // t enumerates OIHW
+    const int s = (int)(t % S);
+    long long u = t / S;
+    const int r = (int)(u % R);
+    u /= R;
+    const int c = (int)(u % C), k = (int)(u / C);
+    const float v = ws[(((size_t)k * R + r) * S + s) * C + c];
+    grad[t] = accumulate ? grad[t] + v : v;
+  }
+}
+
+// stem: w [K][3][7][7] -> [K][4][4][16] bf16
+__global__ void stem_weights_prepare(const float* __restrict__ w, int K, uint16_t* __restrict__ out) {
+  const int total = K * 256;
+  for (int t = blockIdx.x * LT_THREADS + threadIdx.x; t < total; t += gridDim.x * LT_THREADS) {
+    const int ch = t & 15, b = (t >> 4) & 3, a = (t >> 6) & 3, k = t >> 8;
+    float v = 0.f;
+    if (ch < 12) {
+      const int c = ch % 3, dw = (ch / 3) & 1, dh = ch / 6;
+      const int r = 2 * a + dh - 1, s = 2 * b + dw - 1;
+      if (r >= 0 && s >= 0) v = w[((k * 3 + c) * 7 + r) * 7 + s];
+    }
+    out[t] = f2bf(v);
+  }
+}
+
+__global__ void stem_wgrad_finalize(const float* __restrict__ ws, int K, float* __restrict__ grad,
+                                    int accumulate) {
+  const int total = K * 147;
+  for (int t = blockIdx.x * LT_THREADS + threadIdx.x; t < total; t += gridDim.x * LT_THREADS) {
+    const int s = t % 7, r = (t / 7) % 7, c = (t / 49) % 3, k = t / 147;
+    const int a = (r + 1) >> 1, dh = (r + 1) & 1, b = (s + 1) >> 1, dw = (s + 1) & 1;
+    const float v = ws[((k * 4 + a) * 4 + b) * 16 + (dh * 2 + dw) * 3 + c];
+    grad[t] = accumulate ? grad[t] + v : v;
+  }
+}
+
+// image -> space-to-depth [N][H/2][W/2][16] bf16.  FMT 0: f32 NCHW [N][3][H][W]; 1: bf16 NHWC.
+template <int FMT>
+__global__ void image_to_s2d(const void* __restrict__ img, int N, int H, int W, uint16_t* __restrict__ out) {
+  const int H2 = H >> 1, W2 = W >> 1;
+  const long long total = (long long)N * H2 * W2;
+  for (long long t = (long long)blockIdx.x * LT_THREADS + threadIdx.x; t < total;
+       t += (long long)gridDim.x * LT_THREADS) {
+    const int w2 = (int)(t % W2);
+    long long u = t / W2;
+    const int h2 = (int)(u % H2), n = (int)(u / H2);
+    uint16_t v[16];
+#pragma unroll
+    for (int ch = 0; ch < 16; ++ch) {
+      uint16_t o = 0;
+      if (ch < 12) {
+        const int c = ch % 3, dw = (ch / 3) & 1, dh = ch / 6;
+        const int h = 2 * h2 + dh, w = 2 * w2 + dw;
+        if (FMT == 0)
+          o = f2bf(static_cast<const float*>(img)[(((size_t)n * 3 + c) * H + h) * W + w]);
+        else
+          o = static_cast<const uint16_t*>(img)[(((size_t)n * H + h) * W + w) * 3 + c];
+      }
+      v[ch] = o;
+    }
+    uint4* o4 = reinterpret_cast<uint4*>(out + (size_t)t * 16);
+    o4[0] = make_uint4(v[0] | (v[1] << 16), v[2] | (v[3] << 16), v[4] | (v[5] << 16), v[6] | (v[7] << 16));
+    o4[1] = make_uint4(v[8] | (v[9] << 16), v[10] | (v[11] << 16), v[12] | (v[13] << 16), v[14] | (v[15] << 16));
+  }
+}
+
+__global__ void cast_f32_bf16(const float* __restrict__ x, long long n, uint16_t* __restrict__ y) {
+  for (long long t = (long long)blockIdx.x * LT_THREADS + threadIdx.x; t < n; t += (long long)gridDim.x * LT_THREADS)
+    y[t] = f2bf(x[t]);
+}
+
+// hyper[0] = lr, [1] = momentum, [2] = weight_decay, [3] = grad scale (1/world for averaged grads)
+__global__ void sgd_step(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
+                         long long n, const float* __restrict__ hyper) {
+  const float lr = hyper[0], mu = hyper[1], wd = hyper[2], gs = hyper[3];
+  for (long long t = (long long)blockIdx.x * LT_THREADS + threadIdx.x; t < n; t += (long long)gridDim.x * LT_THREADS) {
+    const float pv = p[t];
+    float gv = g[t] * gs;
+    gv = fmaf(wd, pv, gv);          // d_p = grad + weight_decay * p
+    const float b = fmaf(mu, mom[t], gv);  // buf = momentum * buf + d_p  (buf starts at 0 == clone on step 1)
+    mom[t] = b;
+    p[t] = pv - lr * b;             // p -= lr * buf
+  }
+}
+
+inline int grid_for(long long items) {
+  long long b = (items + LT_THREADS - 1) / LT_THREADS;
+  if (b > 2048) b = 2048;
+  return b < 1 ? 1 : (int)b;
+}
+
+}  // namespace
+
+extern "C" int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int S, void* w_krsc, void* w_crsk,
+                                  void* stream) {
+  WM_REQUIRE(w_oihw && (w_krsc || w_crsk), WM_EINVAL);
+  WM_REQUIRE(K > 0 && C > 0 && R > 0 && S > 0, WM_EINVAL);
+  weights_prepare<<<grid_for((long long)K * C * R * S), LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      w_oihw, K, C, R, S, static_cast<uint16_t*>(w_krsc), static_cast<uint16_t*>(w_crsk));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_wgrad_finalize(const float* dw_krsc, int K, int C, int R, int S, float* grad_oihw,
+                                 int accumulate, void* stream) {
+  WM_REQUIRE(dw_krsc && grad_oihw, WM_EINVAL);
+  WM_REQUIRE(K > 0 && C > 0 && R > 0 && S > 0, WM_EINVAL);
+  wgrad_finalize<<<grid_for((long long)K * C * R * S), LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      dw_krsc, K, C, R, S, grad_oihw, accumulate);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_stem_weights_prepare(const float* w_oihw, int K, void* w_s2d, void* stream) {
+  WM_REQUIRE(w_oihw && w_s2d && K > 0, WM_EINVAL);
+  stem_weights_prepare<<<grid_for((long long)K * 256), LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      w_oihw, K, static_cast<uint16_t*>(w_s2d));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_stem_wgrad_finalize(const float* dw_s2d, int K, float* grad_oihw, int accumulate,
+                                      void* stream) {
+  WM_REQUIRE(dw_s2d && grad_oihw && K > 0, WM_EINVAL);
+  stem_wgrad_finalize<<<grid_for((long long)K * 147), LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      dw_s2d, K, grad_oihw, accumulate);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_image_to_s2d(const void* img, int fmt, int N, int H, int W, void* out, void* stream) {
+  WM_REQUIRE(img && out, WM_EINVAL);
+  WM_REQUIRE(N > 0 && H > 0 && W > 0, WM_EINVAL);
+  WM_REQUIRE(H % 2 == 0 && W % 2 == 0, WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long items = (long long)N * (H / 2) * (W / 2);
+  if (fmt == WM_IMG_NCHW_F32)
+    image_to_s2d<0><<<grid_for(items), LT_THREADS, 0, st>>>(img, N, H, W, static_cast<uint16_t*>(out));
+  else if (fmt == WM_IMG_NHWC_BF16)
+    image_to_s2d<1><<<grid_for(items), LT_THREADS, 0, st>>>(img, N, H, W, static_cast<uint16_t*>(out));
+  else
+    return WM_EUNSUPPORTED;
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_cast_f32_bf16(const float* x, long long n, void* y, void* stream) {
+  WM_REQUIRE(x && y && n > 0, WM_EINVAL);
+  cast_f32_bf16<<<grid_for(n), LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(x, n, static_cast<uint16_t*>(y));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_sgd_step(float* params, const float* grads, float* momentum_buf, long long n,
+                           const float* hyper, void* stream) {
+  WM_REQUIRE(params && grads && momentum_buf && hyper && n > 0, WM_EINVAL);
+  sgd_step<<<grid_for(n), LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(params, grads, momentum_buf, n, hyper);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

@@ -1,0 +1,68 @@
+"""ResNet-18 backbone with timm's module tree and state_dict keys
+(`timm.create_model("resnet18", num_classes=0)`, reference scripts/WM811k_benchmark.py:231):
+conv1, bn1, layer{1-4}.{0,1}.{conv1,bn1,conv2,bn2}, layer{2-4}.0.downsample.{0,1}; output [N, 512]."""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from .. import nn as hnn
+from .. import ops
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1):
+        super().__init__()
+        self.conv1 = hnn.Conv2d(inplanes, planes, 3, stride, 1)
+        self.bn1 = hnn.BatchNorm2d(planes)
+        self.conv2 = hnn.Conv2d(planes, planes, 3, 1, 1)
+        self.bn2 = hnn.BatchNorm2d(planes)
+        self.downsample = None
+        if stride != 1 or inplanes != planes:
+            self.downsample = nn.Sequential(hnn.Conv2d(inplanes, planes, 1, stride, 0), hnn.BatchNorm2d(planes))
+        nn.init.zeros_(self.bn2.weight)  # timm zero_init_last
+
+    def forward(self, x):
+        shortcut = x
+        out = self.bn1(self.conv1(x), relu=True)
+        out = self.conv2(out)
+        if self.downsample is not None:
+            shortcut = self.downsample[1](self.downsample[0](x))
+        return self.bn2(out, residual=shortcut, relu=True)
+
+
+class ResNet18(nn.Module):
+    num_features = 512
+
+    def __init__(self, num_classes: int = 0):
+        super().__init__()
+        if num_classes != 0:
+            raise NotImplementedError("only the headless backbone (num_classes=0) is built")
+        self.conv1 = hnn.StemConv(64)
+        self.bn1 = hnn.BatchNorm2d(64)
+        self.layer1 = nn.Sequential(BasicBlock(64, 64), BasicBlock(64, 64))
+        self.layer2 = nn.Sequential(BasicBlock(64, 128, 2), BasicBlock(128, 128))
+        self.layer3 = nn.Sequential(BasicBlock(128, 256, 2), BasicBlock(256, 256))
+        self.layer4 = nn.Sequential(BasicBlock(256, 512, 2), BasicBlock(512, 512))
+
+    def forward_features(self, x):
+        x = self.bn1(self.conv1(x), relu=True)
+        x = ops.max_pool3x3s2(x)
+        x = self.layer1(x)
+        x = self.layer2(x)
+        x = self.layer3(x)
+        return self.layer4(x)
+
+    def forward(self, x):
+        return ops.global_avg_pool(self.forward_features(x))
+
+
+def create_model(name: str, num_classes: int = 0, pretrained: bool = False, **kw):
+    """The one timm entry point the reference's hot path uses."""
+    if name != "resnet18":
+        raise NotImplementedError(f"model {name!r} is not built (only resnet18 is on the hot path)")
+    if pretrained:
+        raise NotImplementedError("no network: pretrained weights cannot be fetched")
+    return ResNet18(num_classes=num_classes)

@@ -1,0 +1,81 @@
+"""nn.Module wrappers (parameters in torch/timm layout, compute in the HIP kernels)."""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class Conv2d(nn.Module):
+    """Bias-free convolution; weight float32 [out, in, kh, kw] (state_dict key `weight`)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0):
+        super().__init__()
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.padding = kernel_size, stride, padding
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
+        nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")  # timm resnet init
+
+    def forward(self, x):
+        return ops.conv2d(x, self.weight, self.stride, self.padding)
+
+
+class StemConv(Conv2d):
+    """ResNet stem: 7x7 stride 2 pad 3 on 3 channels (space-to-depth formulation inside)."""
+
+    def __init__(self, out_channels=64):
+        super().__init__(3, out_channels, 7, 2, 3)
+
+    def forward(self, x):
+        return ops.stem_conv(x, self.weight)
+
+
+class _BatchNorm(nn.Module):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.num_features, self.eps, self.momentum = num_features, eps, momentum
+        self.weight = nn.Parameter(torch.ones(num_features))
+        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features))
+        self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+
+    def forward(self, x, residual=None, relu=False):
+        if self.training:
+            self.num_batches_tracked += ops.current_bn_groups()
+        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                              residual=residual, relu=relu, eps=self.eps, momentum=self.momentum)
+
+
+class BatchNorm2d(_BatchNorm):
+    pass
+
+
+class BatchNorm1d(_BatchNorm):
+    pass
+
+
+class Linear(nn.Module):
+    """Bias-free linear layer (the heads the reference uses pair every Linear with a BatchNorm,
+    lightly: `bias = not batch_norm`)."""
+
+    def __init__(self, in_features, out_features, bias=False):
+        super().__init__()
+        if bias:
+            raise NotImplementedError("Linear with bias has no HIP path yet (heads with batch_norm=False)")
+        self.in_features, self.out_features = in_features, out_features
+        self.weight = nn.Parameter(torch.empty(out_features, in_features))
+        nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Linear default
+
+    def forward(self, x):
+        return ops.linear(x, self.weight)
+
+
+class ReLU(nn.Module):
+    """Marker module: the activation itself is fused into the preceding BatchNorm kernel."""
+
+    def forward(self, x):
+        raise RuntimeError("ReLU is fused into the preceding batch-norm launch; do not call it directly")

@@ -1,0 +1,397 @@
+"""Autograd-aware building blocks over the conv / BN / pool kernels (include/wafer_hip.h).
+
+Activations are bf16 tensors of logical shape [N, C, H, W] in torch.channels_last memory format
+(physically NHWC) or [B, C] row-major; parameters stay float32 in the torch/timm state_dict layout
+(OIHW conv weights), so reference checkpoints load unchanged.  Each Function pairs a forward
+kernel with its backward kernels; there is no CPU fallback.
+"""
+from __future__ import annotations
+
+import contextlib
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+_WEIGHT_EPOCH = 0  # bumped by optimisers that update parameters through raw pointers
+
+
+def bump_weight_epoch() -> None:
+    global _WEIGHT_EPOCH
+    _WEIGHT_EPOCH += 1
+
+
+_BN_GROUPS = 1
+
+
+@contextlib.contextmanager
+def bn_groups(g: int):
+    """Normalise the batch in `g` equal consecutive groups with independent statistics.
+    g = 2 over cat([x0, x1]) equals the reference's two calls forward(x0); forward(x1)
+    (scripts/WM811k_benchmark.py:244-245) in one pass."""
+    global _BN_GROUPS
+    old, _BN_GROUPS = _BN_GROUPS, int(g)
+    try:
+        yield
+    finally:
+        _BN_GROUPS = old
+
+
+def current_bn_groups() -> int:
+    return _BN_GROUPS
+
+
+def _need_cuda(t: torch.Tensor, what: str) -> None:
+    if not t.is_cuda:
+        raise _lib.WaferHipError(f"{what}: the HIP path needs a device tensor (no CPU fallback)")
+
+
+def to_nhwc_bf16(x: torch.Tensor) -> torch.Tensor:
+    """[N,C,H,W] any float dtype/layout -> bf16 channels_last (no copy when already so)."""
+    if x.dim() != 4:
+        raise ValueError("expected a 4-D [N,C,H,W] tensor")
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+    return x.contiguous(memory_format=torch.channels_last)
+
+
+def _nhwc_ok(x: torch.Tensor) -> bool:
+    n, c, h, w = x.shape
+    return x.dtype == torch.bfloat16 and x.stride() == (h * w * c, 1, w * c, c)
+
+
+def _as_nhwc(x: torch.Tensor) -> torch.Tensor:
+    if _nhwc_ok(x):
+        return x
+    n, c, h, w = x.shape
+    out = torch.empty((n, h, w, c), dtype=torch.bfloat16, device=x.device).permute(0, 3, 1, 2)
+    out.copy_(x)
+    return out
+
+
+def _empty_nhwc(n, c, h, w, device) -> torch.Tensor:
+    return torch.empty((n, h, w, c), dtype=torch.bfloat16, device=device).permute(0, 3, 1, 2)
+
+
+class _WeightCache:
+    """bf16 kernel-layout copies of a float32 parameter, rebuilt when the parameter changes.
+    The copies hang off the parameter object itself (attribute `_hip_layouts`), so they live and
+    die with it and a recycled device address can never alias a stale entry."""
+
+    def get(self, w: torch.Tensor, kind: str = "conv", need_crsk: bool = False):
+        tag = (w._version, _WEIGHT_EPOCH, w.data_ptr(), kind)
+        ent = getattr(w, "_hip_layouts", None)
+        if ent is None or ent[0] != tag or (need_crsk and ent[2] is None):
+            lib = _lib.load()
+            wd = w.detach()
+            if not wd.is_contiguous():
+                wd = wd.contiguous()
+            if kind == "stem":
+                k = w.shape[0]
+                krsc = torch.empty((k, 4, 4, 16), dtype=torch.bfloat16, device=w.device)
+                check(lib.wm_stem_weights_prepare(ptr(wd), k, ptr(krsc), stream_ptr()), "wm_stem_weights_prepare")
+                crsk = None
+            else:
+                k, c, r, s = w.shape if kind == "conv" else (w.shape[0], w.shape[1], 1, 1)
+                krsc = torch.empty((k, r, s, c), dtype=torch.bfloat16, device=w.device)
+                crsk = torch.empty((c, r, s, k), dtype=torch.bfloat16, device=w.device) if need_crsk else None
+                check(lib.wm_weights_prepare(ptr(wd), k, c, r, s, ptr(krsc), ptr(crsk), stream_ptr()),
+                      "wm_weights_prepare")
+            ent = (tag, krsc, crsk)
+            w._hip_layouts = ent
+        return ent[1], ent[2]
+
+
+_WCACHE = _WeightCache()
+
+
+def _out_hw(h, w, r, s, stride, pad):
+    return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
+
+
+class _Conv2d(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, stride, pad):
+        _need_cuda(x, "conv2d")
+        x = _as_nhwc(x)
+        n, c, h, w = x.shape
+        k, c2, r, s = weight.shape
+        if c2 != c or weight.dtype != torch.float32:
+            raise ValueError(f"conv2d: input channels {c} vs weight {tuple(weight.shape)} ({weight.dtype})")
+        p, q = _out_hw(h, w, r, s, stride, pad)
+        train = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
+        krsc, _ = _WCACHE.get(weight, need_crsk=train and x.requires_grad)
+        y = _empty_nhwc(n, k, p, q, x.device)
+        check(_lib.load().wm_conv2d_fwd(ptr(x), ptr(krsc), y.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad,
+                                        stream_ptr()), "wm_conv2d_fwd")
+        ctx.save_for_backward(x)
+        ctx.weight = weight
+        ctx.geom = (n, h, w, c, k, r, s, p, q, stride, pad)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        weight = ctx.weight
+        n, h, w, c, k, r, s, p, q, stride, pad = ctx.geom
+        dy = _as_nhwc(dy)
+        lib = _lib.load()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            _, crsk = _WCACHE.get(weight, need_crsk=True)
+            dx = _empty_nhwc(n, c, h, w, dy.device)
+            check(lib.wm_conv2d_dgrad(dy.data_ptr(), ptr(crsk), dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad,
+                                      stream_ptr()), "wm_conv2d_dgrad")
+        if ctx.needs_input_grad[1]:
+            ws = torch.zeros((k, r, s, c), dtype=torch.float32, device=dy.device)
+            check(lib.wm_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), ptr(ws), n, h, w, c, k, r, s, p, q, stride, pad,
+                                      stream_ptr()), "wm_conv2d_wgrad")
+            dw = torch.empty((k, c, r, s), dtype=torch.float32, device=dy.device)
+            check(lib.wm_wgrad_finalize(ptr(ws), k, c, r, s, ptr(dw), 0, stream_ptr()), "wm_wgrad_finalize")
+        return dx, dw, None, None
+
+
+def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
+    """bias-free conv2d; x bf16 NHWC (converted if not), weight float32 [K, C, R, S]."""
+    return _Conv2d.apply(x, weight, int(stride), int(padding))
+
+
+class _StemConv(torch.autograd.Function):
+    """7x7 stride-2 pad-3 convolution of a 3-channel image, run as a 4x4 convolution over the 2x2
+    space-to-depth image (16 channels, 12 used) so every reduction tile is 128 contiguous bytes."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _need_cuda(x, "stem_conv")
+        n, c, h, w = x.shape
+        k = weight.shape[0]
+        if c != 3 or tuple(weight.shape[1:]) != (3, 7, 7) or h % 2 or w % 2:
+            raise ValueError("stem_conv: expects [N,3,even,even] input and [K,3,7,7] weights")
+        if x.requires_grad:
+            raise NotImplementedError("stem_conv: no input gradient (images are data)")
+        lib = _lib.load()
+        if x.dtype == torch.float32 and x.is_contiguous():
+            fmt = _lib.WM_IMG_NCHW_F32
+        else:
+            x = _as_nhwc(x)
+            fmt = _lib.WM_IMG_NHWC_BF16
+        h2, w2 = h // 2, w // 2
+        xs = torch.empty((n, h2, w2, 16), dtype=torch.bfloat16, device=x.device)
+        check(lib.wm_image_to_s2d(x.data_ptr(), fmt, n, h, w, ptr(xs), stream_ptr()), "wm_image_to_s2d")
+        ws2d, _ = _WCACHE.get(weight, kind="stem")
+        y = _empty_nhwc(n, k, h2, w2, x.device)
+        check(lib.wm_conv2d_fwd(ptr(xs), ptr(ws2d), y.data_ptr(), n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2, stream_ptr()),
+              "wm_conv2d_fwd(stem)")
+        ctx.save_for_backward(xs)
+        ctx.geom = (n, h2, w2, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xs,) = ctx.saved_tensors
+        n, h2, w2, k = ctx.geom
+        dy = _as_nhwc(dy)
+        lib = _lib.load()
+        ws = torch.zeros((k, 4, 4, 16), dtype=torch.float32, device=dy.device)
+        check(lib.wm_conv2d_wgrad(dy.data_ptr(), ptr(xs), ptr(ws), n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2, stream_ptr()),
+              "wm_conv2d_wgrad(stem)")
+        dw = torch.empty((k, 3, 7, 7), dtype=torch.float32, device=dy.device)
+        check(lib.wm_stem_wgrad_finalize(ptr(ws), k, ptr(dw), 0, stream_ptr()), "wm_stem_wgrad_finalize")
+        return None, dw
+
+
+def stem_conv(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    return _StemConv.apply(x, weight)
+
+
+_BN_WS = {}
+
+
+def _bn_workspace(rows: int, c: int, g: int, device) -> torch.Tensor:
+    need = _lib.load().wm_bn_workspace_bytes(rows, c, g)
+    if need == 0:
+        raise ValueError(f"batch_norm: unsupported shape rows={rows} C={c} G={g}")
+    ws = _BN_WS.get(device)
+    if ws is None or ws.numel() < need:
+        ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
+        _BN_WS[device] = ws
+    return ws
+
+
+def _rows_c(x: torch.Tensor):
+    if x.dim() == 4:
+        n, c, h, w = x.shape
+        return n * h * w, c
+    if x.dim() == 2:
+        return x.shape[0], x.shape[1]
+    raise ValueError("batch_norm expects [N,C,H,W] or [B,C]")
+
+
+def _as_act(x: torch.Tensor) -> torch.Tensor:
+    if x.dim() == 4:
+        return _as_nhwc(x)
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+    return x.contiguous()
+
+
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, residual, gamma, beta, running_mean, running_var, training, groups, eps, momentum, relu):
+        _need_cuda(y, "batch_norm")
+        y = _as_act(y)
+        if residual is not None:
+            residual = _as_act(residual)
+            if residual.shape != y.shape:
+                raise ValueError("batch_norm: residual shape mismatch")
+        rows, c = _rows_c(y)
+        lib = _lib.load()
+        out = torch.empty_like(y)
+        ws = _bn_workspace(rows, c, groups if training else 1, y.device)
+        if training:
+            if rows % groups:
+                raise ValueError("batch_norm: rows not divisible by groups")
+            mean = torch.empty((groups, c), dtype=torch.float32, device=y.device)
+            invstd = torch.empty_like(mean)
+            check(lib.wm_bn_train_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma), ptr(beta),
+                                      ptr(running_mean), ptr(running_var), rows, c, groups, eps, momentum, int(relu),
+                                      ptr(mean), ptr(invstd), out.data_ptr(), ptr(ws), ws.numel(), stream_ptr()),
+                  "wm_bn_train_fwd")
+            ctx.save_for_backward(y, out if relu else None, gamma, mean, invstd)
+            ctx.meta = (rows, c, groups, relu, residual is not None)
+        else:
+            check(lib.wm_bn_eval_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma), ptr(beta),
+                                     ptr(running_mean), ptr(running_var), rows, c, eps, int(relu), out.data_ptr(),
+                                     ptr(ws), ws.numel(), stream_ptr()), "wm_bn_eval_fwd")
+            ctx.meta = None
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        if ctx.meta is None:
+            raise NotImplementedError("batch_norm: backward through eval-mode statistics is not implemented")
+        y, out, gamma, mean, invstd = ctx.saved_tensors
+        rows, c, groups, relu, has_res = ctx.meta
+        dout = _as_act(dout)
+        lib = _lib.load()
+        dy = torch.empty_like(y)
+        dz = torch.empty_like(y) if has_res else None
+        dgamma = torch.empty((c,), dtype=torch.float32, device=y.device)
+        dbeta = torch.empty_like(dgamma)
+        ws = _bn_workspace(rows, c, groups, y.device)
+        check(lib.wm_bn_train_bwd(y.data_ptr(), dout.data_ptr(), out.data_ptr() if relu else 0, ptr(gamma), ptr(mean),
+                                  ptr(invstd), rows, c, groups, ptr(dgamma), ptr(dbeta), 0, dy.data_ptr(),
+                                  dz.data_ptr() if has_res else 0, ptr(ws), ws.numel(), stream_ptr()), "wm_bn_train_bwd")
+        return dy, dz, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def batch_norm(y, gamma, beta, running_mean, running_var, training: bool, residual=None, relu: bool = False,
+               eps: float = 1e-5, momentum: float = 0.1, groups: Optional[int] = None):
+    """out = relu?(BN(y) (+ residual)) on bf16 [N,C,H,W] (NHWC) or [B,C]."""
+    g = current_bn_groups() if groups is None else groups
+    return _BatchNorm.apply(y, residual, gamma, beta, running_mean, running_var, bool(training), int(g), float(eps),
+                            float(momentum), bool(relu))
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x, "max_pool")
+        x = _as_nhwc(x)
+        n, c, h, w = x.shape
+        p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = _empty_nhwc(n, c, p, q, x.device)
+        idx = torch.empty((n, p, q, c), dtype=torch.uint8, device=x.device)
+        check(_lib.load().wm_maxpool3x3s2_fwd(x.data_ptr(), n, h, w, c, y.data_ptr(), ptr(idx), stream_ptr()),
+              "wm_maxpool3x3s2_fwd")
+        ctx.save_for_backward(idx)
+        ctx.geom = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        n, c, h, w = ctx.geom
+        dy = _as_nhwc(dy)
+        dx = _empty_nhwc(n, c, h, w, dy.device)
+        check(_lib.load().wm_maxpool3x3s2_bwd(dy.data_ptr(), ptr(idx), n, h, w, c, dx.data_ptr(), stream_ptr()),
+              "wm_maxpool3x3s2_bwd")
+        return dx
+
+
+def max_pool3x3s2(x: torch.Tensor) -> torch.Tensor:
+    """nn.MaxPool2d(kernel_size=3, stride=2, padding=1)."""
+    return _MaxPool.apply(x)
+
+
+class _GlobalAvgPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _need_cuda(x, "global_avg_pool")
+        x = _as_nhwc(x)
+        n, c, h, w = x.shape
+        y = torch.empty((n, c), dtype=torch.bfloat16, device=x.device)
+        check(_lib.load().wm_gap_fwd(x.data_ptr(), n, h * w, c, ptr(y), stream_ptr()), "wm_gap_fwd")
+        ctx.geom = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.geom
+        dy = dy.to(torch.bfloat16).contiguous()
+        dx = _empty_nhwc(n, c, h, w, dy.device)
+        check(_lib.load().wm_gap_bwd(ptr(dy), n, h * w, c, dx.data_ptr(), stream_ptr()), "wm_gap_bwd")
+        return dx
+
+
+def global_avg_pool(x: torch.Tensor) -> torch.Tensor:
+    """[N,C,H,W] -> [N,C] (mean over H*W), bf16."""
+    return _GlobalAvgPool.apply(x)
+
+
+class _Linear(torch.autograd.Function):
+    """y = x @ W^T as the 1x1 convolution on a 1x1 image (same MFMA kernel)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _need_cuda(x, "linear")
+        if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1]:
+            raise ValueError(f"linear: x {tuple(x.shape)} vs weight {tuple(weight.shape)}")
+        x = _as_act(x)
+        b, c = x.shape
+        k = weight.shape[0]
+        train = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
+        krsc, _ = _WCACHE.get(weight, kind="linear", need_crsk=train and x.requires_grad)
+        y = torch.empty((b, k), dtype=torch.bfloat16, device=x.device)
+        check(_lib.load().wm_conv2d_fwd(ptr(x), ptr(krsc), ptr(y), b, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
+              "wm_conv2d_fwd(linear)")
+        ctx.save_for_backward(x)
+        ctx.weight = weight
+        ctx.geom = (b, c, k)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        weight = ctx.weight
+        b, c, k = ctx.geom
+        dy = _as_act(dy)
+        lib = _lib.load()
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            _, crsk = _WCACHE.get(weight, kind="linear", need_crsk=True)
+            dx = torch.empty((b, c), dtype=torch.bfloat16, device=dy.device)
+            check(lib.wm_conv2d_dgrad(ptr(dy), ptr(crsk), ptr(dx), b, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
+                  "wm_conv2d_dgrad(linear)")
+        if ctx.needs_input_grad[1]:
+            dw = torch.zeros((k, c), dtype=torch.float32, device=dy.device)  # [K][1][1][C] == OIHW for 1x1
+            check(lib.wm_conv2d_wgrad(ptr(dy), ptr(x), ptr(dw), b, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
+                  "wm_conv2d_wgrad(linear)")
+        return dx, dw
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """Bias-free nn.Linear: x bf16 [B, C], weight float32 [K, C] -> bf16 [B, K]."""
+    return _Linear.apply(x, weight)

@@ -1,0 +1,247 @@
+"""GPU parity of the conv / BN / pool / linear kernels against torch CPU float32 on the same
+(bf16-rounded) inputs.  Tolerances: bf16 output rounding (2^-9 relative) + f32 summation order."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _bf(x):
+    return x.bfloat16().float()
+
+
+def _close(got, ref, rel=8e-3, what=""):
+    got, ref = got.float().cpu(), ref.float()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+
+
+# (N, C, H, W, K, R, stride, pad): every distinct conv of ResNet-18 at a small batch + ragged tiles
+CONVS = [
+    (2, 64, 56, 56, 64, 3, 1, 1), (2, 64, 56, 56, 128, 3, 2, 1), (2, 64, 56, 56, 128, 1, 2, 0),
+    (2, 128, 28, 28, 128, 3, 1, 1), (2, 128, 28, 28, 256, 3, 2, 1), (2, 128, 28, 28, 256, 1, 2, 0),
+    (3, 256, 14, 14, 256, 3, 1, 1), (3, 256, 14, 14, 512, 3, 2, 1), (3, 256, 14, 14, 512, 1, 2, 0),
+    (5, 512, 7, 7, 512, 3, 1, 1), (1, 64, 9, 11, 64, 3, 1, 1), (1, 128, 5, 7, 64, 3, 2, 1),
+]
+
+
+@pytest.mark.parametrize("cfg", CONVS)
+def test_conv2d_fwd_bwd(cfg):
+    from ssl_wafermap_amd import ops
+
+    n, c, h, w, k, r, stride, pad = cfg
+    g = torch.Generator().manual_seed(sum(cfg))
+    x = _bf(torch.randn(n, c, h, w, generator=g))
+    wt = _bf(torch.randn(k, c, r, r, generator=g) * (2.0 / (c * r * r)) ** 0.5)
+    xr, wr = x.clone().requires_grad_(True), wt.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, None, stride, pad)
+    dy = _bf(torch.randn(yr.shape, generator=g))
+    yr.backward(dy)
+    xd = ops.to_nhwc_bf16(x.to(DEV)).requires_grad_(True)
+    wd = wt.to(DEV).requires_grad_(True)
+    yd = ops.conv2d(xd, wd, stride, pad)
+    assert yd.shape == yr.shape and yd.dtype == torch.bfloat16
+    yd.backward(ops.to_nhwc_bf16(dy.to(DEV)))
+    _close(yd, yr.detach(), what="fwd")
+    _close(xd.grad, xr.grad, what="dgrad")
+    _close(wd.grad, wr.grad, rel=4e-3, what="wgrad")
+
+
+def test_conv_weight_cache_follows_updates():
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    x = ops.to_nhwc_bf16(torch.randn(1, 64, 8, 8, generator=g).to(DEV))
+    w = torch.nn.Parameter((torch.randn(64, 64, 3, 3, generator=g) * 0.05).to(DEV))
+    y1 = ops.conv2d(x, w, 1, 1).float()
+    with torch.no_grad():
+        w.mul_(2.0)
+    y2 = ops.conv2d(x, w, 1, 1).float()
+    _close(y2, (2 * y1).cpu(), what="after in-place update")
+
+
+@pytest.mark.parametrize("n,hw", [(2, 224), (3, 64)])
+def test_stem_conv(n, hw):
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(n)
+    x = _bf(torch.randn(n, 3, hw, hw, generator=g))
+    wt = _bf(torch.randn(64, 3, 7, 7, generator=g) * 0.1)
+    wr = wt.clone().requires_grad_(True)
+    yr = F.conv2d(x, wr, None, 2, 3)
+    dy = _bf(torch.randn(yr.shape, generator=g))
+    yr.backward(dy)
+    for xin in (x.to(DEV), ops.to_nhwc_bf16(x.to(DEV))):  # float32 NCHW and bf16 NHWC entries
+        wd = wt.to(DEV).requires_grad_(True)
+        yd = ops.stem_conv(xin, wd)
+        yd.backward(ops.to_nhwc_bf16(dy.to(DEV)))
+        _close(yd, yr.detach(), what="stem fwd")
+        _close(wd.grad, wr.grad, rel=4e-3, what="stem wgrad")
+
+
+@pytest.mark.parametrize("shape,groups,relu,res", [((4, 64, 14, 14), 1, True, False), ((4, 128, 7, 7), 2, True, True),
+                                                   ((6, 512, 3, 3), 2, False, False), ((64, 512), 2, True, False),
+                                                   ((32, 128), 1, False, False), ((2, 64, 112, 112), 1, True, False)])
+def test_batch_norm_train(shape, groups, relu, res):
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(len(shape) + groups)
+    c = shape[1]
+    y = _bf(torch.randn(shape, generator=g) * 2 + 0.5)
+    r = _bf(torch.randn(shape, generator=g)) if res else None
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    dout = _bf(torch.randn(shape, generator=g))
+    yr = y.clone().requires_grad_(True)
+    rr = r.clone().requires_grad_(True) if res else None
+    gr, br = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    rm, rv = torch.zeros(c), torch.ones(c)
+    outs = []
+    for part, rpart in zip(yr.chunk(groups), rr.chunk(groups) if res else [None] * groups):
+        o = F.batch_norm(part, rm, rv, gr, br, True, 0.1, 1e-5)
+        if res:
+            o = o + rpart
+        outs.append(F.relu(o) if relu else o)
+    oref = torch.cat(outs)
+    oref.backward(dout)
+
+    def dv(t):
+        t = t.to(DEV)
+        return ops.to_nhwc_bf16(t) if t.dim() == 4 else t.bfloat16()
+
+    yd = dv(y).requires_grad_(True)
+    rd = dv(r).requires_grad_(True) if res else None
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    rmd, rvd = torch.zeros(c, device=DEV), torch.ones(c, device=DEV)
+    od = ops.batch_norm(yd, gd, bd, rmd, rvd, True, residual=rd, relu=relu, groups=groups)
+    od.backward(dv(dout))
+    _close(od, oref.detach(), what="bn out")
+    _close(yd.grad, yr.grad, rel=1.5e-2, what="bn dy")
+    if res:
+        _close(rd.grad, rr.grad, what="bn dresidual")
+    _close(gd.grad, gr.grad, rel=1e-2, what="dgamma")
+    _close(bd.grad, br.grad, rel=1e-2, what="dbeta")
+    torch.testing.assert_close(rmd.cpu(), rm, atol=2e-3, rtol=1e-2)
+    torch.testing.assert_close(rvd.cpu(), rv, atol=2e-3, rtol=1e-2)
+
+
+def test_batch_norm_eval():
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    y = _bf(torch.randn(3, 64, 5, 5, generator=g))
+    gamma, beta = torch.rand(64, generator=g) + 0.5, torch.randn(64, generator=g)
+    rm, rv = torch.randn(64, generator=g), torch.rand(64, generator=g) + 0.5
+    ref = F.relu(F.batch_norm(y, rm, rv, gamma, beta, False, 0.1, 1e-5))
+    out = ops.batch_norm(ops.to_nhwc_bf16(y.to(DEV)), gamma.to(DEV), beta.to(DEV), rm.to(DEV), rv.to(DEV), False,
+                         relu=True)
+    _close(out, ref, what="bn eval")
+
+
+def test_max_pool_matches_torch_including_ties():
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    x = F.relu(_bf(torch.randn(3, 64, 20, 22, generator=g)))  # many exact zeros -> ties
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 3, 2, 1)
+    dy = _bf(torch.randn(yr.shape, generator=g))
+    yr.backward(dy)
+    xd = ops.to_nhwc_bf16(x.to(DEV)).requires_grad_(True)
+    yd = ops.max_pool3x3s2(xd)
+    yd.backward(ops.to_nhwc_bf16(dy.to(DEV)))
+    assert torch.equal(yd.float().cpu(), yr.detach())
+    _close(xd.grad, xr.grad, rel=8e-3, what="maxpool bwd")
+
+
+def test_global_avg_pool():
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    x = _bf(torch.randn(5, 512, 7, 7, generator=g))
+    xr = x.clone().requires_grad_(True)
+    yr = F.adaptive_avg_pool2d(xr, 1).flatten(1)
+    dy = _bf(torch.randn(5, 512, generator=g))
+    yr.backward(dy)
+    xd = ops.to_nhwc_bf16(x.to(DEV)).requires_grad_(True)
+    yd = ops.global_avg_pool(xd)
+    yd.backward(dy.to(DEV).bfloat16())
+    _close(yd, yr.detach(), what="gap")
+    _close(xd.grad, xr.grad, what="gap bwd")
+
+
+@pytest.mark.parametrize("b,c,k", [(512, 512, 512), (512, 512, 128), (37, 128, 64)])
+def test_linear(b, c, k):
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(b)
+    x = _bf(torch.randn(b, c, generator=g))
+    w = _bf(torch.randn(k, c, generator=g) * c ** -0.5)
+    xr, wr = x.clone().requires_grad_(True), w.clone().requires_grad_(True)
+    yr = F.linear(xr, wr)
+    dy = _bf(torch.randn(b, k, generator=g))
+    yr.backward(dy)
+    xd, wd = x.to(DEV).bfloat16().requires_grad_(True), w.to(DEV).requires_grad_(True)
+    yd = ops.linear(xd, wd)
+    yd.backward(dy.to(DEV).bfloat16())
+    _close(yd, yr.detach(), what="linear")
+    _close(xd.grad, xr.grad, what="linear dx")
+    _close(wd.grad, wr.grad, rel=4e-3, what="linear dw")
+
+
+def test_resnet18_forward_backward_matches_oracle():
+    """Whole backbone + SimCLR head, train mode, two BN groups == the reference's two forwards."""
+    from oracle import resnet as orn
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.heads import SimCLRProjectionHead
+    from ssl_wafermap_amd.models import create_model
+
+    torch.manual_seed(0)
+    backbone = create_model("resnet18", num_classes=0)
+    head = SimCLRProjectionHead(512, 512, 128)
+    for m in backbone.modules():  # un-zero the last BN gammas so every path carries signal
+        if hasattr(m, "bn2"):
+            torch.nn.init.constant_(m.bn2.weight, 0.5)
+    sd = {"backbone." + k: v.clone() for k, v in backbone.state_dict().items()}
+    sd.update({"projection_head." + k: v.clone() for k, v in head.state_dict().items()})
+    sd = {k: (_bf(v) if v.dtype == torch.float32 and v.dim() > 1 else v) for k, v in sd.items()}  # bf16-exact weights
+    backbone.load_state_dict({k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")})
+    head.load_state_dict({k[len("projection_head."):]: v for k, v in sd.items() if k.startswith("projection_head.")})
+    g = torch.Generator().manual_seed(1)
+    lut = torch.tensor([-1.5366, 0.1790, 1.8811])
+    x0 = _bf(lut[torch.randint(0, 3, (8, 1, 64, 64), generator=g)].expand(-1, 3, -1, -1).contiguous())
+    x1 = _bf(lut[torch.randint(0, 3, (8, 1, 64, 64), generator=g)].expand(-1, 3, -1, -1).contiguous())
+    params = {k: v.clone().requires_grad_(v.dtype == torch.float32 and "running" not in k) for k, v in sd.items()}
+    loss_ref, (f0, f1, z0, z1) = orn.simclr_loss(x0, x1, params, 0.5, True)
+    loss_ref.backward()
+
+    backbone.to(DEV).train()
+    head.to(DEV).train()
+    from ssl_wafermap_amd.loss import NTXentLoss
+
+    with ops.bn_groups(2):
+        f = backbone(torch.cat([x0, x1]).to(DEV))
+        z = head(f)
+    loss = NTXentLoss(0.5)(z[:8], z[8:])
+    loss.backward()
+    fr = torch.cat([f0, f1]).detach()
+    cos = F.cosine_similarity(f.float().cpu(), fr, dim=1)
+    assert (1 - cos).max() < 1e-3, f"backbone embedding cosine distance {float((1 - cos).max()):.2e}"
+    zr = torch.cat([z0, z1]).detach()
+    cosz = F.cosine_similarity(z.float().cpu(), zr, dim=1)
+    assert (1 - cosz).max() < 5e-3
+    assert abs(loss.item() - loss_ref.item()) / loss_ref.item() < 2e-2
+    # gradients: direction agreement per parameter tensor
+    worst = 1.0
+    for name, p in list(backbone.named_parameters()) + [("projection_head." + n, p) for n, p in head.named_parameters()]:
+        key = name if name.startswith("projection_head.") else "backbone." + name
+        gr = params[key].grad
+        c = F.cosine_similarity(p.grad.flatten().float().cpu(), gr.flatten(), dim=0).item()
+        worst = min(worst, c)
+        assert c > 0.98, f"{key}: gradient cosine {c:.4f}"
+    # running statistics were updated twice (two groups), as two reference forwards do
+    torch.testing.assert_close(backbone.bn1.running_mean.cpu(), params["backbone.bn1.running_mean"], atol=2e-3, rtol=2e-2)
+    assert int(backbone.bn1.num_batches_tracked) == 2
