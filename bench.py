@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: SimCLR ResNet-18 training throughput on synthetic wafer maps (BASELINE.json).
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one pass of the hot path over one batch: fused two-view augmentation of 256 wafers per
+GPU -> ResNet-18 forward/backward on 2 x 256 images (3 x 224 x 224, bf16, BN statistics per view) ->
+SimCLR projection head -> NT-Xent (in-batch negatives) -> (N > 1: flat RCCL all-reduce of the
+gradient arena) -> fused SGD.  All device work runs in the hand-written HIP kernels of
+libwafer_hip.so; inputs (the ragged uint8 wafer store) are resident in HBM before the timed region.
+
+Prints ONE JSON line (rank 0): metric imgs/sec = wafers (not views) per second, whole job.
+  roofline     : the conv implicit-GEMM kernels (fwd + dgrad + wgrad), algorithmic FLOPs / the summed
+                 HIP-event durations of those launches inside the timed region, vs dense bf16 MFMA peak.
+  cpu_baseline : the torch-CPU oracle (oracle/) running BASELINE configs[0] (bs 32, fp32) on the
+                 host cores for a bounded number of steps (rank 0, N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent
+sys.path.insert(0, str(ROOT))
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md chip table
+R18_GFLOP_PER_SAMPLE = 21.76    # ResNet-18 fwd 3.627 GFLOP x 3 (fwd+bwd) x 2 views
+
+
+def cpu_baseline(seconds_budget: float = 25.0):
+    """Oracle SimCLR step (torch CPU float32), BASELINE configs[0]: bs 32, two views, SGD."""
+    import numpy as np
+    import torch
+
+    from oracle import augment as oa
+    from oracle import resnet as orn
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.heads import SimCLRProjectionHead
+    from ssl_wafermap_amd.models import create_model
+
+    torch.manual_seed(0)
+    cores = torch.get_num_threads()
+    wafers, _ = synthetic_wafers(64, seed=1234)
+    backbone, head = create_model("resnet18", num_classes=0), SimCLRProjectionHead(512, 512, 128)
+    sd = {"backbone." + k: v.clone() for k, v in backbone.state_dict().items()}
+    sd.update({"projection_head." + k: v.clone() for k, v in head.state_dict().items()})
+    params = {k: v.requires_grad_(True) for k, v in sd.items() if v.dtype == torch.float32 and "running" not in k}
+    state = dict(sd)
+    state.update(params)
+    bufs = {}
+    rng = np.random.default_rng(0)
+    bs = 32
+
+    def step(i):
+        idx = (np.arange(bs) + i * bs) % len(wafers)
+        views = []
+        for _ in range(2):
+            imgs = []
+            for s in idx:
+                w = wafers[s]
+                op = oa.OP_DIENOISE if rng.random() < 0.5 else oa.OP_DPW
+                d = oa.ViewDecision(op=op, noise_seed=int(rng.integers(1 << 31)),
+                                    dpw_hw=oa.dpw_dims(*w.shape, oa.dpw_scale(w.shape, rng.beta(0.5, 1.5))),
+                                    rot90=rng.random() < 0.5, vflip=rng.random() < 0.5, hflip=rng.random() < 0.5)
+                imgs.append(oa.augment_view(w, d))
+            views.append(torch.from_numpy(np.stack(imgs)))
+        for p in params.values():
+            p.grad = None
+        loss, _ = orn.simclr_loss(views[0], views[1], state, 0.5, True)
+        loss.backward()
+        with torch.no_grad():
+            orn.sgd_step({k: p for k, p in params.items()}, {k: p.grad for k, p in params.items()}, bufs,
+                         lr=6e-2 * bs / 256)
+        return float(loss)
+
+    step(0)  # warm-up
+    t0 = time.perf_counter()
+    n = 0
+    while True:
+        step(n + 1)
+        n += 1
+        if time.perf_counter() - t0 > seconds_budget or n >= 8:
+            break
+    dt = time.perf_counter() - t0
+    return {"value": round(bs * n / dt, 3), "unit": "imgs/sec", "cores": cores, "kind": "port",
+            "sample": f"{n} SimCLR ResNet-18 steps at bs {bs} (fp32, torch CPU oracle incl. numpy augmentation), "
+                      f"{dt:.1f} s"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=256, help="wafers per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timer", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    from ssl_wafermap_amd import distributed as wdist
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.data import WaferMapDataset
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.models import SimCLR
+    from ssl_wafermap_amd.transforms import BaseViewTransform
+
+    rank, world, local = wdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    B = args.batch
+    wafers, labels = synthetic_wafers(4096, seed=1234 + rank)
+    ds = WaferMapDataset(wafers, labels, transform=BaseViewTransform(), device=dev)
+    torch.manual_seed(0)
+    model = SimCLR(None, 9, batch_size=B * world, max_epochs=150, gather_distributed=False).to(dev).train()
+    (opt,), _ = model.configure_optimizers()
+    sync = wdist.GradSync(opt)
+    rng = np.random.default_rng(rank)
+
+    def step(i):
+        idx = (np.arange(B) + i * B) % len(ds)
+        batch = ds.get_batch(idx, rng)
+        opt.zero_grad()
+        loss = model.training_step(batch, i)
+        loss.backward()
+        sync.start()
+        sync.wait()
+        opt.step()
+        return loss
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        step(i)
+    timer = None if args.no_kernel_timer else ops.KernelTimer()
+    ops.TIMER = timer
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    fence()
+    dt = time.perf_counter() - t0
+    ops.TIMER = None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        imgs = B * world * args.steps
+        value = imgs / dt
+        roof = None
+        if timer is not None:
+            summ = timer.summary()
+            work = sum(v["work"] for v in summ.values())
+            ms = sum(v["ms"] for v in summ.values())
+            ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+            roof = {"bound": "mfma", "kernel": "conv_igemm + conv_wgrad (implicit-GEMM, bf16 MFMA)",
+                    "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+                    "launches": int(sum(v["launches"] for v in summ.values())),
+                    "kernel_ms_per_step": round(ms / args.steps, 3),
+                    "by_kernel": {k: {"TFLOP/s": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                      "ms_per_step": round(v["ms"] / args.steps, 3)} for k, v in summ.items()}}
+        out = {
+            "metric": "imgs/sec (SimCLR ResNet18, bs=256, 224^2)",
+            "value": round(value, 2), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": "SimCLR ResNet-18, 256 wafers/GPU/step, two 3x224x224 views, NT-Xent in-batch "
+                                   "negatives, SGD (BASELINE.json configs[1])",
+                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "model_tflop_per_step_per_gpu": round(R18_GFLOP_PER_SAMPLE * B / 1e3, 3),
+                       "model_mfma_frac": round(value / world * R18_GFLOP_PER_SAMPLE / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)},
+            "final_loss": round(final_loss, 4),
+            "roofline": roof,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

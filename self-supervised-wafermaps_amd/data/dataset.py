@@ -1,0 +1,88 @@
+"""WaferMapDataset + WaferLoader: the reference's dataset (src/ssl_wafermap/data/dataset.py:5-37)
+and its DataLoader usage (scripts/WM811k_benchmark.py:158-195) for a GPU-resident store.
+
+The reference augments one sample at a time in DataLoader worker processes and collates on the
+host; here the loader draws the batch's indices and random decisions on the host and the images
+are born on the device (one kernel launch per view size), already in the layout the convolutions
+read.  Batches have the reference's structure: (views, y) with views a list of [B,3,S,S] tensors
+(or a single tensor for single-view transforms with `unwrap_single=True`)."""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+
+from .store import WaferStore
+
+
+class WaferMapDataset:
+    def __init__(self, X, y=None, transform=None, device: Optional[str] = None):
+        self.store = WaferStore(list(X), device=device)
+        if y is not None:
+            self.y = torch.as_tensor(np.asarray(list(y)))
+        else:
+            self.y = torch.zeros(len(self.store), dtype=torch.long)  # SSL does not need labels
+        if len(self.y) != len(self.store):
+            raise ValueError("X and y differ in length")
+        self.transform = transform
+        if device is not None:
+            self.y = self.y.to(device)
+
+    def to(self, device):
+        self.store.to(device)
+        self.y = self.y.to(device)
+        return self
+
+    def __len__(self):
+        return len(self.store)
+
+    def get_batch(self, indices: np.ndarray, rng: np.random.Generator, fmt: str = "nhwc_bf16"):
+        if self.transform is None:
+            raise ValueError("WaferMapDataset.get_batch needs a transform (images are built by it)")
+        views = self.transform(self.store, np.asarray(indices), rng, fmt=fmt)
+        idx = torch.as_tensor(np.asarray(indices), device=self.y.device)
+        return views, self.y[idx]
+
+    def __getitem__(self, index):
+        views, y = self.get_batch(np.array([index]), np.random.default_rng())
+        return [v[0] for v in views], y[0]
+
+
+class WaferLoader:
+    """DataLoader(dataset, batch_size, shuffle, drop_last) for a WaferMapDataset.  Deterministic:
+    the permutation and every augmentation decision derive from (seed, epoch, batch index) for the
+    GLOBAL batch; with `world_size > 1` each rank takes its contiguous slice of that batch, so the
+    union over ranks is independent of the number of GPUs."""
+
+    def __init__(self, dataset: WaferMapDataset, batch_size: int, shuffle: bool = False, drop_last: bool = False,
+                 seed: int = 0, rank: int = 0, world_size: int = 1, fmt: str = "nhwc_bf16",
+                 unwrap_single: bool = True):
+        self.dataset, self.batch_size = dataset, int(batch_size)
+        self.shuffle, self.drop_last, self.seed = shuffle, drop_last, seed
+        self.rank, self.world_size, self.fmt, self.unwrap_single = rank, world_size, fmt, unwrap_single
+        self.epoch = 0
+
+    def set_epoch(self, epoch: int):
+        self.epoch = epoch
+
+    def __len__(self):
+        gb = self.batch_size * self.world_size
+        n = len(self.dataset)
+        return n // gb if self.drop_last else (n + gb - 1) // gb
+
+    def __iter__(self):
+        n = len(self.dataset)
+        gb = self.batch_size * self.world_size
+        order = np.random.default_rng([self.seed, self.epoch]).permutation(n) if self.shuffle else np.arange(n)
+        for b in range(len(self)):
+            glob = order[b * gb:(b + 1) * gb]
+            mine = glob[self.rank * self.batch_size:(self.rank + 1) * self.batch_size]
+            if len(mine) == 0:
+                continue
+            rng = np.random.default_rng([self.seed, self.epoch, b, self.rank])
+            views, y = self.dataset.get_batch(mine, rng, fmt=self.fmt)
+            if self.unwrap_single and len(views) == 1:
+                yield views[0], y
+            else:
+                yield views, y

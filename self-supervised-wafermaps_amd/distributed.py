@@ -1,0 +1,94 @@
+"""Data parallelism: one process per GPU, torch.distributed over RCCL ("nccl" backend on ROCm).
+
+The reference reaches DDP only through Lightning's `strategy="ddp"` flag, which is off in every
+published run (scripts/WM811k_benchmark.py:54,78-85).  Here the gradient exchange is explicit: the
+fused optimiser keeps all gradients in one flat float32 arena, which is all-reduced (SUM) in a few
+large buckets — xGMI is point-to-point (7 links x ~153 GB/s per GPU), so few, large collectives
+beat many small ones — and the 1/world averaging is folded into the SGD kernel's grad_scale.
+The sharded kNN exchange is a single all-gather of per-shard top-k lists followed by wm_knn_merge.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: Optional[str] = None) -> tuple:
+    """Initialise the default process group from RANK / WORLD_SIZE / LOCAL_RANK / MASTER_* (torchrun)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def rank() -> int:
+    return dist.get_rank() if dist.is_available() and dist.is_initialized() else 0
+
+
+class GradSync:
+    """All-reduce (SUM) of flat gradient arenas in `bucket_bytes` pieces, asynchronously; call
+    `wait()` before the optimiser step.  The sum is turned into the mean by the optimiser's
+    grad_scale = 1/world (set here)."""
+
+    def __init__(self, optimizer, bucket_bytes: int = 32 << 20):
+        self.optimizer = optimizer
+        self.bucket_elems = max(1, bucket_bytes // 4)
+        self.handles: List = []
+        w = world_size()
+        if hasattr(optimizer, "grad_scale"):
+            optimizer.grad_scale = 1.0 / w
+
+    def start(self) -> None:
+        if world_size() == 1:
+            return
+        for arena in self.optimizer.grad_arenas:
+            for o in range(0, arena.numel(), self.bucket_elems):
+                self.handles.append(dist.all_reduce(arena[o:o + self.bucket_elems], op=dist.ReduceOp.SUM, async_op=True))
+
+    def wait(self) -> None:
+        for h in self.handles:
+            h.wait()
+        self.handles.clear()
+
+
+def sync_bn_buffers(module: torch.nn.Module) -> None:
+    """Rank 0's BatchNorm running statistics to everyone (DDP's broadcast_buffers)."""
+    if world_size() == 1:
+        return
+    for b in module.buffers():
+        dist.broadcast(b, src=0)
+
+
+def sharded_knn_topk(query: torch.Tensor, bank_shard: torch.Tensor, k: int, shard_offset: int):
+    """Global top-k over a row-sharded bank: local top-k with global indices, ONE all-gather of the
+    [nq, k] (sim, idx) lists, merge.  Every rank passes the same queries."""
+    from . import functional as F_hip
+
+    sim, idx = F_hip.knn_topk(query, bank_shard, min(k, bank_shard.shape[0]), index_base=shard_offset)
+    if sim.shape[1] < k:  # a shard smaller than k: pad with -inf so lists have equal length
+        pad = k - sim.shape[1]
+        sim = torch.cat([sim, torch.full((sim.shape[0], pad), float("-inf"), device=sim.device)], 1)
+        idx = torch.cat([idx, torch.full((idx.shape[0], pad), 2**31 - 1, dtype=torch.int32, device=idx.device)], 1)
+    w = world_size()
+    if w == 1:
+        return sim, idx
+    sims = [torch.empty_like(sim) for _ in range(w)]
+    idxs = [torch.empty_like(idx) for _ in range(w)]
+    dist.all_gather(sims, sim.contiguous())
+    dist.all_gather(idxs, idx.contiguous())
+    return F_hip.knn_merge(torch.stack(sims), torch.stack(idxs))

@@ -1,1 +1,3 @@
+from .knn import KNNBenchmarkModule, macro_metrics  # noqa: F401
 from .resnet import ResNet18, create_model  # noqa: F401
+from .simclr import SimCLR  # noqa: F401

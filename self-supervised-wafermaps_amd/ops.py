@@ -18,6 +18,40 @@ from ._lib import check, ptr, stream_ptr
 _WEIGHT_EPOCH = 0  # bumped by optimisers that update parameters through raw pointers
 
 
+class KernelTimer:
+    """HIP-event bracket around selected launches (bench.py's live roofline measurement): events
+    are recorded on the stream the kernel is enqueued on, elapsed times are read after a sync."""
+
+    def __init__(self):
+        self.records = []  # (name, algorithmic work, start event, end event)
+
+    def run(self, name, work, fn, *args):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        rc = fn(*args)
+        b.record()
+        self.records.append((name, work, a, b))
+        return rc
+
+    def summary(self):
+        out = {}
+        for name, work, a, b in self.records:
+            d = out.setdefault(name, {"launches": 0, "work": 0.0, "ms": 0.0})
+            d["launches"] += 1
+            d["work"] += work
+            d["ms"] += a.elapsed_time(b)
+        return out
+
+
+TIMER = None  # set to a KernelTimer to bracket the conv launches
+
+
+def _run(name, work, fn, *args):
+    if TIMER is None:
+        return fn(*args)
+    return TIMER.run(name, work, fn, *args)
+
+
 def bump_weight_epoch() -> None:
     global _WEIGHT_EPOCH
     _WEIGHT_EPOCH += 1
@@ -124,8 +158,8 @@ class _Conv2d(torch.autograd.Function):
         train = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
         krsc, _ = _WCACHE.get(weight, need_crsk=train and x.requires_grad)
         y = _empty_nhwc(n, k, p, q, x.device)
-        check(_lib.load().wm_conv2d_fwd(ptr(x), ptr(krsc), y.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad,
-                                        stream_ptr()), "wm_conv2d_fwd")
+        check(_run("conv_fwd", 2.0 * n * p * q * k * r * s * c, _lib.load().wm_conv2d_fwd, ptr(x), ptr(krsc),
+                   y.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_fwd")
         ctx.save_for_backward(x)
         ctx.weight = weight
         ctx.geom = (n, h, w, c, k, r, s, p, q, stride, pad)
@@ -142,12 +176,12 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, crsk = _WCACHE.get(weight, need_crsk=True)
             dx = _empty_nhwc(n, c, h, w, dy.device)
-            check(lib.wm_conv2d_dgrad(dy.data_ptr(), ptr(crsk), dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad,
-                                      stream_ptr()), "wm_conv2d_dgrad")
+            check(_run("conv_dgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_dgrad, dy.data_ptr(), ptr(crsk),
+                       dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_dgrad")
         if ctx.needs_input_grad[1]:
             ws = torch.zeros((k, r, s, c), dtype=torch.float32, device=dy.device)
-            check(lib.wm_conv2d_wgrad(dy.data_ptr(), x.data_ptr(), ptr(ws), n, h, w, c, k, r, s, p, q, stride, pad,
-                                      stream_ptr()), "wm_conv2d_wgrad")
+            check(_run("conv_wgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_wgrad, dy.data_ptr(), x.data_ptr(),
+                       ptr(ws), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_wgrad")
             dw = torch.empty((k, c, r, s), dtype=torch.float32, device=dy.device)
             check(lib.wm_wgrad_finalize(ptr(ws), k, c, r, s, ptr(dw), 0, stream_ptr()), "wm_wgrad_finalize")
         return dx, dw, None, None
@@ -182,8 +216,8 @@ class _StemConv(torch.autograd.Function):
         check(lib.wm_image_to_s2d(x.data_ptr(), fmt, n, h, w, ptr(xs), stream_ptr()), "wm_image_to_s2d")
         ws2d, _ = _WCACHE.get(weight, kind="stem")
         y = _empty_nhwc(n, k, h2, w2, x.device)
-        check(lib.wm_conv2d_fwd(ptr(xs), ptr(ws2d), y.data_ptr(), n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2, stream_ptr()),
-              "wm_conv2d_fwd(stem)")
+        check(_run("conv_fwd", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_fwd, ptr(xs), ptr(ws2d), y.data_ptr(), n, h2, w2,
+                   16, k, 4, 4, h2, w2, 1, 2, stream_ptr()), "wm_conv2d_fwd(stem)")
         ctx.save_for_backward(xs)
         ctx.geom = (n, h2, w2, k)
         return y
@@ -195,8 +229,8 @@ class _StemConv(torch.autograd.Function):
         dy = _as_nhwc(dy)
         lib = _lib.load()
         ws = torch.zeros((k, 4, 4, 16), dtype=torch.float32, device=dy.device)
-        check(lib.wm_conv2d_wgrad(dy.data_ptr(), ptr(xs), ptr(ws), n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2, stream_ptr()),
-              "wm_conv2d_wgrad(stem)")
+        check(_run("conv_wgrad", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_wgrad, dy.data_ptr(), ptr(xs), ptr(ws), n, h2,
+                   w2, 16, k, 4, 4, h2, w2, 1, 2, stream_ptr()), "wm_conv2d_wgrad(stem)")
         dw = torch.empty((k, 3, 7, 7), dtype=torch.float32, device=dy.device)
         check(lib.wm_stem_wgrad_finalize(ptr(ws), k, ptr(dw), 0, stream_ptr()), "wm_stem_wgrad_finalize")
         return None, dw

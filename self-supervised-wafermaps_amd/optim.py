@@ -1,0 +1,81 @@
+"""Fused optimiser over flat parameter / gradient arenas.
+
+`SGD` computes exactly torch.optim.SGD's update (momentum, weight decay, no dampening / nesterov —
+what the reference's SimCLR uses, scripts/WM811k_benchmark.py:250-255) in ONE kernel launch over a
+contiguous float32 arena.  Parameters keep their identity (their .data become views of the arena,
+their .grad views of the gradient arena), so LR schedulers, state_dicts and a flat RCCL all-reduce
+of the gradients all work on the same memory.
+"""
+from __future__ import annotations
+
+from typing import List
+
+import torch
+
+from . import _lib, ops
+from ._lib import check, ptr, stream_ptr
+
+_ALIGN = 64  # elements: every parameter starts on a 256-byte boundary
+
+
+class _Arena:
+    def __init__(self, params: List[torch.nn.Parameter]):
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise _lib.WaferHipError("fused SGD needs parameters on the GPU")
+        offs, total = [], 0
+        for p in params:
+            if p.dtype != torch.float32:
+                raise TypeError("fused SGD arena holds float32 parameters only")
+            offs.append(total)
+            total += (p.numel() + _ALIGN - 1) // _ALIGN * _ALIGN
+        self.numel = total
+        self.params = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.grads = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.momentum = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                n = p.numel()
+                self.params[o:o + n].copy_(p.detach().reshape(-1))
+                p.data = self.params[o:o + n].view(p.shape)
+                p.grad = self.grads[o:o + n].view(p.shape)
+        self.offsets = offs
+
+
+class SGD(torch.optim.Optimizer):
+    def __init__(self, params, lr: float, momentum: float = 0.0, weight_decay: float = 0.0, grad_scale: float = 1.0):
+        if lr < 0 or momentum < 0 or weight_decay < 0:
+            raise ValueError("invalid SGD hyper-parameter")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self.grad_scale = float(grad_scale)
+        self._arenas, self._hyper, self._hyper_host = [], [], []
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            arena = _Arena(ps)
+            self._arenas.append(arena)
+            self._hyper.append(torch.zeros(4, dtype=torch.float32, device=arena.params.device))
+            self._hyper_host.append(None)
+        ops.bump_weight_epoch()
+
+    @property
+    def grad_arenas(self) -> List[torch.Tensor]:
+        """Flat gradient buffers (one per param group): what data-parallel training all-reduces."""
+        return [a.grads for a in self._arenas]
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        for a in self._arenas:
+            a.grads.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        lib = _lib.load()
+        for group, arena, hyper, i in zip(self.param_groups, self._arenas, self._hyper, range(len(self._arenas))):
+            h = (float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]), self.grad_scale)
+            if h != self._hyper_host[i]:
+                hyper.copy_(torch.tensor(h, dtype=torch.float32), non_blocking=False)
+                self._hyper_host[i] = h
+            check(lib.wm_sgd_step(ptr(arena.params), ptr(arena.grads), ptr(arena.momentum), arena.numel, ptr(hyper),
+                                  stream_ptr()), "wm_sgd_step")
+        ops.bump_weight_epoch()
+        return loss

@@ -3,3 +3,4 @@ from .augmentations import (  # noqa: F401
     get_inference_transforms, multicrop_view, sample_view_params,
 )
 from .utils import NORMALIZE_STATS  # noqa: F401
+from .views import BaseViewTransform, InferenceTransform, MultiCropTransform, MultiViewTransform, Views  # noqa: F401

@@ -1,0 +1,87 @@
+"""Multi-view transforms with the reference's names and constructor signatures:
+BaseViewTransform (src/ssl_wafermap/transforms/wafer_base_transform.py:8-59) and
+MultiCropTransform (src/ssl_wafermap/transforms/wafer_multicrop_transform.py:88-171), both
+lightly MultiViewTransforms = a list of per-view pipelines.  Here a pipeline is a ViewSpec and a
+whole batch of every view is produced by one kernel launch per output size."""
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from ..data.store import WaferStore
+from .augmentations import (ViewSpec, augment_views, get_base_transforms, get_inference_transforms, multicrop_view,
+                            sample_view_params)
+from .utils import NORMALIZE_STATS
+
+
+class Views(list):
+    """List of per-view batch tensors; `.stacked` is the same memory as one [V*B, ...] tensor when
+    all views share a size (lets the model run every view in one pass without a concat copy)."""
+
+    stacked = None
+
+
+class MultiViewTransform:
+    def __init__(self, transforms: Sequence[ViewSpec]):
+        self.transforms = list(transforms)
+
+    def __call__(self, store: WaferStore, sample_idx: np.ndarray, rng: np.random.Generator,
+                 fmt: str = "nhwc_bf16") -> Views:
+        n = len(sample_idx)
+        out = Views()
+        # consecutive views with the same geometry share a launch
+        i = 0
+        while i < len(self.transforms):
+            spec = self.transforms[i]
+            j = i
+            while j < len(self.transforms) and (self.transforms[j].img_size, self.transforms[j].out_size,
+                                                  self.transforms[j].normalize) == (spec.img_size, spec.out_size,
+                                                                                    spec.normalize):
+                j += 1
+            params = np.concatenate([
+                sample_view_params(self.transforms[v], sample_idx, store.heights_np, store.widths_np, rng,
+                                   out_slot_base=(v - i) * n) for v in range(i, j)])
+            batch = augment_views(store, params, img_size=spec.img_size, out_size=spec.out_size, fmt=fmt,
+                                  normalize=spec.normalize, mean=NORMALIZE_STATS["mean"][0],
+                                  std=NORMALIZE_STATS["std"][0], n_slots=(j - i) * n)
+            for v in range(j - i):
+                out.append(batch[v * n:(v + 1) * n])
+            if i == 0 and j == len(self.transforms):
+                out.stacked = batch
+            i = j
+        return out
+
+
+class BaseViewTransform(MultiViewTransform):
+    def __init__(self, img_size: List[int] = [224, 224], die_noise_prob: float = 0.03, crop: bool = False,
+                 denoise: bool = False, hf_prob: float = 0.5, vf_prob: float = 0.5, rr_prob: float = 0.5,
+                 normalize: bool = True, n_views: int = 2):
+        assert n_views > 0, "n_views must be greater than 0"
+        view = get_base_transforms(img_size=img_size, die_noise_prob=die_noise_prob, denoise=denoise, crop=crop,
+                                   hf_prob=hf_prob, vf_prob=vf_prob, rr_prob=rr_prob, to_tensor=True,
+                                   normalize=normalize)
+        super().__init__([view] * n_views)
+
+
+class MultiCropTransform(MultiViewTransform):
+    def __init__(self, img_size: List[int] = [224, 224], global_crop_size: int = 224,
+                 global_crop_scale: Tuple[float, float] = (0.6, 1.0), local_crop_size: int = 96,
+                 local_crop_scale: Tuple[float, float] = (0.1, 0.4), n_global_views: int = 2, n_local_views: int = 6,
+                 die_noise_prob: float = 0.03, denoise: bool = False, hf_prob: float = 0.5, vf_prob: float = 0.5,
+                 rr_prob: float = 0.5, normalize: bool = True):
+        assert n_global_views > 0, "n_global_views must be greater than 0"
+        assert n_local_views > 0, "n_local_views must be greater than 0"
+        kw = dict(img_size=img_size, die_noise_prob=die_noise_prob, denoise=denoise, hf_prob=hf_prob,
+                  vf_prob=vf_prob, rr_prob=rr_prob, normalize=normalize)
+        g = multicrop_view(crop_size=global_crop_size, crop_scale=global_crop_scale, **kw)
+        l = multicrop_view(crop_size=local_crop_size, crop_scale=local_crop_scale, **kw)
+        super().__init__([g] * n_global_views + [l] * n_local_views)
+
+
+class InferenceTransform(MultiViewTransform):
+    """get_inference_transforms as a one-view transform (the kNN bank / validation loaders)."""
+
+    def __init__(self, img_size: List[int] = [224, 224], normalize: bool = True):
+        super().__init__([get_inference_transforms(img_size, normalize)])

@@ -1,0 +1,101 @@
+"""GPU: the training loop pieces — fused SGD parity, loader determinism, a short SimCLR fit with
+kNN validation through the reference-shaped module API."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def test_fused_sgd_matches_torch_sgd():
+    from ssl_wafermap_amd import optim
+
+    torch.manual_seed(0)
+    shapes = [(64, 3, 7, 7), (64,), (128, 64, 3, 3), (5,), (512, 512)]
+    ref = [torch.nn.Parameter(torch.randn(s)) for s in shapes]
+    mine = [torch.nn.Parameter(p.detach().clone().to(DEV)) for p in ref]
+    o_ref = torch.optim.SGD(ref, lr=0.06, momentum=0.9, weight_decay=5e-4)
+    o_hip = optim.SGD(mine, lr=0.06, momentum=0.9, weight_decay=5e-4)
+    sched_ref = torch.optim.lr_scheduler.CosineAnnealingLR(o_ref, 10)
+    sched_hip = torch.optim.lr_scheduler.CosineAnnealingLR(o_hip, 10)
+    for it in range(4):
+        o_ref.zero_grad()
+        o_hip.zero_grad()
+        for p, q in zip(ref, mine):
+            g = torch.randn(p.shape, generator=torch.Generator().manual_seed(it * 10 + p.numel() % 7))
+            p.grad = g.clone()
+            q.grad.add_(g.to(DEV))  # accumulates into the arena view, as autograd does
+        o_ref.step()
+        o_hip.step()
+        sched_ref.step()
+        sched_hip.step()
+        for p, q in zip(ref, mine):
+            torch.testing.assert_close(q.detach().cpu(), p.detach(), atol=1e-6, rtol=1e-6)
+    assert all(q.grad.data_ptr() >= o_hip.grad_arenas[0].data_ptr() for q in mine)
+
+
+def test_loader_is_deterministic_and_rank_sliced():
+    from ssl_wafermap_amd.data import WaferLoader, WaferMapDataset
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.transforms import BaseViewTransform, InferenceTransform
+
+    wafers, labels = synthetic_wafers(40, seed=3)
+    ds = WaferMapDataset(wafers, labels, transform=BaseViewTransform(), device=DEV)
+    a = [(v.stacked.clone(), y.clone()) for v, y in WaferLoader(ds, 8, shuffle=True, drop_last=True, seed=5)]
+    b = [(v.stacked.clone(), y.clone()) for v, y in WaferLoader(ds, 8, shuffle=True, drop_last=True, seed=5)]
+    assert len(a) == 5 and all(torch.equal(x[0], z[0]) and torch.equal(x[1], z[1]) for x, z in zip(a, b))
+    assert a[0][0].shape == (16, 3, 224, 224) and a[0][0].dtype == torch.bfloat16
+    # two ranks of 4 see the two halves of the global batch of 8 (labels identify the samples)
+    r0 = [y for _, y in WaferLoader(ds, 4, shuffle=True, drop_last=True, seed=5, rank=0, world_size=2)]
+    r1 = [y for _, y in WaferLoader(ds, 4, shuffle=True, drop_last=True, seed=5, rank=1, world_size=2)]
+    for (_, y), y0, y1 in zip(a, r0, r1):
+        assert torch.equal(torch.cat([y0, y1]), y)
+    dv = WaferMapDataset(wafers, labels, transform=InferenceTransform(), device=DEV)
+    x, y = next(iter(WaferLoader(dv, 10)))
+    assert x.shape == (10, 3, 224, 224) and y.shape == (10,)
+
+
+def test_simclr_fit_with_knn_validation():
+    from ssl_wafermap_amd.data import WaferLoader, WaferMapDataset
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.models import SimCLR
+    from ssl_wafermap_amd.trainer import Trainer
+    from ssl_wafermap_amd.transforms import BaseViewTransform, InferenceTransform
+
+    wafers, labels = synthetic_wafers(96, seed=1)
+    ds_ssl = WaferMapDataset(wafers[:64], labels[:64], transform=BaseViewTransform(), device=DEV)
+    ds_knn = WaferMapDataset(wafers[:64], labels[:64], transform=InferenceTransform(), device=DEV)
+    ds_val = WaferMapDataset(wafers[64:], labels[64:], transform=InferenceTransform(), device=DEV)
+    torch.manual_seed(0)
+    model = SimCLR(WaferLoader(ds_knn, 16), 9, knn_k=5, knn_t=0.1, batch_size=16, max_epochs=3).to(DEV)
+    w0 = model.backbone.conv1.weight.detach().clone()
+    hist = Trainer(max_epochs=3, verbose=False).fit(model, WaferLoader(ds_ssl, 16, shuffle=True, drop_last=True, seed=0),
+                                                    WaferLoader(ds_val, 16))
+    assert len(hist) == 3
+    losses = [h["train_loss_ssl"] for h in hist]
+    assert all(np.isfinite(losses)) and losses[-1] < losses[0] + 0.2
+    assert 0.0 <= hist[-1]["knn_accuracy"] <= 1.0 and 0.0 <= hist[-1]["knn_f1"] <= 1.0
+    assert model.confusion_matrix[-1].shape == (9, 9)
+    assert not torch.equal(w0, model.backbone.conv1.weight.detach())
+    assert torch.isfinite(model.logged["rep_std"]).all()
+    # loss at init is near log(2B-1) for random embeddings (reference band: 3.73 at bs 64 ~ log 127 = 4.84 upper bound)
+    assert losses[0] < np.log(2 * 16 - 1) + 0.5
+
+
+def test_macro_metrics_match_sklearn():
+    from sklearn.metrics import confusion_matrix, f1_score, recall_score
+
+    from ssl_wafermap_amd.models import macro_metrics
+
+    rng = np.random.default_rng(0)
+    t = rng.integers(0, 7, 500)  # classes 7, 8 never occur
+    p = np.where(rng.random(500) < 0.6, t, rng.integers(0, 9, 500))
+    acc, f1, cm = macro_metrics(torch.tensor(p), torch.tensor(t), 9)
+    labs = sorted(set(t))
+    assert abs(acc - recall_score(t, p, labels=labs, average="macro")) < 1e-6
+    seen = sorted(set(t) | set(p))
+    assert abs(f1 - f1_score(t, p, labels=seen, average="macro")) < 1e-6
+    ref = confusion_matrix(t, p, labels=list(range(9))).astype(float)
+    ref = ref / np.maximum(ref.sum(1, keepdims=True), 1)
+    np.testing.assert_allclose(cm.numpy(), ref, atol=1e-6)
