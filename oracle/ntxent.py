@@ -17,13 +17,13 @@ def ntxent_lightly(out0, out1, temperature=0.5, out0_large=None, out1_large=None
     out1 = F.normalize(out1, dim=1)
     if out0_large is None:
         out0_large, out1_large = out0, out1
-        diag_mask = torch.eye(batch_size, dtype=torch.bool)
+        diag_mask = torch.eye(batch_size, dtype=torch.bool, device=out0.device)
     else:
         out0_large = F.normalize(out0_large, dim=1)
         out1_large = F.normalize(out1_large, dim=1)
         world = out0_large.shape[0] // batch_size
-        diag_mask = torch.zeros(batch_size, batch_size * world, dtype=torch.bool)
-        diag_mask[:, rank * batch_size : (rank + 1) * batch_size] = torch.eye(batch_size, dtype=torch.bool)
+        diag_mask = torch.zeros(batch_size, batch_size * world, dtype=torch.bool, device=out0.device)
+        diag_mask[:, rank * batch_size : (rank + 1) * batch_size] = torch.eye(batch_size, dtype=torch.bool, device=out0.device)
     logits_00 = torch.einsum("nc,mc->nm", out0, out0_large) / temperature
     logits_01 = torch.einsum("nc,mc->nm", out0, out1_large) / temperature
     logits_10 = torch.einsum("nc,mc->nm", out1, out0_large) / temperature
@@ -33,7 +33,7 @@ def ntxent_lightly(out0, out1, temperature=0.5, out0_large=None, out1_large=None
     logits_0100 = torch.cat([logits_01, logits_00], dim=1)
     logits_1011 = torch.cat([logits_10, logits_11], dim=1)
     logits = torch.cat([logits_0100, logits_1011], dim=0)
-    labels = torch.arange(batch_size, dtype=torch.long) + rank * batch_size
+    labels = torch.arange(batch_size, dtype=torch.long, device=out0.device) + rank * batch_size
     labels = labels.repeat(2)
     return F.cross_entropy(logits, labels, reduction="mean")
 

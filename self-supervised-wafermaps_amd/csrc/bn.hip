@@ -114,21 +114,50 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restri
   }
 }
 
-// Forward finalize: one block; thread c handles channel c (loop if C > blockDim).
-__global__ void bn_fwd_finalize(const float* __restrict__ part, int nblk, int G, int C,
-                                int rows_per_group, const float* __restrict__ gamma,
-                                const float* __restrict__ beta, float eps, float momentum,
-                                float* __restrict__ running_mean, float* __restrict__ running_var,
-                                float* __restrict__ mean, float* __restrict__ invstd,
-                                float* __restrict__ scale, float* __restrict__ shift) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    float rm = running_mean ? running_mean[c] : 0.f, rv = running_var ? running_var[c] : 0.f;
-    for (int g = 0; g < G; ++g) {
-      double s = 0.0, ss = 0.0;
-      for (int b = 0; b < nblk; ++b) {
-        s += (double)part[((size_t)(g * nblk + b) * 2 + 0) * C + c];
-        ss += (double)part[((size_t)(g * nblk + b) * 2 + 1) * C + c];
-      }
+// Reduce the [nblk] partial sums of one (group, channel) pair: 32 lanes of a 1024-thread block
+// stride over the partials of 32 adjacent channels (128-byte coalesced rows), then combine in LDS.
+__device__ __forceinline__ void finalize_sums(const float* __restrict__ part, int nblk, int g, int C, int c,
+                                              int bl, int cl, double (*red)[32][33], double& s, double& ss) {
+  double a = 0.0, b = 0.0;
+  if (c < C) {
+    for (int k = bl; k < nblk; k += 32) {
+      a += (double)part[((size_t)(g * nblk + k) * 2 + 0) * C + c];
+      b += (double)part[((size_t)(g * nblk + k) * 2 + 1) * C + c];
+    }
+  }
+  __syncthreads();  // previous group's readers are done with `red`
+  red[0][bl][cl] = a;
+  red[1][bl][cl] = b;
+  __syncthreads();
+  s = 0.0;
+  ss = 0.0;
+  if (bl == 0) {
+    for (int k = 0; k < 32; ++k) {
+      s += red[0][k][cl];
+      ss += red[1][k][cl];
+    }
+  }
+}
+
+// Forward finalize: grid = ceil(C/32) blocks of 1024 threads.
+__global__ __launch_bounds__(1024) void bn_fwd_finalize(
+    const float* __restrict__ part, int nblk, int G, int C, int rows_per_group,
+    const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
+    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean,
+    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+  __shared__ double red[2][32][33];
+  const int bl = threadIdx.x >> 5, cl = threadIdx.x & 31;
+  const int c = blockIdx.x * 32 + cl;
+  const bool owner = bl == 0 && c < C;
+  float rm = 0.f, rv = 0.f;
+  if (owner) {
+    rm = running_mean ? running_mean[c] : 0.f;
+    rv = running_var ? running_var[c] : 0.f;
+  }
+  for (int g = 0; g < G; ++g) {
+    double s, ss;
+    finalize_sums(part, nblk, g, C, c, bl, cl, red, s, ss);
+    if (owner) {
       const double m = s / rows_per_group;
       double var = ss / rows_per_group - m * m;
       if (var < 0.0) var = 0.0;
@@ -144,6 +173,8 @@ __global__ void bn_fwd_finalize(const float* __restrict__ part, int nblk, int G,
       rm = (1.f - momentum) * rm + momentum * fm;
       rv = (1.f - momentum) * rv + momentum * (float)unb;
     }
+  }
+  if (owner) {
     if (running_mean) running_mean[c] = rm;
     if (running_var) running_var[c] = rv;
   }
@@ -201,19 +232,19 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply(const uint16_t* __restric
 
 // Backward finalize: dgamma/dbeta and the per-(group, channel) coefficients of the apply pass.
 // coef[(g*5 + t)*C + c]: t = 0 mean, 1 invstd, 2 gamma*invstd, 3 s1/M, 4 s2/M.
-__global__ void bn_bwd_finalize(const float* __restrict__ part, int nblk, int G, int C,
-                                int rows_per_group, const float* __restrict__ gamma,
-                                const float* __restrict__ mean, const float* __restrict__ invstd,
-                                float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                int accumulate, float* __restrict__ coef) {
-  for (int c = threadIdx.x; c < C; c += blockDim.x) {
-    double tg = 0.0, tb = 0.0;
-    for (int g = 0; g < G; ++g) {
-      double s1 = 0.0, s2 = 0.0;
-      for (int b = 0; b < nblk; ++b) {
-        s1 += (double)part[((size_t)(g * nblk + b) * 2 + 0) * C + c];
-        s2 += (double)part[((size_t)(g * nblk + b) * 2 + 1) * C + c];
-      }
+__global__ __launch_bounds__(1024) void bn_bwd_finalize(
+    const float* __restrict__ part, int nblk, int G, int C, int rows_per_group,
+    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
+    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+  __shared__ double red[2][32][33];
+  const int bl = threadIdx.x >> 5, cl = threadIdx.x & 31;
+  const int c = blockIdx.x * 32 + cl;
+  const bool owner = bl == 0 && c < C;
+  double tg = 0.0, tb = 0.0;
+  for (int g = 0; g < G; ++g) {
+    double s1, s2;
+    finalize_sums(part, nblk, g, C, c, bl, cl, red, s1, s2);
+    if (owner) {
       tb += s1;
       tg += s2;
       const float is = invstd[(size_t)g * C + c];
@@ -223,6 +254,8 @@ __global__ void bn_bwd_finalize(const float* __restrict__ part, int nblk, int G,
       coef[((size_t)g * 5 + 3) * C + c] = (float)(s1 / rows_per_group);
       coef[((size_t)g * 5 + 4) * C + c] = (float)(s2 / rows_per_group);
     }
+  }
+  if (owner) {
     if (dgamma) dgamma[c] = (accumulate ? dgamma[c] : 0.f) + (float)tg;
     if (dbeta) dbeta[c] = (accumulate ? dbeta[c] : 0.f) + (float)tb;
   }
@@ -282,7 +315,7 @@ inline int reduce_blocks(int rows_per_group, int C) {
   const int tpr = C >> 3;
   const int rpp = BN_THREADS / tpr > 0 ? BN_THREADS / tpr : 1;
   int nblk = wm_cdiv(rows_per_group, rpp * 16);
-  if (nblk > 512) nblk = 512;
+  if (nblk > 256) nblk = 256;
   if (nblk < 1) nblk = 1;
   return nblk;
 }
@@ -330,9 +363,8 @@ extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float*
   bn_reduce<0><<<dim3(nblk, G), BN_THREADS, lds, st>>>(static_cast<const uint16_t*>(y), nullptr, nullptr,
                                                        nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk), part);
   WM_LAUNCH_CHECK();
-  bn_fwd_finalize<<<1, C < 1024 ? ((C + 63) / 64) * 64 : 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, beta, eps,
-                                                                      momentum, running_mean, running_var,
-                                                                      save_mean, save_invstd, scale, shift);
+  bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, beta, eps, momentum, running_mean,
+                                                   running_var, save_mean, save_invstd, scale, shift);
   WM_LAUNCH_CHECK();
   bn_apply<<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(static_cast<const uint16_t*>(y),
                                                            static_cast<const uint16_t*>(residual), scale, shift,
@@ -381,8 +413,8 @@ extern "C" int wm_bn_train_bwd(const void* y, const void* dout, const void* out_
       static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
       save_mean, save_invstd, rpg, C, wm_cdiv(rpg, nblk), part);
   WM_LAUNCH_CHECK();
-  bn_bwd_finalize<<<1, C < 1024 ? ((C + 63) / 64) * 64 : 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, save_mean,
-                                                                      save_invstd, dgamma, dbeta, accumulate, coef);
+  bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, save_mean, save_invstd, dgamma, dbeta,
+                                                   accumulate, coef);
   WM_LAUNCH_CHECK();
   bn_bwd_apply<<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
       static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
