@@ -28,6 +28,9 @@ PARAM_DTYPE = np.dtype(
 assert PARAM_DTYPE.itemsize == 64
 
 
+_POWER_LAW_TABLES = {}
+
+
 # ---- the reference's stage-1 transform names, as parameter holders -------------------------------
 @dataclass(frozen=True)
 class DieNoise:
@@ -59,12 +62,25 @@ class DPWTransform:
     beta: float = 1.5
     p: float = 5.0
 
+    def _power_law_one(self, x: int) -> float:
+        # plain Python float arithmetic, operation for operation as the reference does it
+        # (augmentations.py:152-174): numpy's vectorised pow differs in the last bit for some x
+        if x <= self.domain_lower:
+            return self.out_upper
+        if x >= self.domain_upper:
+            return self.out_lower
+        domain_range = self.domain_upper - self.domain_lower
+        normalized_x = abs(x - self.domain_lower) / domain_range
+        y = (1 - normalized_x) ** self.p
+        return self.out_lower + y * (self.out_upper - self.out_lower)
+
     def power_law(self, x: np.ndarray) -> np.ndarray:
-        x = np.asarray(x, dtype=np.float64)
-        norm = np.abs(x - self.domain_lower) / (self.domain_upper - self.domain_lower)
-        y = self.out_lower + (1 - norm) ** self.p * (self.out_upper - self.out_lower)
-        y = np.where(x <= self.domain_lower, self.out_upper, y)
-        return np.where(x >= self.domain_upper, self.out_lower, y)
+        x = np.asarray(x, dtype=np.int64)
+        table = _POWER_LAW_TABLES.get(self)
+        if table is None:
+            table = np.array([self._power_law_one(int(v)) for v in range(0, 513)], dtype=np.float64)
+            _POWER_LAW_TABLES[self] = table
+        return table[np.clip(x, 0, 512)]
 
     def scales(self, heights, widths, beta_draws) -> np.ndarray:
         lower = self.power_law(np.maximum(heights, widths))

@@ -1,0 +1,165 @@
+"""World-size-2 gloo tests (CPU) of the data-parallel host logic: gradient bucketing, the
+gather_distributed plumbing of NTXentLoss (kernels replaced by a torch stand-in that implements
+the SAME contract as wm_ntxent_fwd/bwd), and rank slicing of the loader."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import ntxent as on
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _spawn(fn, world, *args):
+    port = _free_port()
+    mp.spawn(_entry, args=(world, port, fn, args), nprocs=world, join=True)
+
+
+def _entry(rank, world, port, fn, args):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        fn(rank, world, *args)
+    finally:
+        dist.destroy_process_group()
+
+
+# ---- torch stand-ins with the kernels' contract (include/wafer_hip.h: wm_ntxent_fwd / wm_ntxent_bwd)
+def _ids(b_local, b_global, off):
+    v = torch.arange(2).repeat_interleave(b_local)
+    i = torch.arange(b_local).repeat(2)
+    return v * b_global + off + i, (1 - v) * b_global + off + i
+
+
+def ref_ntxent_forward(zn, zall, b_local, b_global, off, t):
+    self_g, pos_g = _ids(b_local, b_global, off)
+    s = zn @ zall.t() / t
+    pos = s[torch.arange(2 * b_local), pos_g]
+    s = s.clone()
+    s[torch.arange(2 * b_local), self_g] = float("-inf")
+    lse = torch.logsumexp(s, dim=1)
+    return lse, lse - pos
+
+
+def ref_ntxent_backward(zn, zall, lse_all, b_local, b_global, off, t, grad_scale):
+    self_g, pos_g = _ids(b_local, b_global, off)
+    s = zn @ zall.t() / t
+    m = torch.exp(s - lse_all[self_g][:, None]) + torch.exp(s - lse_all[None, :])
+    m[torch.arange(2 * b_local), pos_g] -= 2.0
+    m[torch.arange(2 * b_local), self_g] = 0.0
+    return grad_scale / t * (m @ zall)
+
+
+def _grad_sync(rank, world):
+    from ssl_wafermap_amd import distributed as wdist
+
+    class FakeOpt:
+        grad_scale = 1.0
+
+        def __init__(self):
+            g = torch.Generator().manual_seed(rank)
+            self.grad_arenas = [torch.randn(1000, generator=g), torch.randn(37, generator=g)]
+
+    opt = FakeOpt()
+    mine = [a.clone() for a in opt.grad_arenas]
+    sync = wdist.GradSync(opt, bucket_bytes=256 * 4)  # several buckets + a ragged tail
+    assert opt.grad_scale == 1.0 / world
+    sync.start()
+    sync.wait()
+    other = [torch.randn(1000, generator=torch.Generator().manual_seed(1 - rank)), None]
+    g = torch.Generator().manual_seed(1 - rank)
+    other = [torch.randn(1000, generator=g), torch.randn(37, generator=g)]
+    for a, m, o in zip(opt.grad_arenas, mine, other):
+        torch.testing.assert_close(a, m + o)
+    assert wdist.world_size() == world and wdist.rank() == rank
+
+
+def test_grad_sync_buckets_world2():
+    _spawn(_grad_sync, 2)
+
+
+def _ntxent_gathered(rank, world):
+    import ssl_wafermap_amd.functional as F_hip
+    from ssl_wafermap_amd.loss import NTXentLoss
+
+    # replace the three kernel entry points by contract-equivalent torch code (no GPU here)
+    F_hip.ntxent_forward = ref_ntxent_forward
+    F_hip.ntxent_backward = ref_ntxent_backward
+    F_hip.l2_normalize = lambda x, eps=1e-12, out_dtype=None: torch.nn.functional.normalize(x, dim=1, eps=eps)
+    b, d, t = 6, 32, 0.5
+    g = torch.Generator().manual_seed(0)
+    z0_all, z1_all = torch.randn(world * b, d, generator=g), torch.randn(world * b, d, generator=g)
+    z0 = z0_all[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+    z1 = z1_all[rank * b:(rank + 1) * b].clone().requires_grad_(True)
+    loss = NTXentLoss(temperature=t, gather_distributed=True)(z0, z1)
+    loss.backward()
+    # reference: lightly's gathered branch; gradients summed over ranks (GatherLayer.backward)
+    r0, r1 = z0_all.clone().requires_grad_(True), z1_all.clone().requires_grad_(True)
+    losses = [on.ntxent_lightly(r0[k * b:(k + 1) * b], r1[k * b:(k + 1) * b], t, r0, r1, rank=k) for k in range(world)]
+    torch.stack(losses).sum().backward()
+    assert abs(loss.item() - losses[rank].item()) < 1e-5
+    torch.testing.assert_close(z0.grad, r0.grad[rank * b:(rank + 1) * b], atol=1e-6, rtol=1e-4)
+    torch.testing.assert_close(z1.grad, r1.grad[rank * b:(rank + 1) * b], atol=1e-6, rtol=1e-4)
+    # and the mean over ranks of the gathered losses is the single-process loss on the global batch
+    full = on.ntxent_lightly(z0_all, z1_all, t)
+    tot = loss.detach().clone()
+    dist.all_reduce(tot)
+    assert abs(tot.item() / world - full.item()) < 1e-5
+
+
+def test_ntxent_gather_distributed_world2():
+    _spawn(_ntxent_gathered, 2)
+
+
+def test_contract_stand_in_matches_autograd_single_process():
+    """The torch stand-in used above obeys the documented kernel contract (and so do the kernels:
+    tests/test_gpu_embed.py checks them against the same oracle on the GPU)."""
+    g = torch.Generator().manual_seed(3)
+    b, d, t = 10, 16, 0.5
+    z0, z1 = torch.randn(b, d, generator=g), torch.randn(b, d, generator=g)
+    zn = torch.nn.functional.normalize(torch.cat([z0, z1]), dim=1)
+    lse, rows = ref_ntxent_forward(zn, zn, b, b, 0, t)
+    ref = on.ntxent_lightly(z0, z1, t)
+    assert abs(rows.mean() - ref) < 1e-6
+    znr = zn.clone().requires_grad_(True)
+    on.ntxent_lightly(znr[:b], znr[b:], t).backward()
+    dzn = ref_ntxent_backward(zn, zn, lse, b, b, 0, t, 1.0 / (2 * b))
+    proj = dzn - zn * (dzn * zn).sum(1, keepdim=True)
+    torch.testing.assert_close(proj, znr.grad, atol=1e-6, rtol=1e-4)
+
+
+def test_loader_rank_slices_partition_the_global_batch():
+    from ssl_wafermap_amd.data.dataset import WaferLoader
+
+    class FakeDataset:
+        def __len__(self):
+            return 50
+
+        def get_batch(self, indices, rng, fmt="nhwc_bf16"):
+            return [torch.as_tensor(indices)], torch.as_tensor(indices)
+
+    ds = FakeDataset()
+    full = [y for _, y in WaferLoader(ds, 8, shuffle=True, drop_last=True, seed=3)]
+    parts = [[y for _, y in WaferLoader(ds, 4, shuffle=True, drop_last=True, seed=3, rank=r, world_size=2)] for r in range(2)]
+    assert len(full) == 6 == len(parts[0]) == len(parts[1])
+    for f, a, b in zip(full, parts[0], parts[1]):
+        assert torch.equal(torch.cat([a, b]), f)
+    seen = torch.cat(full)
+    assert len(set(seen.tolist())) == 48  # a permutation without repeats
+    again = [y for _, y in WaferLoader(ds, 8, shuffle=True, drop_last=True, seed=3)]
+    assert all(torch.equal(a, b) for a, b in zip(full, again))
+    nxt = WaferLoader(ds, 8, shuffle=True, drop_last=True, seed=3)
+    nxt.set_epoch(1)
+    assert not torch.equal(torch.cat([y for _, y in nxt]), seen)
