@@ -15,6 +15,14 @@
 // the top-k list of a query is lane-local and needs no cross-lane traffic in the hot loop.
 //   bf16: v_mfma_f32_32x32x16_bf16, one 16-byte fragment = one MFMA (k = 8h+j)
 //   f32 : v_mfma_f32_32x32x2_f32 (exact f32 fmaf chain), one 16-byte fragment = 4 MFMAs
+//
+// Selection is two-stage so that the streaming loop is branch-free: a lane folds the 16 values an
+// accumulator tile gives it into a running MAXIMUM over a fixed group of 64 bank rows (4 chunks x 16
+// rows) and offers that one (max, group id) pair to its sorted list once per group.  The k best
+// elements always lie inside the k groups with the largest maxima (each group whose max reaches
+// the k-th best value holds at least one of the k best), so after the cross-block merge a small
+// rescoring kernel recomputes the <= K*64 candidate rows of every query exactly and orders them
+// (value descending, bank index ascending).
 #include "common.h"
 #include <limits.h>
 
@@ -55,7 +63,7 @@ __device__ __forceinline__ int acc_row(int reg, int half) {
 template <int DT, int QT, int K>
 __global__ __launch_bounds__(KNN_THREADS) void knn_block_topk(
     const uint8_t* __restrict__ query, const uint8_t* __restrict__ bank, int nq, int n,
-    int rowbytes, int chunks_per_slice, int nslices, int index_base, float* __restrict__ part_sim,
+    int rowbytes, int chunks_per_slice, int nslices, float* __restrict__ part_sim,
     int* __restrict__ part_idx) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int QB = QT * 32;
@@ -126,6 +134,9 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_block_topk(
   };
 
   f32x16_t acc[QT];
+  float gmax[QT];
+#pragma unroll
+  for (int t = 0; t < QT; ++t) gmax[t] = -INFINITY;
 
   if (iters > 0) {
     load_iter(0);
@@ -166,14 +177,21 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_block_topk(
       }
     }
     if (slab == nslab - 1) {
-      const int nb = (chunk_begin + it / nslab) * KNN_ROWS + wave * 32;
+      const int crel = it / nslab;  // chunk index inside this slice
+      const int nb = (chunk_begin + crel) * KNN_ROWS + wave * 32;
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
+        float m = gmax[t];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const int brow = nb + acc_row(e, h);
-          const float v = acc[t][e];
-          if (brow < n && v > lv[t][K - 1]) topk_insert<K>(lv[t], li[t], v, brow + index_base);
+        for (int e = 0; e < 16; ++e) m = fmaxf(m, (nb + acc_row(e, h) < n) ? acc[t][e] : -INFINITY);
+        gmax[t] = m;
+      }
+      if ((crel & 3) == 3 || it == iters - 1) {  // group of 4 chunks complete (or slice ends)
+        const int gid = ((chunk_begin + (crel & ~3)) << 3) | (wave << 1) | h;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          if (gmax[t] > lv[t][K - 1]) topk_insert<K>(lv[t], li[t], gmax[t], gid);
+          gmax[t] = -INFINITY;
         }
       }
     }
@@ -291,6 +309,102 @@ __global__ __launch_bounds__(64) void knn_merge_lists(const float* __restrict__ 
   }
 }
 
+// Exact scores of the candidate rows of one query: kg groups x 64 rows (group id -> rows as the
+// streaming kernel enumerates them), then the best `kout` by (value desc, index asc).
+template <int DT>
+__global__ __launch_bounds__(256) void knn_rescore(const uint8_t* __restrict__ query,
+                                                   const uint8_t* __restrict__ bank, int n, int d,
+                                                   int rowbytes, const int* __restrict__ gids, int kg,
+                                                   int chunks_per_slice, int total_chunks, int index_base,
+                                                   int kout, float* __restrict__ out_sim,
+                                                   int* __restrict__ out_idx) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t rs_smem[];
+  float* qf = reinterpret_cast<float*>(rs_smem);            // [d]
+  float* cv = qf + d;                                        // [kg*64]
+  int* ci = reinterpret_cast<int*>(cv + kg * 64);            // [kg*64]
+  const int q = blockIdx.x, tid = threadIdx.x;
+  for (int c = tid; c < d; c += 256) {
+    if constexpr (DT == WM_BF16) qf[c] = bf2f(reinterpret_cast<const uint16_t*>(query + (size_t)q * rowbytes)[c]);
+    else qf[c] = reinterpret_cast<const float*>(query + (size_t)q * rowbytes)[c];
+  }
+  __syncthreads();
+  const int ncand = kg * 64;
+  for (int c = tid; c < ncand; c += 256) {
+    const int gid = gids[(size_t)q * kg + (c >> 6)];
+    const int j = c & 63, cc = j >> 4, e = j & 15;
+    float v = -INFINITY;
+    int row = INT_MAX;
+    if (gid != INT_MAX) {
+      const int c0 = gid >> 3, w = (gid >> 1) & 3, hh = gid & 1;
+      const int slice = c0 / chunks_per_slice;
+      int cend = (slice + 1) * chunks_per_slice;
+      if (cend > total_chunks) cend = total_chunks;
+      const int chunk = c0 + cc;
+      const int r = chunk * KNN_ROWS + w * 32 + acc_row(e, hh);
+      if (chunk < cend && r < n) {
+        row = r;
+        float acc = 0.f;
+        const uint8_t* br = bank + (size_t)r * rowbytes;
+        for (int k = 0; k < d; k += 8) {
+          if constexpr (DT == WM_BF16) {
+            const uint4 u = *reinterpret_cast<const uint4*>(br + k * 2);
+            const uint32_t ws[4] = {u.x, u.y, u.z, u.w};
+#pragma unroll
+            for (int x = 0; x < 4; ++x) {
+              acc = fmaf(bf2f((uint16_t)(ws[x] & 0xffff)), qf[k + 2 * x], acc);
+              acc = fmaf(bf2f((uint16_t)(ws[x] >> 16)), qf[k + 2 * x + 1], acc);
+            }
+          } else {
+            const float4 a = *reinterpret_cast<const float4*>(br + k * 4);
+            const float4 b = *reinterpret_cast<const float4*>(br + k * 4 + 16);
+            acc = fmaf(a.x, qf[k], acc); acc = fmaf(a.y, qf[k + 1], acc);
+            acc = fmaf(a.z, qf[k + 2], acc); acc = fmaf(a.w, qf[k + 3], acc);
+            acc = fmaf(b.x, qf[k + 4], acc); acc = fmaf(b.y, qf[k + 5], acc);
+            acc = fmaf(b.z, qf[k + 6], acc); acc = fmaf(b.w, qf[k + 7], acc);
+          }
+        }
+        v = acc;
+      }
+    }
+    cv[c] = v;
+    ci[c] = row;
+  }
+  __syncthreads();
+  if (tid < 64) {  // one wave: kout rounds of arg-best over the candidates
+    for (int t = 0; t < kout; ++t) {
+      float bv = -INFINITY;
+      int bi = INT_MAX, bp = -1;
+      for (int c = tid; c < ncand; c += 64) {
+        const float v = cv[c];
+        const int i = ci[c];
+        if (i != INT_MAX && (bp < 0 || better(v, i, bv, bi))) {
+          bv = v;
+          bi = i;
+          bp = c;
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        const int op = __shfl_xor(bp, o, 64);
+        if (op >= 0 && (bp < 0 || better(ov, oi, bv, bi))) {
+          bv = ov;
+          bi = oi;
+          bp = op;
+        }
+      }
+      if (tid == 0) {
+        out_sim[(size_t)q * kout + t] = bv;
+        out_idx[(size_t)q * kout + t] = bp >= 0 ? bi + index_base : -1;
+        if (bp >= 0) ci[bp] = INT_MAX;  // consumed
+      }
+      __builtin_amdgcn_s_waitcnt(0);  // tid 0's LDS write lands before the next round's reads
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
 constexpr int VOTE_MAX_CLASSES = 64;
 
 __global__ void knn_vote_kernel(const float* __restrict__ sim, const int* __restrict__ idx,
@@ -339,7 +453,7 @@ inline KnnPlan make_plan(int nq, int n, int rowbytes, int k) {
   p.qt = pick_qt(rowbytes, nq, p.kt);
   p.qtiles = wm_cdiv(nq, p.qt * 32);
   const int total_chunks = wm_cdiv(n, KNN_ROWS);
-  int want = 1024 / p.qtiles;
+  int want = 512 / p.qtiles;
   if (want < 1) want = 1;
   p.nslices = total_chunks < want ? total_chunks : want;
   p.chunks_per_slice = wm_cdiv(total_chunks, p.nslices);
@@ -349,7 +463,7 @@ inline KnnPlan make_plan(int nq, int n, int rowbytes, int k) {
 
 template <int DT, int QT, int K>
 int launch_block(const KnnPlan& p, const void* query, const void* bank, int nq, int n,
-                 int rowbytes, int index_base, float* ps, int* pi, hipStream_t st) {
+                 int rowbytes, float* ps, int* pi, hipStream_t st) {
   const size_t lds = 2 * (size_t)KNN_BUF + (size_t)QT * 32 * rowbytes;
   static bool attr_set = false;  // idempotent; a race only repeats the call
   if (!attr_set) {
@@ -361,20 +475,20 @@ int launch_block(const KnnPlan& p, const void* query, const void* bank, int nq, 
   dim3 grid(p.nslices, p.qtiles);
   knn_block_topk<DT, QT, K><<<grid, KNN_THREADS, lds, st>>>(
       static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), nq, n, rowbytes,
-      p.chunks_per_slice, p.nslices, index_base, ps, pi);
+      p.chunks_per_slice, p.nslices, ps, pi);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
 
 template <int DT, int K>
 int dispatch_qt(const KnnPlan& p, const void* query, const void* bank, int nq, int n, int rowbytes,
-                int index_base, float* ps, int* pi, hipStream_t st) {
+                float* ps, int* pi, hipStream_t st) {
   if constexpr (K <= 8) {
-    if (p.qt == 4) return launch_block<DT, 4, K>(p, query, bank, nq, n, rowbytes, index_base, ps, pi, st);
+    if (p.qt == 4) return launch_block<DT, 4, K>(p, query, bank, nq, n, rowbytes, ps, pi, st);
   }
   switch (p.qt) {
-    case 2: return launch_block<DT, 2, K>(p, query, bank, nq, n, rowbytes, index_base, ps, pi, st);
-    default: return launch_block<DT, 1, K>(p, query, bank, nq, n, rowbytes, index_base, ps, pi, st);
+    case 2: return launch_block<DT, 2, K>(p, query, bank, nq, n, rowbytes, ps, pi, st);
+    default: return launch_block<DT, 1, K>(p, query, bank, nq, n, rowbytes, ps, pi, st);
   }
 }
 
@@ -387,7 +501,7 @@ extern "C" size_t wm_knn_topk_workspace_bytes(int nq, int n, int d, int k) {
   const KnnPlan pf = make_plan(nq, n, d * 4, k);
   const size_t a = (size_t)pb.qtiles * pb.qt * 32 * pb.nslices * pb.kt * 8;
   const size_t b = (size_t)pf.qtiles * pf.qt * 32 * pf.nslices * pf.kt * 8;
-  return (a > b ? a : b) + 256;
+  return (a > b ? a : b) + (size_t)nq * pb.kt * 8 + 256;
 }
 
 extern "C" int wm_knn_topk(const void* query, const void* bank, int nq, int n, int d, int dtype,
@@ -405,24 +519,38 @@ extern "C" int wm_knn_topk(const void* query, const void* bank, int nq, int n, i
              WM_EALIGN);
   const KnnPlan p = make_plan(nq, n, rowbytes, k);
   const size_t cand = (size_t)p.qtiles * p.qt * 32 * p.nslices * p.kt;
-  WM_REQUIRE(workspace_bytes >= cand * 8, WM_EWORKSPACE);
+  WM_REQUIRE(workspace_bytes >= cand * 8 + (size_t)nq * p.kt * 8, WM_EWORKSPACE);
   float* ps = static_cast<float*>(workspace);
   int* pi = reinterpret_cast<int*>(ps + cand);
   hipStream_t st = static_cast<hipStream_t>(stream);
   int rc;
   if (dtype == WM_BF16) {
-    rc = p.kt == 8 ? dispatch_qt<WM_BF16, 8>(p, query, bank, nq, n, rowbytes, bank_index_base, ps, pi, st)
-                   : dispatch_qt<WM_BF16, 16>(p, query, bank, nq, n, rowbytes, bank_index_base, ps, pi, st);
+    rc = p.kt == 8 ? dispatch_qt<WM_BF16, 8>(p, query, bank, nq, n, rowbytes, ps, pi, st)
+                   : dispatch_qt<WM_BF16, 16>(p, query, bank, nq, n, rowbytes, ps, pi, st);
   } else {
-    rc = p.kt == 8 ? dispatch_qt<WM_F32, 8>(p, query, bank, nq, n, rowbytes, bank_index_base, ps, pi, st)
-                   : dispatch_qt<WM_F32, 16>(p, query, bank, nq, n, rowbytes, bank_index_base, ps, pi, st);
+    rc = p.kt == 8 ? dispatch_qt<WM_F32, 8>(p, query, bank, nq, n, rowbytes, ps, pi, st)
+                   : dispatch_qt<WM_F32, 16>(p, query, bank, nq, n, rowbytes, ps, pi, st);
   }
   if (rc != WM_OK) return rc;
+  // candidate groups of every query: [nq][kt] (value, group id), best first
+  float* gsim = ps + 2 * cand;
+  int* gidx = reinterpret_cast<int*>(gsim + (size_t)nq * p.kt);
   const long long sq = (long long)p.nslices * p.kt, sp = p.kt;
   if (p.kt == 8)
-    knn_merge_lists<8><<<nq, 64, 0, st>>>(ps, pi, p.nslices, p.kt, sq, sp, k, out_sim, out_idx);
+    knn_merge_lists<8><<<nq, 64, 0, st>>>(ps, pi, p.nslices, p.kt, sq, sp, p.kt, gsim, gidx);
   else
-    knn_merge_lists<16><<<nq, 64, 0, st>>>(ps, pi, p.nslices, p.kt, sq, sp, k, out_sim, out_idx);
+    knn_merge_lists<16><<<nq, 64, 0, st>>>(ps, pi, p.nslices, p.kt, sq, sp, p.kt, gsim, gidx);
+  WM_LAUNCH_CHECK();
+  const size_t lds = (size_t)d * 4 + (size_t)p.kt * 64 * 8;
+  const int total_chunks = wm_cdiv(n, KNN_ROWS);
+  if (dtype == WM_BF16)
+    knn_rescore<WM_BF16><<<nq, 256, lds, st>>>(static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), n,
+                                               d, rowbytes, gidx, p.kt, p.chunks_per_slice, total_chunks,
+                                               bank_index_base, k, out_sim, out_idx);
+  else
+    knn_rescore<WM_F32><<<nq, 256, lds, st>>>(static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), n,
+                                              d, rowbytes, gidx, p.kt, p.chunks_per_slice, total_chunks,
+                                              bank_index_base, k, out_sim, out_idx);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
