@@ -102,7 +102,7 @@ int wm_augment_views(const uint8_t* wafers, const int64_t* offsets, const int32_
  * never written to HBM.
  * ------------------------------------------------------------------------------------------- */
 
-/* query [nq][d], bank [n][d] row-major, both `dtype` (WM_F32 or WM_BF16); row bytes % 256 == 0.
+/* query [nq][d], bank [n][d] row-major, both `dtype` (WM_F32 or WM_BF16); row bytes % 256 == 0; d <= 512 (k <= 8 when a row exceeds 1 KB).
  * out_sim [nq][k] float32 descending, out_idx [nq][k] int32 (ties: lower bank index first).
  * 1 <= k <= 16, k <= n.  bank_index_base is added to every emitted index (sharded banks). */
 size_t wm_knn_topk_workspace_bytes(int nq, int n, int d, int k);

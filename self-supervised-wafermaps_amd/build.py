@@ -67,7 +67,10 @@ def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> Path:
     def compile_one(item):
         s, obj = item
         cmd = [hipcc, *FLAGS, "-c", str(s), "-o", str(obj)]
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
+        except subprocess.TimeoutExpired as e:  # a pathological instantiation must fail loudly, not hang
+            raise RuntimeError(f"hipcc timed out after 1200 s on {s.name}") from e
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {s.name}:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():

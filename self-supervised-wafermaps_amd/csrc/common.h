@@ -48,4 +48,24 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// LDS byte address of a __shared__ pointer (what M0 / ds instructions take).
+__device__ __forceinline__ uint32_t lds_addr(const void* p) {
+  return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)p;
+}
+
+// One global_load_lds_dwordx4: every lane fetches 16 bytes from its own `gsrc`; the wave's 1 KiB
+// lands at LDS byte address `lds_base` (wave-uniform) + 16 * lane.  Issued from inline asm so that
+// hipcc neither counts it nor drains it with an s_waitcnt vmcnt(0) before the next ds_read: the
+// caller orders it with its own counted `s_waitcnt vmcnt(N)` followed by a barrier
+// (cdna_hip_programming.md §5.7: M0 is written and restored inside the same statement).
+__device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_base) {
+  uint32_t keep;
+  const uint32_t base = __builtin_amdgcn_readfirstlane(lds_base);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(base)
+      : "memory");
+}
+
 static inline int wm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -60,13 +60,22 @@ __device__ __forceinline__ int acc_row(int reg, int half) {
   return (reg & 3) + 8 * (reg >> 2) + 4 * half;
 }
 
-template <int DT, int QT, int K>
-__global__ __launch_bounds__(KNN_THREADS) void knn_block_topk(
+// 256 zero bytes: the global_load_lds source of bank rows past the end
+__device__ __attribute__((aligned(256))) uint8_t knn_zero_page[256];
+
+// Streaming kernel.  The bank slice flows HBM -> LDS by global_load_lds (16 B per lane, 1 KiB per
+// wave instruction, no VGPR staging) into a ring of S 32-KB stages; S-1 chunks stay in flight
+// behind a counted s_waitcnt vmcnt and a raw s_barrier (cdna_hip_programming.md "Pipelining across
+// barriers").  LDS rows are 256 B; the DMA destination is lane-linear, so the XOR swizzle is
+// applied to the per-lane SOURCE chunk and again on the fragment reads.
+template <int DT, int QT, int K, int S, bool QREG>
+__global__ __launch_bounds__(KNN_THREADS) void knn_stream(
     const uint8_t* __restrict__ query, const uint8_t* __restrict__ bank, int nq, int n,
     int rowbytes, int chunks_per_slice, int nslices, float* __restrict__ part_sim,
     int* __restrict__ part_idx) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   constexpr int QB = QT * 32;
+  constexpr int PER_STAGE = 8;  // global_load_lds instructions per thread per stage
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,12 +84,58 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_block_topk(
   const int q0 = blockIdx.y * QB;
   const int slice = blockIdx.x;
 
-  uint8_t* bankbuf = smem;                // 2 x KNN_BUF
-  uint8_t* qbuf = smem + 2 * KNN_BUF;     // QB x rowbytes
+  uint8_t* ring = smem;                  // S x KNN_BUF
+  uint8_t* qbuf = smem + S * KNN_BUF;    // QB x rowbytes
 
-  // ---- stage the query tile (swizzled), zero rows past nq
+  // Block b owns chunks b, b + nslices, b + 2*nslices, ...: at any instant the resident blocks read
+  // a contiguous window of the bank, which spreads over all HBM channels (contiguous per-block
+  // slices would start every block on the same channel).
+  const int total_chunks = (n + KNN_ROWS - 1) / KNN_ROWS;
+  const int my_chunks = slice < total_chunks ? (total_chunks - slice + nslices - 1) / nslices : 0;
+  const int iters = my_chunks * nslab;
+  (void)chunks_per_slice;
+
+  // lane geometry of one DMA instruction: 4 rows x 16 chunks.  A thread's 8 source addresses
+  // advance by a constant stride from one of its chunks to the next, so they are kept as running
+  // pointers; only the last chunk of the bank can hold rows past n (-> zero page).
+  const int drow = lane >> 4, dpc = lane & 15;
+  const size_t chunk_stride_bytes = (size_t)nslices * KNN_ROWS * rowbytes;
+  const uint8_t* srcp[PER_STAGE];
+  int soff[PER_STAGE];  // byte offset of the lane's 16-byte piece inside a zero page / slab
+#pragma unroll
+  for (int i = 0; i < PER_STAGE; ++i) {
+    const int row = i * 16 + wave * 4 + drow;
+    soff[i] = (dpc ^ (row & 15)) * 16;  // logical chunk that lands at physical slot dpc
+    srcp[i] = bank + ((size_t)slice * KNN_ROWS + row) * rowbytes + soff[i];
+  }
+  int issued = 0;  // next (chunk, slab) pair to issue, in order
+  auto issue = [&](int it) {
+    const int crel = it / nslab, slab = it - crel * nslab;
+    const int chunk = slice + crel * nslices;
+    const int nb = chunk * KNN_ROWS;
+    const bool tail = nb + KNN_ROWS > n;  // block-uniform
+    uint8_t* stage = ring + (it % S) * KNN_BUF;
+#pragma unroll
+    for (int i = 0; i < PER_STAGE; ++i) {
+      const int row0 = i * 16 + wave * 4;  // wave-uniform first row of this instruction
+      const uint8_t* src = srcp[i] + (size_t)slab * KNN_SLAB;
+      if (tail && nb + row0 + drow >= n) src = knn_zero_page + soff[i];
+      glds16(src, lds_addr(stage + row0 * KNN_SLAB));
+    }
+    if (slab == nslab - 1) {
+#pragma unroll
+      for (int i = 0; i < PER_STAGE; ++i) srcp[i] += chunk_stride_bytes;
+    }
+    ++issued;
+  };
+  (void)issued;
+
+  // prologue: S-1 stages in flight, then the query tile (plain loads; drained before the loop)
+#pragma unroll
+  for (int p = 0; p < S - 1; ++p)
+    if (p < iters) issue(p);
   {
-    const int ppr = rowbytes >> 4;  // 16-byte pieces per row
+    const int ppr = rowbytes >> 4;
     const int total = QB * ppr;
     for (int p = tid; p < total; p += KNN_THREADS) {
       const int row = p / ppr, c = p - row * ppr;
@@ -88,8 +143,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_block_topk(
       if (q0 + row < nq)
         v = *reinterpret_cast<const uint4*>(query + (size_t)(q0 + row) * rowbytes + (size_t)c * 16);
       const int slab = c >> 4, ch = c & 15;
-      *reinterpret_cast<uint4*>(qbuf + (size_t)row * rowbytes + slab * KNN_SLAB +
-                                ((ch ^ (row & 15)) << 4)) = v;
+      *reinterpret_cast<uint4*>(qbuf + (size_t)row * rowbytes + slab * KNN_SLAB + ((ch ^ (row & 15)) << 4)) = v;
     }
   }
 
@@ -102,83 +156,90 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_block_topk(
       lv[t][j] = -INFINITY;
       li[t][j] = INT_MAX;
     }
-
-  const int chunk_begin = slice * chunks_per_slice;
-  const int total_chunks = (n + KNN_ROWS - 1) / KNN_ROWS;
-  int chunk_end = chunk_begin + chunks_per_slice;
-  if (chunk_end > total_chunks) chunk_end = total_chunks;
-  const int iters = (chunk_end - chunk_begin) * nslab;
-
-  uint4 stage[8];
-  auto load_iter = [&](int it) {
-    const int chunk = chunk_begin + it / nslab, slab = it % nslab;
-    const int nb = chunk * KNN_ROWS;
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int p = tid + KNN_THREADS * i;
-      const int row = p >> 4, ch = p & 15;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (nb + row < n)
-        v = *reinterpret_cast<const uint4*>(bank + (size_t)(nb + row) * rowbytes +
-                                            (size_t)slab * KNN_SLAB + ch * 16);
-      stage[i] = v;
-    }
-  };
-  auto store_iter = [&](uint8_t* buf) {
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int p = tid + KNN_THREADS * i;
-      const int row = p >> 4, ch = p & 15;
-      *reinterpret_cast<uint4*>(buf + row * KNN_SLAB + ((ch ^ (row & 15)) << 4)) = stage[i];
-    }
-  };
-
   f32x16_t acc[QT];
   float gmax[QT];
 #pragma unroll
   for (int t = 0; t < QT; ++t) gmax[t] = -INFINITY;
 
-  if (iters > 0) {
-    load_iter(0);
-    store_iter(bankbuf);
+  // With one wave per SIMD nothing hides an LDS round trip between dependent ds_read -> MFMA
+  // pairs, so when a row is a single 256-byte slab the query fragments live in registers for the
+  // whole kernel and the 8 bank fragments of an iteration are fetched up front.
+  uint4 qreg[QREG ? QT : 1][8];
+  if constexpr (QREG) {
+    __syncthreads();  // query tile staged
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8)
+        qreg[t][s8] = *reinterpret_cast<const uint4*>(qbuf + (size_t)(t * 32 + r) * rowbytes +
+                                                      (((2 * s8 + h) ^ (r & 15)) << 4));
   }
-  __syncthreads();
 
   for (int it = 0; it < iters; ++it) {
-    const int cur = it & 1;
-    const int slab = it % nslab;
-    if (it + 1 < iters) load_iter(it + 1);
-    if (slab == 0) {
+    // stage `it` must have landed: in steady state S-2 younger stages may still be in flight
+    if (it + S - 1 < iters) {
+      if constexpr (S == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      else if constexpr (S == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the query tile's ds_writes (first pass)
+    __builtin_amdgcn_s_barrier();
+    if (it + S - 1 < iters) issue(it + S - 1);  // reuses the stage consumed in iteration it-1
+    const int slab = QREG ? 0 : it % nslab;
+    if (QREG || slab == 0) {
 #pragma unroll
       for (int t = 0; t < QT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     }
-    const uint8_t* abuf = bankbuf + cur * KNN_BUF + (wave * 32 + r) * KNN_SLAB;
-    const uint8_t* qrow = qbuf + (size_t)r * rowbytes + slab * KNN_SLAB;
+    const uint8_t* abuf = ring + (it % S) * KNN_BUF + (wave * 32 + r) * KNN_SLAB;
+    if constexpr (QREG) {
+      uint4 a[8];
 #pragma unroll
-    for (int s = 0; s < 8; ++s) {
-      const int off = ((2 * s + h) ^ (r & 15)) << 4;
-      const uint4 a = *reinterpret_cast<const uint4*>(abuf + off);
+      for (int s8 = 0; s8 < 8; ++s8) a[s8] = *reinterpret_cast<const uint4*>(abuf + (((2 * s8 + h) ^ (r & 15)) << 4));
 #pragma unroll
-      for (int t = 0; t < QT; ++t) {
-        const uint4 b = *reinterpret_cast<const uint4*>(qrow + (size_t)t * 32 * rowbytes + off);
-        if constexpr (DT == WM_BF16) {
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
-                                                           __builtin_bit_cast(bf16x8_t, b),
-                                                           acc[t], 0, 0, 0);
-        } else {
-          const f32x4_t af = __builtin_bit_cast(f32x4_t, a);
-          const f32x4_t bf = __builtin_bit_cast(f32x4_t, b);
+      for (int s8 = 0; s8 < 8; ++s8) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc[t], 0, 0, 0);
+        for (int t = 0; t < QT; ++t) {
+          if constexpr (DT == WM_BF16) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[s8]),
+                                                             __builtin_bit_cast(bf16x8_t, qreg[t][s8]), acc[t], 0, 0, 0);
+          } else {
+            const f32x4_t af = __builtin_bit_cast(f32x4_t, a[s8]);
+            const f32x4_t bf = __builtin_bit_cast(f32x4_t, qreg[t][s8]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc[t], 0, 0, 0);
+          }
+        }
+      }
+    } else {
+      const uint8_t* qrow = qbuf + (size_t)r * rowbytes + slab * KNN_SLAB;
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const int off = ((2 * s + h) ^ (r & 15)) << 4;
+        const uint4 a = *reinterpret_cast<const uint4*>(abuf + off);
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          const uint4 b = *reinterpret_cast<const uint4*>(qrow + (size_t)t * 32 * rowbytes + off);
+          if constexpr (DT == WM_BF16) {
+            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a),
+                                                             __builtin_bit_cast(bf16x8_t, b), acc[t], 0, 0, 0);
+          } else {
+            const f32x4_t af = __builtin_bit_cast(f32x4_t, a);
+            const f32x4_t bf = __builtin_bit_cast(f32x4_t, b);
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc[t], 0, 0, 0);
+          }
         }
       }
     }
-    if (slab == nslab - 1) {
+    if (QREG || slab == nslab - 1) {
       const int crel = it / nslab;  // chunk index inside this slice
-      const int nb = (chunk_begin + crel) * KNN_ROWS + wave * 32;
+      const int nb = (slice + crel * nslices) * KNN_ROWS + wave * 32;
 #pragma unroll
       for (int t = 0; t < QT; ++t) {
         float m = gmax[t];
@@ -187,7 +248,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_block_topk(
         gmax[t] = m;
       }
       if ((crel & 3) == 3 || it == iters - 1) {  // group of 4 chunks complete (or slice ends)
-        const int gid = ((chunk_begin + (crel & ~3)) << 3) | (wave << 1) | h;
+        const int gid = ((slice + (crel & ~3) * nslices) << 3) | (wave << 1) | h;
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
           if (gmax[t] > lv[t][K - 1]) topk_insert<K>(lv[t], li[t], gmax[t], gid);
@@ -195,9 +256,8 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_block_topk(
         }
       }
     }
-    if (it + 1 < iters) store_iter(bankbuf + (cur ^ 1) * KNN_BUF);
-    __syncthreads();
   }
+  __syncthreads();  // ring is free: reuse it for the cross-wave merge
 
   // ---- merge: (lane, lane+32) by shuffle, then the 4 waves through LDS (bank buffers are free)
 #pragma unroll
@@ -309,68 +369,170 @@ __global__ __launch_bounds__(64) void knn_merge_lists(const float* __restrict__ 
   }
 }
 
-// Exact scores of the candidate rows of one query: kg groups x 64 rows (group id -> rows as the
-// streaming kernel enumerates them), then the best `kout` by (value desc, index asc).
-template <int DT>
-__global__ __launch_bounds__(256) void knn_rescore(const uint8_t* __restrict__ query,
-                                                   const uint8_t* __restrict__ bank, int n, int d,
-                                                   int rowbytes, const int* __restrict__ gids, int kg,
-                                                   int chunks_per_slice, int total_chunks, int index_base,
-                                                   int kout, float* __restrict__ out_sim,
-                                                   int* __restrict__ out_idx) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t rs_smem[];
-  float* qf = reinterpret_cast<float*>(rs_smem);            // [d]
-  float* cv = qf + d;                                        // [kg*64]
-  int* ci = reinterpret_cast<int*>(cv + kg * 64);            // [kg*64]
+// One block per query: merge the per-slice group lists, rescore the winning groups, pick the top k.
+//  1. rank the heads of the `nslices` sorted runs (all pairs through LDS, total order with the run
+//     index as tie-break): the K best GROUPS can only come from the K runs with the best heads;
+//  2. rank those K*K entries the same way -> the K best groups;
+//  3. recompute the K*64 candidate rows exactly (8 lanes per row, 16-byte pieces, xor-shuffle sum);
+//  4. k rounds of wave arg-best (value descending, bank index ascending).
+template <int DT, int K>
+__global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ query,
+                                                  const uint8_t* __restrict__ bank, int n, int d,
+                                                  int rowbytes, const float* __restrict__ part_sim,
+                                                  const int* __restrict__ part_idx, int nslices,
+                                                  int chunk_stride, int total_chunks, int index_base,
+                                                  int kout, float* __restrict__ out_sim,
+                                                  int* __restrict__ out_idx) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t sl_smem[];
+  float* hv = reinterpret_cast<float*>(sl_smem);        // [4K] wave winners (values)
+  int* hg = reinterpret_cast<int*>(hv + 4 * K);          // [4K] (group ids)
+  int* selrun = hg + 4 * K;                              // [4K] (run indices), later the K best groups
+  float* c2v = reinterpret_cast<float*>(selrun + 4 * K); // [K*K]
+  int* c2g = reinterpret_cast<int*>(c2v + K * K);        // [K*K]
+  int* topg = c2g + K * K;                               // [K]
+  float* cv = reinterpret_cast<float*>(topg + K);        // [K*64]
+  int* ci = reinterpret_cast<int*>(cv + K * 64);         // [K*64]
+  float* qf = reinterpret_cast<float*>(ci + K * 64);     // [d]
   const int q = blockIdx.x, tid = threadIdx.x;
+  const size_t qbase = (size_t)q * nslices * K;
+
   for (int c = tid; c < d; c += 256) {
     if constexpr (DT == WM_BF16) qf[c] = bf2f(reinterpret_cast<const uint16_t*>(query + (size_t)q * rowbytes)[c]);
     else qf[c] = reinterpret_cast<const float*>(query + (size_t)q * rowbytes)[c];
   }
-  __syncthreads();
-  const int ncand = kg * 64;
-  for (int c = tid; c < ncand; c += 256) {
-    const int gid = gids[(size_t)q * kg + (c >> 6)];
-    const int j = c & 63, cc = j >> 4, e = j & 15;
-    float v = -INFINITY;
-    int row = INT_MAX;
-    if (gid != INT_MAX) {
-      const int c0 = gid >> 3, w = (gid >> 1) & 3, hh = gid & 1;
-      const int slice = c0 / chunks_per_slice;
-      int cend = (slice + 1) * chunks_per_slice;
-      if (cend > total_chunks) cend = total_chunks;
-      const int chunk = c0 + cc;
-      const int r = chunk * KNN_ROWS + w * 32 + acc_row(e, hh);
-      if (chunk < cend && r < n) {
-        row = r;
-        float acc = 0.f;
-        const uint8_t* br = bank + (size_t)r * rowbytes;
-        for (int k = 0; k < d; k += 8) {
-          if constexpr (DT == WM_BF16) {
-            const uint4 u = *reinterpret_cast<const uint4*>(br + k * 2);
-            const uint32_t ws[4] = {u.x, u.y, u.z, u.w};
+  if (tid < K) topg[tid] = INT_MAX;  // ranks no valid run reaches stay "no run"
+  // 1. each wave picks the K best run heads among its share (two per lane) by K rounds of wave
+  //    arg-best; run index breaks ties so the order is total
+  {
+    const int lane = tid & 63, wv = tid >> 6;
+    float v0 = -INFINITY, v1 = -INFINITY;
+    int g0 = INT_MAX, g1 = INT_MAX;
+    const int i0 = tid, i1 = tid + 256;
+    if (i0 < nslices) { v0 = part_sim[qbase + (size_t)i0 * K]; g0 = part_idx[qbase + (size_t)i0 * K]; }
+    if (i1 < nslices) { v1 = part_sim[qbase + (size_t)i1 * K]; g1 = part_idx[qbase + (size_t)i1 * K]; }
+    bool u0 = i0 < nslices, u1 = i1 < nslices;
+    for (int t = 0; t < K; ++t) {
+      float bv = -INFINITY;
+      int bg = INT_MAX, bi = INT_MAX;
+      if (u0) { bv = v0; bg = g0; bi = i0; }
+      if (u1 && (bi == INT_MAX || better(v1, g1, bv, bg))) { bv = v1; bg = g1; bi = i1; }
 #pragma unroll
-            for (int x = 0; x < 4; ++x) {
-              acc = fmaf(bf2f((uint16_t)(ws[x] & 0xffff)), qf[k + 2 * x], acc);
-              acc = fmaf(bf2f((uint16_t)(ws[x] >> 16)), qf[k + 2 * x + 1], acc);
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(bv, o, 64);
+        const int og = __shfl_xor(bg, o, 64);
+        const int oi = __shfl_xor(bi, o, 64);
+        if (oi != INT_MAX && (bi == INT_MAX || better(ov, og, bv, bg) || (ov == bv && og == bg && oi < bi))) {
+          bv = ov; bg = og; bi = oi;
+        }
+      }
+      if (bi == i0) u0 = false;
+      if (bi == i1) u1 = false;
+      if (lane == 0) { hv[wv * K + t] = bv; hg[wv * K + t] = bg; selrun[wv * K + t] = bi; }
+    }
+  }
+  __syncthreads();
+  // 2. the K best of the 4*K wave winners -> the K runs that can hold the K best groups
+  if (tid < 4 * K) {
+    const float v = hv[tid];
+    const int g = hg[tid], ri = selrun[tid];
+    int rank = 0;
+    for (int j = 0; j < 4 * K; ++j) {
+      const bool jb = selrun[j] != INT_MAX && (ri == INT_MAX || better(hv[j], hg[j], v, g) || (hv[j] == v && hg[j] == g && selrun[j] < ri));
+      rank += jb ? 1 : 0;
+    }
+    if (rank < K) topg[rank] = ri;  // reuse topg as the selected-run list for a moment
+  }
+  __syncthreads();
+  if (tid < K * K) {
+    const int run = topg[tid / K];
+    c2v[tid] = run != INT_MAX ? part_sim[qbase + (size_t)run * K + (tid % K)] : -INFINITY;
+    c2g[tid] = run != INT_MAX ? part_idx[qbase + (size_t)run * K + (tid % K)] : INT_MAX;
+  }
+  __syncthreads();
+  if (tid < K * K) {
+    const float v = c2v[tid];
+    const int g = c2g[tid];
+    int rank = 0;
+#pragma unroll 8
+    for (int j = 0; j < K * K; ++j)
+      rank += (better(c2v[j], c2g[j], v, g) || (c2v[j] == v && c2g[j] == g && j < tid)) ? 1 : 0;
+    if (rank < K) selrun[rank] = g;  // the K best groups (ids), best first
+  }
+  __syncthreads();
+  if (tid < K) topg[tid] = selrun[tid];
+  __syncthreads();
+
+  // ---- exact rescoring: 4 lanes per row, 64 rows per pass; a lane's pieces are sub, sub+4, ...
+  // All loads of PASSES passes are issued before any arithmetic (the work is pure latency).
+  const int sub = tid & 3, slot = tid >> 2;
+  const int pieces = rowbytes >> 4;  // 16-byte pieces per row
+  constexpr int EPP = DT == WM_BF16 ? 8 : 4;  // elements per piece
+  constexpr int PASSES = 4;
+  for (int c0p = 0; c0p < K * 64; c0p += 64 * PASSES) {
+    int rows[PASSES];
+    float accs[PASSES];
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int c = c0p + ps * 64 + slot;
+      const int gid = topg[c >> 6];
+      const int j = c & 63, cc = j >> 4, e = j & 15;
+      int row = INT_MAX;
+      if (gid != INT_MAX) {
+        const int c0 = gid >> 3, w = (gid >> 1) & 3, hh = gid & 1;
+        const int chunk = c0 + cc * chunk_stride;  // the streaming block's next chunks
+        const int rr = chunk * KNN_ROWS + w * 32 + acc_row(e, hh);
+        if (chunk < total_chunks && rr < n) row = rr;
+      }
+      rows[ps] = row;
+      accs[ps] = 0.f;
+    }
+    for (int pc0 = 0; pc0 < pieces; pc0 += 16) {  // 4 pieces per lane per step
+      uint4 u[PASSES][4];
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int pc = pc0 + sub + 4 * x;
+          u[ps][x] = (rows[ps] != INT_MAX && pc < pieces)
+                         ? *reinterpret_cast<const uint4*>(bank + (size_t)rows[ps] * rowbytes + pc * 16)
+                         : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+      for (int ps = 0; ps < PASSES; ++ps)
+#pragma unroll
+        for (int x = 0; x < 4; ++x) {
+          const int pc = pc0 + sub + 4 * x;
+          if (pc < pieces) {
+            const float* qq = qf + pc * EPP;
+            const uint32_t ws[4] = {u[ps][x].x, u[ps][x].y, u[ps][x].z, u[ps][x].w};
+            if constexpr (DT == WM_BF16) {
+#pragma unroll
+              for (int y = 0; y < 4; ++y) {
+                accs[ps] = fmaf(bf2f((uint16_t)(ws[y] & 0xffff)), qq[2 * y], accs[ps]);
+                accs[ps] = fmaf(bf2f((uint16_t)(ws[y] >> 16)), qq[2 * y + 1], accs[ps]);
+              }
+            } else {
+#pragma unroll
+              for (int y = 0; y < 4; ++y) accs[ps] = fmaf(__builtin_bit_cast(float, ws[y]), qq[y], accs[ps]);
             }
-          } else {
-            const float4 a = *reinterpret_cast<const float4*>(br + k * 4);
-            const float4 b = *reinterpret_cast<const float4*>(br + k * 4 + 16);
-            acc = fmaf(a.x, qf[k], acc); acc = fmaf(a.y, qf[k + 1], acc);
-            acc = fmaf(a.z, qf[k + 2], acc); acc = fmaf(a.w, qf[k + 3], acc);
-            acc = fmaf(b.x, qf[k + 4], acc); acc = fmaf(b.y, qf[k + 5], acc);
-            acc = fmaf(b.z, qf[k + 6], acc); acc = fmaf(b.w, qf[k + 7], acc);
           }
         }
-        v = acc;
+    }
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      float a = accs[ps];
+      a += __shfl_xor(a, 1, 64);
+      a += __shfl_xor(a, 2, 64);
+      if (sub == 0) {
+        const int c = c0p + ps * 64 + slot;
+        cv[c] = rows[ps] != INT_MAX ? a : -INFINITY;
+        ci[c] = rows[ps];
       }
     }
-    cv[c] = v;
-    ci[c] = row;
   }
   __syncthreads();
   if (tid < 64) {  // one wave: kout rounds of arg-best over the candidates
+    const int ncand = K * 64;
     for (int t = 0; t < kout; ++t) {
       float bv = -INFINITY;
       int bi = INT_MAX, bp = -1;
@@ -399,7 +561,7 @@ __global__ __launch_bounds__(256) void knn_rescore(const uint8_t* __restrict__ q
         out_idx[(size_t)q * kout + t] = bp >= 0 ? bi + index_base : -1;
         if (bp >= 0) ci[bp] = INT_MAX;  // consumed
       }
-      __builtin_amdgcn_s_waitcnt(0);  // tid 0's LDS write lands before the next round's reads
+      __builtin_amdgcn_s_waitcnt(0);  // lane 0's LDS write lands before the next round's reads
       __builtin_amdgcn_wave_barrier();
     }
   }
@@ -438,8 +600,8 @@ __global__ void knn_vote_kernel(const float* __restrict__ sim, const int* __rest
 
 inline int pick_qt(int rowbytes, int nq, int kt) {
   int qt = kt > 8 ? 2 : 4;  // K=16 lists at QT=4 would not fit the register file
-  while (qt > 1 && qt * 32 * rowbytes > 65536) qt >>= 1;
-  while (qt > 1 && (qt / 2) * 32 >= nq) qt >>= 1;  // do not carry empty query sub-tiles
+  while (qt > 1 && qt * 32 * rowbytes > 65536) qt >>= 1;   // query tile <= 64 KB of LDS
+  while (qt > 2 && (qt / 2) * 32 >= nq) qt >>= 1;            // do not carry empty query sub-tiles
   return qt;
 }
 
@@ -453,31 +615,44 @@ inline KnnPlan make_plan(int nq, int n, int rowbytes, int k) {
   p.qt = pick_qt(rowbytes, nq, p.kt);
   p.qtiles = wm_cdiv(nq, p.qt * 32);
   const int total_chunks = wm_cdiv(n, KNN_ROWS);
-  int want = 512 / p.qtiles;
+  int want = 256 / p.qtiles;  // one resident block per CU (the LDS ring fills a CU)
   if (want < 1) want = 1;
+  if (want > 512) want = 512;
   p.nslices = total_chunks < want ? total_chunks : want;
   p.chunks_per_slice = wm_cdiv(total_chunks, p.nslices);
   p.nslices = wm_cdiv(total_chunks, p.chunks_per_slice);
   return p;
 }
 
-template <int DT, int QT, int K>
-int launch_block(const KnnPlan& p, const void* query, const void* bank, int nq, int n,
-                 int rowbytes, float* ps, int* pi, hipStream_t st) {
-  const size_t lds = 2 * (size_t)KNN_BUF + (size_t)QT * 32 * rowbytes;
+template <int DT, int QT, int K, int S, bool QREG>
+int launch_stream(const KnnPlan& p, const void* query, const void* bank, int nq, int n, int rowbytes,
+                  float* ps, int* pi, hipStream_t st) {
+  const size_t lds = (size_t)S * KNN_BUF + (size_t)QT * 32 * rowbytes;
   static bool attr_set = false;  // idempotent; a race only repeats the call
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_block_topk<DT, QT, K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, 2 * KNN_BUF + 65536);
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream<DT, QT, K, S, QREG>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   dim3 grid(p.nslices, p.qtiles);
-  knn_block_topk<DT, QT, K><<<grid, KNN_THREADS, lds, st>>>(
+  knn_stream<DT, QT, K, S, QREG><<<grid, KNN_THREADS, lds, st>>>(
       static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), nq, n, rowbytes,
       p.chunks_per_slice, p.nslices, ps, pi);
   WM_LAUNCH_CHECK();
   return WM_OK;
+}
+
+// Instantiations are kept few (each is a large, fully unrolled kernel): query tiles of 64 or 128
+// (a smaller batch is zero-padded), K = 8 or 16 (16 only with 64-query tiles), register-resident
+// query fragments only for bf16 rows of exactly one slab (d = 128), ring depth 4 there and 3 otherwise.
+template <int DT, int QT, int K>
+int launch_block(const KnnPlan& p, const void* query, const void* bank, int nq, int n, int rowbytes,
+                 float* ps, int* pi, hipStream_t st) {
+  if constexpr (DT == WM_BF16) {
+    if (rowbytes == KNN_SLAB) return launch_stream<DT, QT, K, 4, true>(p, query, bank, nq, n, rowbytes, ps, pi, st);
+  }
+  return launch_stream<DT, QT, K, 3, false>(p, query, bank, nq, n, rowbytes, ps, pi, st);
 }
 
 template <int DT, int K>
@@ -486,10 +661,23 @@ int dispatch_qt(const KnnPlan& p, const void* query, const void* bank, int nq, i
   if constexpr (K <= 8) {
     if (p.qt == 4) return launch_block<DT, 4, K>(p, query, bank, nq, n, rowbytes, ps, pi, st);
   }
-  switch (p.qt) {
-    case 2: return launch_block<DT, 2, K>(p, query, bank, nq, n, rowbytes, ps, pi, st);
-    default: return launch_block<DT, 1, K>(p, query, bank, nq, n, rowbytes, ps, pi, st);
+  if constexpr (DT == WM_F32 && K <= 8) {  // 2048-byte rows (512 float32 features): 32-query tiles
+    if (p.qt == 1) return launch_block<DT, 1, K>(p, query, bank, nq, n, rowbytes, ps, pi, st);
   }
+  if (p.qt == 1) return WM_EUNSUPPORTED;  // k > 8 with rows above 1 KB is not instantiated
+  return launch_block<DT, 2, K>(p, query, bank, nq, n, rowbytes, ps, pi, st);
+}
+
+template <int DT, int K>
+int launch_select(const KnnPlan& p, const void* query, const void* bank, int n, int d, int rowbytes, int nq,
+                  const float* ps, const int* pi, int index_base, int kout, float* out_sim, int* out_idx,
+                  hipStream_t st) {
+  const size_t lds = (12 * K + 2 * K * K + K) * 4 + (size_t)K * 64 * 8 + (size_t)d * 4;
+  knn_select<DT, K><<<nq, 256, lds, st>>>(static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), n, d,
+                                          rowbytes, ps, pi, p.nslices, p.nslices, wm_cdiv(n, KNN_ROWS),
+                                          index_base, kout, out_sim, out_idx);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
 }
 
 }  // namespace
@@ -512,7 +700,7 @@ extern "C" int wm_knn_topk(const void* query, const void* bank, int nq, int n, i
   WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_EUNSUPPORTED);
   WM_REQUIRE(k <= 16 && k <= n, WM_EUNSUPPORTED);
   const int rowbytes = d * (dtype == WM_BF16 ? 2 : 4);
-  WM_REQUIRE(rowbytes % KNN_SLAB == 0 && rowbytes <= 2048, WM_EUNSUPPORTED);
+  WM_REQUIRE(rowbytes % KNN_SLAB == 0 && rowbytes <= (dtype == WM_F32 ? 2048 : 1024), WM_EUNSUPPORTED);
   WM_REQUIRE((reinterpret_cast<uintptr_t>(query) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(bank) & 15) == 0 &&
                  (reinterpret_cast<uintptr_t>(workspace) & 15) == 0,
@@ -532,27 +720,11 @@ extern "C" int wm_knn_topk(const void* query, const void* bank, int nq, int n, i
                    : dispatch_qt<WM_F32, 16>(p, query, bank, nq, n, rowbytes, ps, pi, st);
   }
   if (rc != WM_OK) return rc;
-  // candidate groups of every query: [nq][kt] (value, group id), best first
-  float* gsim = ps + 2 * cand;
-  int* gidx = reinterpret_cast<int*>(gsim + (size_t)nq * p.kt);
-  const long long sq = (long long)p.nslices * p.kt, sp = p.kt;
-  if (p.kt == 8)
-    knn_merge_lists<8><<<nq, 64, 0, st>>>(ps, pi, p.nslices, p.kt, sq, sp, p.kt, gsim, gidx);
-  else
-    knn_merge_lists<16><<<nq, 64, 0, st>>>(ps, pi, p.nslices, p.kt, sq, sp, p.kt, gsim, gidx);
-  WM_LAUNCH_CHECK();
-  const size_t lds = (size_t)d * 4 + (size_t)p.kt * 64 * 8;
-  const int total_chunks = wm_cdiv(n, KNN_ROWS);
   if (dtype == WM_BF16)
-    knn_rescore<WM_BF16><<<nq, 256, lds, st>>>(static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), n,
-                                               d, rowbytes, gidx, p.kt, p.chunks_per_slice, total_chunks,
-                                               bank_index_base, k, out_sim, out_idx);
-  else
-    knn_rescore<WM_F32><<<nq, 256, lds, st>>>(static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), n,
-                                              d, rowbytes, gidx, p.kt, p.chunks_per_slice, total_chunks,
-                                              bank_index_base, k, out_sim, out_idx);
-  WM_LAUNCH_CHECK();
-  return WM_OK;
+    return p.kt == 8 ? launch_select<WM_BF16, 8>(p, query, bank, n, d, rowbytes, nq, ps, pi, bank_index_base, k, out_sim, out_idx, st)
+                     : launch_select<WM_BF16, 16>(p, query, bank, n, d, rowbytes, nq, ps, pi, bank_index_base, k, out_sim, out_idx, st);
+  return p.kt == 8 ? launch_select<WM_F32, 8>(p, query, bank, n, d, rowbytes, nq, ps, pi, bank_index_base, k, out_sim, out_idx, st)
+                   : launch_select<WM_F32, 16>(p, query, bank, n, d, rowbytes, nq, ps, pi, bank_index_base, k, out_sim, out_idx, st);
 }
 
 extern "C" int wm_knn_merge(const float* in_sim, const int32_t* in_idx, int parts, int nq, int k,

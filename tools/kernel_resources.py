@@ -2,7 +2,7 @@
 import re, subprocess, sys
 src = sys.argv[1]
 r = subprocess.run(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-c", src, "-o", "/dev/null",
-                    "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True)
+                    "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900)
 cur = {}
 rows = []
 for line in r.stderr.splitlines():
