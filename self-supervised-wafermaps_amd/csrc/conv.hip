@@ -44,26 +44,33 @@ struct ConvArgs {
   int N, SH, SW, SC, DH, DW, DC, R, S, stride, pad, M, nkt;
 };
 
-__device__ __forceinline__ uint4 ldg128(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+// 128 zero bytes: the global_load_lds source of padded / out-of-range taps
+__device__ __attribute__((aligned(256))) uint16_t conv_zero_page[128];
 
+// Both operand tiles go HBM -> LDS by global_load_lds (16 B per lane, 1 KiB per wave instruction,
+// no VGPR staging, no ds_write).  The DMA destination is lane-linear, so a lane fetches the LOGICAL
+// chunk that belongs at its physical slot: chunk = slot ^ (row & 7) (the same involution is applied
+// on the fragment reads).  Two stages; the tile for k-step kt+1 is in flight under the MFMAs of kt:
+//   s_waitcnt vmcnt(0) ; s_barrier ; issue(kt+1) ; compute(kt)
 template <int BN, int CPT, bool DGRAD>
 __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t cv_smem[];
   constexpr int A_BYTES = CV_BM * CV_ROW;
   constexpr int B_BYTES = BN * CV_ROW;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int NB = BN / 32;  // weight rows staged per thread
+  constexpr int NB = BN / 32;  // weight rows fetched per thread
   constexpr int NJ = BN / 32;  // 16-channel fragments per wave (a wave owns BN/2 channels)
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * CV_BM, n0 = blockIdx.y * BN;
-  const int chunk = tid & 7, rowl = tid >> 3;
-  const int swz = (chunk ^ (rowl & 7)) << 4;  // (rowl + 32 i) & 7 == rowl & 7
+  const int rowl = tid >> 3;                   // rows rowl + 32 i; (rowl + 32 i) & 7 == rowl & 7
+  const int chunk = (tid & 7) ^ (rowl & 7);    // logical 16-byte chunk this lane fetches
 
   int bh[4], bw[4], nb[4];
   bool mv[4];
+  const uint16_t* p0[4];
   const int dhw = a.DH * a.DW;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -80,58 +87,57 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
       bw[i] = dw + a.pad;
     }
     nb[i] = n * a.SH * a.SW;
+    // address of (tap 0, channel chunk) for this row; may lie outside the tensor (never read then)
+    p0[i] = a.src + ((long long)(nb[i] + bh[i] * a.SW + bw[i]) * a.SC + chunk * 8);
   }
   const size_t wrow = (size_t)a.R * a.S * a.SC;
+  const uint16_t* pb[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) pb[i] = a.wt + (size_t)(n0 + rowl + 32 * i) * wrow + chunk * 8;
 
-  uint4 ra[4], rb[NB];
-  auto gload = [&](int kt) {
-    int r, s, coff;
+  auto issue = [&](int kt, uint8_t* stage) {
+    int r, s;
+    long long koff;  // uniform element offset of this k-tile relative to p0
     if constexpr (CPT == 8) {
       const int cpk = a.SC >> 6;
       const int tap = kt / cpk;
-      coff = (kt - tap * cpk) * 64 + chunk * 8;
+      const int c0 = (kt - tap * cpk) * 64;
       r = tap / a.S;
       s = tap - r * a.S;
-    } else {  // 16-channel source: one k-tile = kernel row kt, taps s = 0..3
+      koff = DGRAD ? ((long long)(-r * a.SW - s) * a.SC + c0) : ((long long)(r * a.SW + s) * a.SC + c0);
+    } else {  // 16-channel source: one k-tile = kernel row kt; the lane's chunk picks the tap
       r = kt;
       s = chunk >> 1;
-      coff = (chunk & 1) * 8;
+      koff = (long long)r * a.SW * a.SC;
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      int sh, sw;
       bool ok = mv[i];
+      const uint16_t* src;
       if constexpr (!DGRAD) {
-        sh = bh[i] + r;
-        sw = bw[i] + s;
+        const int sh = bh[i] + r, sw = bw[i] + s;
+        ok = ok && (unsigned)sh < (unsigned)a.SH && (unsigned)sw < (unsigned)a.SW;
+        src = p0[i] + koff;
       } else {
         const int th = bh[i] - r, tw = bw[i] - s;
         ok = ok && th >= 0 && tw >= 0;
         if (a.stride == 2) {
           ok = ok && (((th | tw) & 1) == 0);
-          sh = th >> 1;
-          sw = tw >> 1;
+          const int sh = th >> 1, sw = tw >> 1;
+          ok = ok && sh < a.SH && sw < a.SW;
+          const int c0 = (kt % (a.SC >> 6)) * 64;
+          src = a.src + ((long long)(nb[i] + sh * a.SW + sw) * a.SC + c0 + chunk * 8);
         } else {
-          sh = th;
-          sw = tw;
+          ok = ok && th < a.SH && tw < a.SW;
+          src = p0[i] + koff;
         }
       }
-      ok = ok && (unsigned)sh < (unsigned)a.SH && (unsigned)sw < (unsigned)a.SW;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = ldg128(a.src + ((size_t)(nb[i] + sh * a.SW + sw) * a.SC + coff));
-      ra[i] = v;
+      if (!ok) src = conv_zero_page + chunk * 8;
+      glds16(src, lds_addr(stage + (wave * 8 + 32 * i) * CV_ROW));
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      rb[i] = ldg128(a.wt + (size_t)(n0 + rowl + 32 * i) * wrow + (size_t)kt * 64 + chunk * 8);
-  };
-  auto sstore = [&](uint8_t* buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i)
-      *reinterpret_cast<uint4*>(buf + (rowl + 32 * i) * CV_ROW + swz) = ra[i];
-#pragma unroll
-    for (int i = 0; i < NB; ++i)
-      *reinterpret_cast<uint4*>(buf + A_BYTES + (rowl + 32 * i) * CV_ROW + swz) = rb[i];
+      glds16(pb[i] + (size_t)kt * 64, lds_addr(stage + A_BYTES + (wave * 8 + 32 * i) * CV_ROW));
   };
 
   f32x4_t acc[NJ][4];
@@ -164,16 +170,14 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
     }
   };
 
-  gload(0);
-  sstore(cv_smem);
-  __syncthreads();
+  issue(0, cv_smem);
   for (int kt = 0; kt < a.nkt; ++kt) {
-    uint8_t* cur = cv_smem + (kt & 1) * STAGE;
-    if (kt + 1 < a.nkt) gload(kt + 1);
-    compute(cur);
-    if (kt + 1 < a.nkt) sstore(cv_smem + ((kt + 1) & 1) * STAGE);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt have landed
+    __builtin_amdgcn_s_barrier();                     // ... everyone's; and compute(kt-1) is over
+    if (kt + 1 < a.nkt) issue(kt + 1, cv_smem + ((kt + 1) & 1) * STAGE);
+    compute(cv_smem + (kt & 1) * STAGE);
   }
+  __syncthreads();
 
   // ---- epilogue: accumulators -> bf16 tile in LDS ([pixel][channel], rows padded by 16 B) -> HBM
   constexpr int CS = BN * 2 + 16;
@@ -206,16 +210,26 @@ struct WgradArgs {
 
 constexpr int WG_PIX = 64;  // pixels per staged chunk (two MFMA k-steps)
 
+// Tiles keep their natural [pixel][channel] layout (rows of 256 B for 128 channels, 128 B for 64)
+// and are read with ds_read_b64_tr_b16.  A half-wave reads 8 consecutive rows x one 32-byte column
+// block, so the 32-byte block index is XOR-swizzled by the row: block ^ (row & 7) in 256-byte rows,
+// block ^ ((row >> 1) & 3) in 128-byte rows (two rows per 64-bank line) — conflict free, and
+// compatible with the lane-linear global_load_lds destination (swizzle applied to the source).
+template <int ROWB>
+__device__ __forceinline__ int wg_swz(int row, int blk) {
+  return ROWB == 256 ? (blk ^ (row & 7)) : (blk ^ ((row >> 1) & 3));
+}
+
 template <int BMO, int CPT>
 __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t wg_smem[];
-  constexpr int SA = BMO * 2 + 32;  // dY tile row stride (bytes)
-  constexpr int SB = 64 * 2 + 32;   // X tile row stride
-  constexpr int A_BYTES = WG_PIX * SA;
-  constexpr int STAGE = A_BYTES + WG_PIX * SB;
-  constexpr int NA = BMO / 32;       // dY pieces per thread (64 rows x BMO/8 chunks / 256)
-  constexpr int ACH = BMO / 8;       // 16-byte chunks per dY row
-  constexpr int MJ = 2;              // 16-channel fragments per wave along K
+  constexpr int RA = BMO * 2;  // dY tile row bytes
+  constexpr int RB = 128;      // X tile row bytes
+  constexpr int A_BYTES = WG_PIX * RA;
+  constexpr int STAGE = A_BYTES + WG_PIX * RB;
+  constexpr int NA = A_BYTES / 4096;  // dY DMA instructions per wave (1 KiB each, 4 waves)
+  constexpr int RPI_A = 1024 / RA;    // rows per dY instruction (4 or 8)
+  constexpr int MJ = 2;               // 16-channel fragments per wave along K
   constexpr int NJ = BMO == 128 ? 4 : 2;  // 16-column fragments per wave
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -225,19 +239,23 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   const int cout_w = BMO == 128 ? wave * 32 : (wave >> 1) * 32;
   const int col_w = BMO == 128 ? 0 : (wave & 1) * 32;
 
-  // column tile -> tap / channel offset for this thread's X chunk
-  const int xchunk = tid & 7, xrow = tid >> 3;  // rows xrow, xrow + 32
-  int r, s, coff;
+  // ---- DMA lane geometry
+  // dY: instruction i of wave w covers rows (i*4 + w)*RPI_A .. +RPI_A-1
+  const int a_ro = RA == 256 ? (lane >> 4) : (lane >> 3);          // row inside the instruction
+  const int a_pc = RA == 256 ? (lane & 15) : (lane & 7);           // physical 16-byte slot
+  // X: instruction i (0,1) of wave w covers rows (i*4 + w)*8 .. +7
+  const int x_ro = lane >> 3, x_pc = lane & 7;
+
+  // column tile -> tap / channel offset of this lane's X chunk (logical chunk depends on the row)
+  int r, s_uniform;
   if constexpr (CPT == 8) {
     const int cpk = a.C >> 6;
     const int tap = ct / cpk;
-    coff = (ct - tap * cpk) * 64 + xchunk * 8;
     r = tap / a.S;
-    s = tap - r * a.S;
+    s_uniform = tap - r * a.S;
   } else {
     r = ct;
-    s = xchunk >> 1;
-    coff = (xchunk & 1) * 8;
+    s_uniform = 0;
   }
 
   const int chunk_begin = blockIdx.z * a.chunks_per_split;
@@ -246,36 +264,47 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   const int iters = chunk_end - chunk_begin;
   if (iters <= 0) return;
 
-  // running (n, p, q) of this thread's two X rows
-  int pn[2], pp[2], pq[2];
+  // running (n, p, q) of this lane's two X rows
+  int pn[2], pp[2], pq[2], xrow[2], xlc[2];
   const int pqn = a.P * a.Q;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int m = chunk_begin * WG_PIX + xrow + 32 * i;
+    xrow[i] = (i * 4 + wave) * 8 + x_ro;
+    xlc[i] = (wg_swz<RB>(xrow[i], x_pc >> 1) << 1) | (x_pc & 1);  // logical 16-byte chunk
+    const int m = chunk_begin * WG_PIX + xrow[i];
     pn[i] = m / pqn;
     const int rem = m - pn[i] * pqn;
     pp[i] = rem / a.Q;
     pq[i] = rem - pp[i] * a.Q;
   }
 
-  uint4 ra[NA], rx[2];
-  auto gload = [&](int it) {
+  auto issue = [&](int it, uint8_t* stage) {
     const int pix0 = (chunk_begin + it) * WG_PIX;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int p = tid + CV_THREADS * i;
-      const int row = p / ACH, ch = p - row * ACH;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (pix0 + row < a.M) v = ldg128(a.dy + (size_t)(pix0 + row) * a.K + k0 + ch * 8);
-      ra[i] = v;
+      const int row0 = (i * 4 + wave) * RPI_A;
+      const int row = row0 + a_ro;
+      const int lc = (wg_swz<RA>(row, a_pc >> 1) << 1) | (a_pc & 1);
+      const uint16_t* src = a.dy + (size_t)(pix0 + row) * a.K + k0 + lc * 8;
+      if (pix0 + row >= a.M) src = conv_zero_page + lc * 8;
+      glds16(src, lds_addr(stage + row0 * RA));
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
+      int s, coff;
+      if constexpr (CPT == 8) {
+        const int cpk = a.C >> 6;
+        s = s_uniform;
+        coff = (ct % cpk) * 64 + xlc[i] * 8;
+      } else {
+        s = xlc[i] >> 1;
+        coff = (xlc[i] & 1) * 8;
+      }
       const int sh = pp[i] * a.stride - a.pad + r, sw = pq[i] * a.stride - a.pad + s;
-      const bool ok = (pix0 + xrow + 32 * i < a.M) && (unsigned)sh < (unsigned)a.H && (unsigned)sw < (unsigned)a.W;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (ok) v = ldg128(a.x + ((size_t)((pn[i] * a.H + sh) * a.W + sw) * a.C + coff));
-      rx[i] = v;
+      const bool ok = (pix0 + xrow[i] < a.M) && (unsigned)sh < (unsigned)a.H && (unsigned)sw < (unsigned)a.W;
+      const uint16_t* src = a.x + ((size_t)((pn[i] * a.H + sh) * a.W + sw) * a.C + coff);
+      if (!ok) src = conv_zero_page + xlc[i] * 8;
+      glds16(src, lds_addr(stage + A_BYTES + ((i * 4 + wave) * 8) * RB));
       // advance this row by one chunk (64 pixels)
       pq[i] += WG_PIX;
       while (pq[i] >= a.Q) {
@@ -287,17 +316,6 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
       }
     }
   };
-  auto sstore = [&](uint8_t* buf) {
-#pragma unroll
-    for (int i = 0; i < NA; ++i) {
-      const int p = tid + CV_THREADS * i;
-      const int row = p / ACH, ch = p - row * ACH;
-      *reinterpret_cast<uint4*>(buf + row * SA + ch * 16) = ra[i];
-    }
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-      *reinterpret_cast<uint4*>(buf + A_BYTES + (xrow + 32 * i) * SB + xchunk * 16) = rx[i];
-  };
 
   f32x4_t acc[MJ][NJ];
 #pragma unroll
@@ -308,9 +326,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   // transposed-read geometry: 16-lane group g, lane (q, p) inside it; MFMA k-slot (g, e) holds
   // pixel 4g + e (e < 4) or 16 + 4g + (e - 4) of the 32-pixel k-step — same map for both operands.
   const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
-  auto tr_read = [&](const uint8_t* base, int stride, int row, int colbyte) -> s16x4_t {
-    return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-        (__attribute__((address_space(3))) s16x4_t*)(base + row * stride + colbyte));
+  auto tr_read = [&](const uint8_t* p) -> s16x4_t {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
   };
   auto compute = [&](const uint8_t* buf) {
 #pragma unroll
@@ -319,15 +336,17 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
       bf16x8_t af[MJ], bfr[NJ];
 #pragma unroll
       for (int i = 0; i < MJ; ++i) {
-        const int cb = (cout_w + i * 16 + 4 * tp) * 2;
-        const s16x4_t lo = tr_read(buf, SA, r0, cb), hi = tr_read(buf, SA, r1, cb);
+        const int blk = (cout_w + i * 16) >> 4;
+        const s16x4_t lo = tr_read(buf + r0 * RA + wg_swz<RA>(r0, blk) * 32 + 8 * tp);
+        const s16x4_t hi = tr_read(buf + r1 * RA + wg_swz<RA>(r1, blk) * 32 + 8 * tp);
         const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         af[i] = __builtin_bit_cast(bf16x8_t, v);
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int cb = (col_w + j * 16 + 4 * tp) * 2;
-        const s16x4_t lo = tr_read(buf + A_BYTES, SB, r0, cb), hi = tr_read(buf + A_BYTES, SB, r1, cb);
+        const int blk = (col_w + j * 16) >> 4;
+        const s16x4_t lo = tr_read(buf + A_BYTES + r0 * RB + wg_swz<RB>(r0, blk) * 32 + 8 * tp);
+        const s16x4_t hi = tr_read(buf + A_BYTES + r1 * RB + wg_swz<RB>(r1, blk) * 32 + 8 * tp);
         const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         bfr[j] = __builtin_bit_cast(bf16x8_t, v);
       }
@@ -339,15 +358,12 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
     }
   };
 
-  gload(0);
-  sstore(wg_smem);
-  __syncthreads();
+  issue(0, wg_smem);
   for (int it = 0; it < iters; ++it) {
-    uint8_t* cur = wg_smem + (it & 1) * STAGE;
-    if (it + 1 < iters) gload(it + 1);
-    compute(cur);
-    if (it + 1 < iters) sstore(wg_smem + ((it + 1) & 1) * STAGE);
-    __syncthreads();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (it + 1 < iters) issue(it + 1, wg_smem + ((it + 1) & 1) * STAGE);
+    compute(wg_smem + (it & 1) * STAGE);
   }
 
   const size_t rsc = (size_t)a.R * a.S * a.C;
@@ -388,7 +404,7 @@ int launch_igemm(const ConvArgs& a, hipStream_t st) {
 
 template <int BMO, int CPT>
 int launch_wgrad(WgradArgs a, hipStream_t st) {
-  constexpr int lds = 2 * (WG_PIX * (BMO * 2 + 32) + WG_PIX * (64 * 2 + 32));
+  constexpr int lds = 2 * (WG_PIX * BMO * 2 + WG_PIX * 128);
   static bool attr = false;
   if (!attr) {
     const int rc = set_lds(&conv_wgrad<BMO, CPT>, lds);
