@@ -52,8 +52,14 @@ __device__ __attribute__((aligned(256))) uint16_t conv_zero_page[128];
 // chunk that belongs at its physical slot: chunk = slot ^ (row & 7) (the same involution is applied
 // on the fragment reads).  Two stages; the tile for k-step kt+1 is in flight under the MFMAs of kt:
 //   s_waitcnt vmcnt(0) ; s_barrier ; issue(kt+1) ; compute(kt)
-template <int BN, int CPT, bool DGRAD>
+// MODE 0: forward.  MODE 1: dgrad (any stride; stride-2 taps that do not hit a source pixel are
+// fetched as zeros).  MODE 2: dgrad of a stride-2 convolution with the destination pixels ordered by
+// parity class (h&1, w&1): all 128 rows of a tile then share the set of taps that hit a source
+// pixel (r = r0 + 2 jr, s = s0 + 2 js), so only those k-tiles are executed — 9/4 instead of 9 per
+// pixel for 3x3, and three of four classes of the 1x1 downsample just store zeros.
+template <int BN, int CPT, int MODE>
 __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
+  constexpr bool DGRAD = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) uint8_t cv_smem[];
   constexpr int A_BYTES = CV_BM * CV_ROW;
   constexpr int B_BYTES = BN * CV_ROW;
@@ -72,23 +78,49 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   bool mv[4];
   const uint16_t* p0[4];
   const int dhw = a.DH * a.DW;
+  // MODE 2: parity class of this tile and its valid-tap grid
+  int r0 = 0, s0 = 0, nr = 0, ns = 0, nkt = a.nkt;
+  if constexpr (MODE == 2) {
+    const int cls = a.M >> 2;
+    const int pc = m0 / cls;
+    const int ph = pc >> 1, pw = pc & 1;
+    r0 = (ph + a.pad) & 1;
+    s0 = (pw + a.pad) & 1;
+    nr = r0 < a.R ? (a.R - r0 + 1) >> 1 : 0;
+    ns = s0 < a.S ? (a.S - s0 + 1) >> 1 : 0;
+    nkt = nr * ns * (a.SC >> 6);
+    const int h2w2 = (a.DH >> 1) * (a.DW >> 1);
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int m = m0 + rowl + 32 * i;
-    mv[i] = m < a.M;
-    const int mm = mv[i] ? m : 0;
-    const int n = mm / dhw, rem = mm - n * dhw;
-    const int dh = rem / a.DW, dw = rem - dh * a.DW;
-    if constexpr (!DGRAD) {
-      bh[i] = dh * a.stride - a.pad;
-      bw[i] = dw * a.stride - a.pad;
-    } else {
-      bh[i] = dh + a.pad;
-      bw[i] = dw + a.pad;
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + rowl + 32 * i - pc * cls;  // index inside the class
+      mv[i] = true;                                   // class size % 128 == 0 (host-checked)
+      const int n = m / h2w2, rem = m - n * h2w2;
+      const int h2 = rem / (a.DW >> 1), w2 = rem - h2 * (a.DW >> 1);
+      // source pixel of tap (r, s): (h2 + (ph + pad - r)/2, w2 + (pw + pad - s)/2)
+      bh[i] = h2 + ((ph + a.pad - r0) >> 1);
+      bw[i] = w2 + ((pw + a.pad - s0) >> 1);
+      nb[i] = n * a.SH * a.SW;
+      p0[i] = a.src + ((long long)(nb[i] + bh[i] * a.SW + bw[i]) * a.SC + chunk * 8);
     }
-    nb[i] = n * a.SH * a.SW;
-    // address of (tap 0, channel chunk) for this row; may lie outside the tensor (never read then)
-    p0[i] = a.src + ((long long)(nb[i] + bh[i] * a.SW + bw[i]) * a.SC + chunk * 8);
+  } else {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int m = m0 + rowl + 32 * i;
+      mv[i] = m < a.M;
+      const int mm = mv[i] ? m : 0;
+      const int n = mm / dhw, rem = mm - n * dhw;
+      const int dh = rem / a.DW, dw = rem - dh * a.DW;
+      if constexpr (!DGRAD) {
+        bh[i] = dh * a.stride - a.pad;
+        bw[i] = dw * a.stride - a.pad;
+      } else {
+        bh[i] = dh + a.pad;
+        bw[i] = dw + a.pad;
+      }
+      nb[i] = n * a.SH * a.SW;
+      // address of (tap 0, channel chunk) for this row; may lie outside the tensor (never read then)
+      p0[i] = a.src + ((long long)(nb[i] + bh[i] * a.SW + bw[i]) * a.SC + chunk * 8);
+    }
   }
   const size_t wrow = (size_t)a.R * a.S * a.SC;
   const uint16_t* pb[NB];
@@ -98,7 +130,28 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   auto issue = [&](int kt, uint8_t* stage) {
     int r, s;
     long long koff;  // uniform element offset of this k-tile relative to p0
-    if constexpr (CPT == 8) {
+    if constexpr (MODE == 2) {
+      const int cpk = a.SC >> 6;
+      const int tapj = kt / cpk;
+      const int c0 = (kt - tapj * cpk) * 64;
+      const int jr = tapj / ns, js = tapj - jr * ns;
+      r = jr;  // steps of -1 source pixel per valid tap
+      s = js;
+      koff = (long long)(-jr * a.SW - js) * a.SC + c0;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int sh = bh[i] - jr, sw = bw[i] - js;
+        const bool ok = (unsigned)sh < (unsigned)a.SH && (unsigned)sw < (unsigned)a.SW;
+        const uint16_t* src = ok ? p0[i] + koff : conv_zero_page + chunk * 8;
+        glds16(src, lds_addr(stage + (wave * 8 + 32 * i) * CV_ROW));
+      }
+      // weights: tap (r0 + 2 jr, s0 + 2 js)
+      const size_t wk = ((size_t)((r0 + 2 * jr) * a.S + (s0 + 2 * js)) * a.SC) + c0;
+#pragma unroll
+      for (int i = 0; i < NB; ++i)
+        glds16(pb[i] + wk, lds_addr(stage + A_BYTES + (wave * 8 + 32 * i) * CV_ROW));
+      return;
+    } else if constexpr (CPT == 8) {
       const int cpk = a.SC >> 6;
       const int tap = kt / cpk;
       const int c0 = (kt - tap * cpk) * 64;
@@ -170,11 +223,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
     }
   };
 
-  issue(0, cv_smem);
-  for (int kt = 0; kt < a.nkt; ++kt) {
+  if (nkt > 0) issue(0, cv_smem);
+  for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt have landed
     __builtin_amdgcn_s_barrier();                     // ... everyone's; and compute(kt-1) is over
-    if (kt + 1 < a.nkt) issue(kt + 1, cv_smem + ((kt + 1) & 1) * STAGE);
+    if (kt + 1 < nkt) issue(kt + 1, cv_smem + ((kt + 1) & 1) * STAGE);
     compute(cv_smem + (kt & 1) * STAGE);
   }
   __syncthreads();
@@ -194,8 +247,18 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   constexpr int CPR = BN / 8;
   for (int p = tid; p < CV_BM * CPR; p += CV_THREADS) {
     const int row = p / CPR, ch = p - row * CPR;
+    size_t pix = (size_t)(m0 + row);
+    if constexpr (MODE == 2) {  // class-ordered row -> pixel (n, 2 h2 + ph, 2 w2 + pw)
+      const int cls = a.M >> 2;
+      const int pc = m0 / cls;
+      const int m = m0 + row - pc * cls;
+      const int h2w2 = (a.DH >> 1) * (a.DW >> 1);
+      const int n = m / h2w2, rem = m - n * h2w2;
+      const int h2 = rem / (a.DW >> 1), w2 = rem - h2 * (a.DW >> 1);
+      pix = ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
+    }
     if (m0 + row < a.M)
-      *reinterpret_cast<uint4*>(a.dst + (size_t)(m0 + row) * a.DC + n0 + ch * 8) =
+      *reinterpret_cast<uint4*>(a.dst + pix * a.DC + n0 + ch * 8) =
           *reinterpret_cast<const uint4*>(cv_smem + row * CS + ch * 16);
   }
 }
@@ -220,43 +283,33 @@ __device__ __forceinline__ int wg_swz(int row, int blk) {
   return ROWB == 256 ? (blk ^ (row & 7)) : (blk ^ ((row >> 1) & 3));
 }
 
-template <int BMO, int CPT>
+// A block owns BMO output channels x NT consecutive 64-column tiles of the (r,s,c) axis: the dY
+// tile is fetched once per 64-pixel chunk and multiplied against NT gathered X tiles, so the MFMA
+// work per barrier is NT x that of a single tile (layer1 and the stem have only 64 channels).
+template <int BMO, int CPT, int NT>
 __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t wg_smem[];
   constexpr int RA = BMO * 2;  // dY tile row bytes
   constexpr int RB = 128;      // X tile row bytes
   constexpr int A_BYTES = WG_PIX * RA;
-  constexpr int STAGE = A_BYTES + WG_PIX * RB;
+  constexpr int X_BYTES = WG_PIX * RB;
+  constexpr int STAGE = A_BYTES + NT * X_BYTES;
   constexpr int NA = A_BYTES / 4096;  // dY DMA instructions per wave (1 KiB each, 4 waves)
   constexpr int RPI_A = 1024 / RA;    // rows per dY instruction (4 or 8)
   constexpr int MJ = 2;               // 16-channel fragments per wave along K
-  constexpr int NJ = BMO == 128 ? 4 : 2;  // 16-column fragments per wave
+  constexpr int NJ = BMO == 128 ? 4 : 2;  // 16-column fragments per wave per tile
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ct = blockIdx.x;  // 64-column tile of the (r,s,c) axis
+  const int ct0 = blockIdx.x * NT;  // first 64-column tile
   const int k0 = blockIdx.y * BMO;
   const int cout_w = BMO == 128 ? wave * 32 : (wave >> 1) * 32;
   const int col_w = BMO == 128 ? 0 : (wave & 1) * 32;
 
   // ---- DMA lane geometry
-  // dY: instruction i of wave w covers rows (i*4 + w)*RPI_A .. +RPI_A-1
-  const int a_ro = RA == 256 ? (lane >> 4) : (lane >> 3);          // row inside the instruction
-  const int a_pc = RA == 256 ? (lane & 15) : (lane & 7);           // physical 16-byte slot
-  // X: instruction i (0,1) of wave w covers rows (i*4 + w)*8 .. +7
-  const int x_ro = lane >> 3, x_pc = lane & 7;
-
-  // column tile -> tap / channel offset of this lane's X chunk (logical chunk depends on the row)
-  int r, s_uniform;
-  if constexpr (CPT == 8) {
-    const int cpk = a.C >> 6;
-    const int tap = ct / cpk;
-    r = tap / a.S;
-    s_uniform = tap - r * a.S;
-  } else {
-    r = ct;
-    s_uniform = 0;
-  }
+  const int a_ro = RA == 256 ? (lane >> 4) : (lane >> 3);  // row inside a dY instruction
+  const int a_pc = RA == 256 ? (lane & 15) : (lane & 7);   // physical 16-byte slot
+  const int x_ro = lane >> 3, x_pc = lane & 7;             // X: 8 rows x 8 slots per instruction
 
   const int chunk_begin = blockIdx.z * a.chunks_per_split;
   int chunk_end = chunk_begin + a.chunks_per_split;
@@ -264,7 +317,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   const int iters = chunk_end - chunk_begin;
   if (iters <= 0) return;
 
-  // running (n, p, q) of this lane's two X rows
+  // running (n, p, q) of this lane's two X rows (shared by the NT tiles)
   int pn[2], pp[2], pq[2], xrow[2], xlc[2];
   const int pqn = a.P * a.Q;
 #pragma unroll
@@ -291,20 +344,30 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-      int s, coff;
-      if constexpr (CPT == 8) {
-        const int cpk = a.C >> 6;
-        s = s_uniform;
-        coff = (ct % cpk) * 64 + xlc[i] * 8;
-      } else {
-        s = xlc[i] >> 1;
-        coff = (xlc[i] & 1) * 8;
+      const bool inb = pix0 + xrow[i] < a.M;
+      const int hb = pp[i] * a.stride - a.pad, wb = pq[i] * a.stride - a.pad;
+      const size_t nbase = (size_t)pn[i] * a.H;
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int ct = ct0 + t;
+        int r, s, coff;
+        if constexpr (CPT == 8) {
+          const int cpk = a.C >> 6;
+          const int tap = ct / cpk;
+          r = tap / a.S;
+          s = tap - r * a.S;
+          coff = (ct - tap * cpk) * 64 + xlc[i] * 8;
+        } else {
+          r = ct;
+          s = xlc[i] >> 1;
+          coff = (xlc[i] & 1) * 8;
+        }
+        const int sh = hb + r, sw = wb + s;
+        const bool ok = inb && (unsigned)sh < (unsigned)a.H && (unsigned)sw < (unsigned)a.W;
+        const uint16_t* src = a.x + (((nbase + sh) * a.W + sw) * a.C + coff);
+        if (!ok) src = conv_zero_page + xlc[i] * 8;
+        glds16(src, lds_addr(stage + A_BYTES + t * X_BYTES + ((i * 4 + wave) * 8) * RB));
       }
-      const int sh = pp[i] * a.stride - a.pad + r, sw = pq[i] * a.stride - a.pad + s;
-      const bool ok = (pix0 + xrow[i] < a.M) && (unsigned)sh < (unsigned)a.H && (unsigned)sw < (unsigned)a.W;
-      const uint16_t* src = a.x + ((size_t)((pn[i] * a.H + sh) * a.W + sw) * a.C + coff);
-      if (!ok) src = conv_zero_page + xlc[i] * 8;
-      glds16(src, lds_addr(stage + A_BYTES + ((i * 4 + wave) * 8) * RB));
       // advance this row by one chunk (64 pixels)
       pq[i] += WG_PIX;
       while (pq[i] >= a.Q) {
@@ -317,11 +380,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
     }
   };
 
-  f32x4_t acc[MJ][NJ];
+  f32x4_t acc[MJ][NT * NJ];
 #pragma unroll
   for (int i = 0; i < MJ; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < NT * NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // transposed-read geometry: 16-lane group g, lane (q, p) inside it; MFMA k-slot (g, e) holds
   // pixel 4g + e (e < 4) or 16 + 4g + (e - 4) of the 32-pixel k-step — same map for both operands.
@@ -333,7 +396,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
       const int r0 = ks * 32 + 4 * tg + tq, r1 = r0 + 16;
-      bf16x8_t af[MJ], bfr[NJ];
+      bf16x8_t af[MJ];
 #pragma unroll
       for (int i = 0; i < MJ; ++i) {
         const int blk = (cout_w + i * 16) >> 4;
@@ -343,18 +406,23 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
         af[i] = __builtin_bit_cast(bf16x8_t, v);
       }
 #pragma unroll
-      for (int j = 0; j < NJ; ++j) {
-        const int blk = (col_w + j * 16) >> 4;
-        const s16x4_t lo = tr_read(buf + A_BYTES + r0 * RB + wg_swz<RB>(r0, blk) * 32 + 8 * tp);
-        const s16x4_t hi = tr_read(buf + A_BYTES + r1 * RB + wg_swz<RB>(r1, blk) * 32 + 8 * tp);
-        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-        bfr[j] = __builtin_bit_cast(bf16x8_t, v);
+      for (int t = 0; t < NT; ++t) {
+        const uint8_t* xb = buf + A_BYTES + t * X_BYTES;
+        bf16x8_t bfr[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const int blk = (col_w + j * 16) >> 4;
+          const s16x4_t lo = tr_read(xb + r0 * RB + wg_swz<RB>(r0, blk) * 32 + 8 * tp);
+          const s16x4_t hi = tr_read(xb + r1 * RB + wg_swz<RB>(r1, blk) * 32 + 8 * tp);
+          const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          bfr[j] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int i = 0; i < MJ; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][t * NJ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][t * NJ + j], 0, 0, 0);
       }
-#pragma unroll
-      for (int i = 0; i < MJ; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j)
-          acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   };
 
@@ -371,13 +439,15 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
 #pragma unroll
   for (int i = 0; i < MJ; ++i)
 #pragma unroll
-    for (int j = 0; j < NJ; ++j)
+    for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int kk = k0 + cout_w + i * 16 + fg * 4 + e;
-        const int col = ct * 64 + col_w + j * 16 + fr;
-        atomicAdd(a.dw + (size_t)kk * rsc + col, acc[i][j][e]);
-      }
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = k0 + cout_w + i * 16 + fg * 4 + e;
+          const int col = (ct0 + t) * 64 + col_w + j * 16 + fr;
+          atomicAdd(a.dw + (size_t)kk * rsc + col, acc[i][t * NJ + j][e]);
+        }
 }
 
 template <typename K>
@@ -387,40 +457,40 @@ int set_lds(K kernel, int bytes) {
   return e == hipSuccess ? WM_OK : (int)e;
 }
 
-template <int BN, int CPT, bool DGRAD>
+template <int BN, int CPT, int MODE>
 int launch_igemm(const ConvArgs& a, hipStream_t st) {
   constexpr int lds = 2 * (CV_BM * CV_ROW + BN * CV_ROW);
   static bool attr = false;
   if (!attr) {
-    const int rc = set_lds(&conv_igemm<BN, CPT, DGRAD>, lds);
+    const int rc = set_lds(&conv_igemm<BN, CPT, MODE>, lds);
     if (rc != WM_OK) return rc;
     attr = true;
   }
   dim3 grid(wm_cdiv(a.M, CV_BM), a.DC / BN);
-  conv_igemm<BN, CPT, DGRAD><<<grid, CV_THREADS, lds, st>>>(a);
+  conv_igemm<BN, CPT, MODE><<<grid, CV_THREADS, lds, st>>>(a);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
 
-template <int BMO, int CPT>
+template <int BMO, int CPT, int NT>
 int launch_wgrad(WgradArgs a, hipStream_t st) {
-  constexpr int lds = 2 * (WG_PIX * BMO * 2 + WG_PIX * 128);
+  constexpr int lds = 2 * (WG_PIX * BMO * 2 + NT * WG_PIX * 128);
   static bool attr = false;
   if (!attr) {
-    const int rc = set_lds(&conv_wgrad<BMO, CPT>, lds);
+    const int rc = set_lds(&conv_wgrad<BMO, CPT, NT>, lds);
     if (rc != WM_OK) return rc;
     attr = true;
   }
-  const int coltiles = a.R * a.S * a.C / 64;
+  const int colgroups = a.R * a.S * a.C / 64 / NT;
   const int ktiles = a.K / BMO;
   a.total_chunks = wm_cdiv(a.M, WG_PIX);
-  int nsplit = 2048 / (coltiles * ktiles);
+  int nsplit = (NT == 1 ? 2048 : 1536) / (colgroups * ktiles);
   if (nsplit < 1) nsplit = 1;
   if (nsplit > a.total_chunks) nsplit = a.total_chunks;
   a.chunks_per_split = wm_cdiv(a.total_chunks, nsplit);
   nsplit = wm_cdiv(a.total_chunks, a.chunks_per_split);
-  dim3 grid(coltiles, ktiles, nsplit);
-  conv_wgrad<BMO, CPT><<<grid, CV_THREADS, lds, st>>>(a);
+  dim3 grid(colgroups, ktiles, nsplit);
+  conv_wgrad<BMO, CPT, NT><<<grid, CV_THREADS, lds, st>>>(a);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -459,10 +529,10 @@ extern "C" int wm_conv2d_fwd(const void* x, const void* w_krsc, void* y, int N, 
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (C == 16) {
     a.nkt = R;
-    return K % 128 == 0 ? launch_igemm<128, 2, false>(a, st) : launch_igemm<64, 2, false>(a, st);
+    return K % 128 == 0 ? launch_igemm<128, 2, 0>(a, st) : launch_igemm<64, 2, 0>(a, st);
   }
   a.nkt = R * S * (C / 64);
-  return K % 128 == 0 ? launch_igemm<128, 8, false>(a, st) : launch_igemm<64, 8, false>(a, st);
+  return K % 128 == 0 ? launch_igemm<128, 8, 0>(a, st) : launch_igemm<64, 8, 0>(a, st);
 }
 
 extern "C" int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W,
@@ -481,7 +551,10 @@ extern "C" int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.M = N * H * W;
   a.nkt = R * S * (K / 64);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  return C % 128 == 0 ? launch_igemm<128, 8, true>(a, st) : launch_igemm<64, 8, true>(a, st);
+  // stride 2 with even image sides and class size % 128 == 0: parity-class ordering (no wasted taps)
+  if (stride == 2 && H % 2 == 0 && W % 2 == 0 && ((long long)N * (H / 2) * (W / 2)) % CV_BM == 0)
+    return C % 128 == 0 ? launch_igemm<128, 8, 2>(a, st) : launch_igemm<64, 8, 2>(a, st);
+  return C % 128 == 0 ? launch_igemm<128, 8, 1>(a, st) : launch_igemm<64, 8, 1>(a, st);
 }
 
 extern "C" int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_krsc, int N, int H, int W,
@@ -499,6 +572,11 @@ extern "C" int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_krsc, in
   a.stride = stride; a.pad = pad; a.M = N * P * Q;
   a.chunks_per_split = 0; a.total_chunks = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (C == 16) return K % 128 == 0 ? launch_wgrad<128, 2>(a, st) : launch_wgrad<64, 2>(a, st);
-  return K % 128 == 0 ? launch_wgrad<128, 8>(a, st) : launch_wgrad<64, 8>(a, st);
+  const int coltiles = R * S * C / 64;
+  if (C == 16) {  // stem: the 4 kernel rows together
+    if (K % 128 == 0) return coltiles % 2 == 0 ? launch_wgrad<128, 2, 2>(a, st) : launch_wgrad<128, 2, 1>(a, st);
+    return coltiles % 4 == 0 ? launch_wgrad<64, 2, 4>(a, st) : launch_wgrad<64, 2, 1>(a, st);
+  }
+  if (K % 128 == 0) return (coltiles % 2 == 0 && C > 128) ? launch_wgrad<128, 8, 2>(a, st) : launch_wgrad<128, 8, 1>(a, st);
+  return coltiles % 3 == 0 ? launch_wgrad<64, 8, 3>(a, st) : launch_wgrad<64, 8, 1>(a, st);
 }

@@ -26,6 +26,8 @@ CONVS = [
     (2, 128, 28, 28, 128, 3, 1, 1), (2, 128, 28, 28, 256, 3, 2, 1), (2, 128, 28, 28, 256, 1, 2, 0),
     (3, 256, 14, 14, 256, 3, 1, 1), (3, 256, 14, 14, 512, 3, 2, 1), (3, 256, 14, 14, 512, 1, 2, 0),
     (5, 512, 7, 7, 512, 3, 1, 1), (1, 64, 9, 11, 64, 3, 1, 1), (1, 128, 5, 7, 64, 3, 2, 1),
+    # stride-2 dgrad by parity class (needs N*(H/2)*(W/2) % 128 == 0)
+    (8, 64, 56, 56, 128, 3, 2, 1), (8, 64, 56, 56, 128, 1, 2, 0), (32, 128, 28, 28, 256, 3, 2, 1),
 ]
 
 
