@@ -102,6 +102,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--timer-every", type=int, default=10, help="bracket the conv launches on every n-th timed step")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
     args = ap.parse_args()
 
     import numpy as np
@@ -130,7 +131,7 @@ def main():
     sync = wdist.GradSync(opt)
     rng = np.random.default_rng(rank)
 
-    def step(i):
+    def eager_step(i):
         idx = (np.arange(B) + i * B) % len(ds)
         batch = ds.get_batch(idx, rng)
         opt.zero_grad()
@@ -141,6 +142,14 @@ def main():
         opt.step()
         return loss
 
+    graphed = None
+
+    def step(i):
+        # sampled steps (kernel timer on) run eagerly: timing events cannot be captured
+        if graphed is None or ops.TIMER is not None:
+            return eager_step(i)
+        return graphed.step((np.arange(B) + i * B) % len(ds), rng, sync)
+
     def fence():
         if world > 1:
             dist.barrier()
@@ -148,6 +157,16 @@ def main():
 
     for i in range(args.warmup):
         step(i)
+    if not args.no_graph:
+        try:
+            from ssl_wafermap_amd.graph import GraphedTrainStep
+
+            graphed = GraphedTrainStep(model, opt, ds, B).capture(np.arange(B), rng)
+            for i in range(2):
+                step(i)
+        except Exception as e:  # capture is an optimisation: report and continue eagerly
+            print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
+            graphed = None
     timer = None if args.no_kernel_timer else ops.KernelTimer()
     timed_steps = 0
     fence()
@@ -158,6 +177,7 @@ def main():
         timed_steps += int(sample)
         loss = step(args.warmup + i)
     ops.TIMER = None
+    host_dt = time.perf_counter() - t0  # time the host needed to enqueue the K steps (no sync yet)
     fence()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -191,9 +211,11 @@ def main():
             "config": {"workload": "SimCLR ResNet-18, 256 wafers/GPU/step, two 3x224x224 views, NT-Xent in-batch "
                                    "negatives, SGD (BASELINE.json configs[1])",
                        "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "hip_graph": graphed is not None,
                        "model_tflop_per_step_per_gpu": round(R18_GFLOP_PER_SAMPLE * B / 1e3, 3),
                        "model_mfma_frac": round(value / world * R18_GFLOP_PER_SAMPLE / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)},
             "final_loss": round(final_loss, 4),
+            "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3),
             "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:

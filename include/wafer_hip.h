@@ -180,15 +180,16 @@ int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_krsc, int N, int H,
 /* f32 OIHW master weights -> bf16 [K][R][S][C] and/or [C][R][S][K] (either may be NULL). */
 int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int S, void* w_krsc, void* w_crsk,
                        void* stream);
-/* wgrad accumulator [K][R][S][C] f32 -> OIHW gradient (= or +=). */
-int wm_wgrad_finalize(const float* dw_krsc, int K, int C, int R, int S, float* grad_oihw,
+/* wgrad accumulator [K][R][S][C] f32 -> OIHW gradient (= or +=); the accumulator is cleared as it
+ * is read, so a persistent one needs zeroing only once. */
+int wm_wgrad_finalize(float* dw_krsc, int K, int C, int R, int S, float* grad_oihw,
                       int accumulate, void* stream);
 /* The 7x7/2 pad-3 stem on 3 channels run as a 4x4/1 pad-2 convolution over the 2x2 space-to-depth
  * image [N][H/2][W/2][16] (channel (dh*2+dw)*3+c, 12 used): weights [K][3][7][7] f32 ->
  * [K][4][4][16] bf16, its gradient back, and the image transform (fmt WM_IMG_NCHW_F32 or
  * WM_IMG_NHWC_BF16 with 3 channels). */
 int wm_stem_weights_prepare(const float* w_oihw, int K, void* w_s2d, void* stream);
-int wm_stem_wgrad_finalize(const float* dw_s2d, int K, float* grad_oihw, int accumulate, void* stream);
+int wm_stem_wgrad_finalize(float* dw_s2d, int K, float* grad_oihw, int accumulate, void* stream);
 int wm_image_to_s2d(const void* img, int fmt, int N, int H, int W, void* out, void* stream);
 int wm_cast_f32_bf16(const float* x, long long n, void* y, void* stream);
 

@@ -30,7 +30,7 @@ __global__ void weights_prepare(const float* __restrict__ w, int K, int C, int R
   }
 }
 
-__global__ void wgrad_finalize(const float* __restrict__ ws, int K, int C, int R, int S,
+__global__ void wgrad_finalize(float* __restrict__ ws, int K, int C, int R, int S,
                                float* __restrict__ grad, int accumulate) {
   const long long total = (long long)K * C * R * S;
   for (long long t = (long long)blockIdx.x * LT_THREADS + threadIdx.x; t < total;
@@ -41,7 +41,9 @@ __global__ void wgrad_finalize(const float* __restrict__ ws, int K, int C, int R
     const int r = (int)(u % R);
     u /= R;
     const int c = (int)(u % C), k = (int)(u / C);
-    const float v = ws[(((size_t)k * R + r) * S + s) * C + c];
+    const size_t wi = (((size_t)k * R + r) * S + s) * C + c;
+    const float v = ws[wi];
+    ws[wi] = 0.f;  // read-and-clear: the accumulator is ready for the next step's atomics
     grad[t] = accumulate ? grad[t] + v : v;
   }
 }
@@ -61,13 +63,15 @@ __global__ void stem_weights_prepare(const float* __restrict__ w, int K, uint16_
   }
 }
 
-__global__ void stem_wgrad_finalize(const float* __restrict__ ws, int K, float* __restrict__ grad,
+__global__ void stem_wgrad_finalize(float* __restrict__ ws, int K, float* __restrict__ grad,
                                     int accumulate) {
   const int total = K * 147;
   for (int t = blockIdx.x * LT_THREADS + threadIdx.x; t < total; t += gridDim.x * LT_THREADS) {
     const int s = t % 7, r = (t / 7) % 7, c = (t / 49) % 3, k = t / 147;
     const int a = (r + 1) >> 1, dh = (r + 1) & 1, b = (s + 1) >> 1, dw = (s + 1) & 1;
-    const float v = ws[((k * 4 + a) * 4 + b) * 16 + (dh * 2 + dw) * 3 + c];
+    const int wi = ((k * 4 + a) * 4 + b) * 16 + (dh * 2 + dw) * 3 + c;
+    const float v = ws[wi];
+    ws[wi] = 0.f;  // read-and-clear (the 4 pad channels and the r' = 0 taps are never written)
     grad[t] = accumulate ? grad[t] + v : v;
   }
 }
@@ -139,7 +143,7 @@ extern "C" int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int 
   return WM_OK;
 }
 
-extern "C" int wm_wgrad_finalize(const float* dw_krsc, int K, int C, int R, int S, float* grad_oihw,
+extern "C" int wm_wgrad_finalize(float* dw_krsc, int K, int C, int R, int S, float* grad_oihw,
                                  int accumulate, void* stream) {
   WM_REQUIRE(dw_krsc && grad_oihw, WM_EINVAL);
   WM_REQUIRE(K > 0 && C > 0 && R > 0 && S > 0, WM_EINVAL);
@@ -157,7 +161,7 @@ extern "C" int wm_stem_weights_prepare(const float* w_oihw, int K, void* w_s2d, 
   return WM_OK;
 }
 
-extern "C" int wm_stem_wgrad_finalize(const float* dw_s2d, int K, float* grad_oihw, int accumulate,
+extern "C" int wm_stem_wgrad_finalize(float* dw_s2d, int K, float* grad_oihw, int accumulate,
                                       void* stream) {
   WM_REQUIRE(dw_s2d && grad_oihw && K > 0, WM_EINVAL);
   stem_wgrad_finalize<<<grid_for((long long)K * 147), LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(

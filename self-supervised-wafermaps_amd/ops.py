@@ -122,15 +122,19 @@ class _WeightCache:
             wd = w.detach()
             if not wd.is_contiguous():
                 wd = wd.contiguous()
+            old_k = ent[1] if ent is not None and ent[0][3] == kind else None   # reuse the buffers:
+            old_c = ent[2] if ent is not None and ent[0][3] == kind else None   # static addresses (graphs)
             if kind == "stem":
                 k = w.shape[0]
-                krsc = torch.empty((k, 4, 4, 16), dtype=torch.bfloat16, device=w.device)
+                krsc = old_k if old_k is not None else torch.empty((k, 4, 4, 16), dtype=torch.bfloat16, device=w.device)
                 check(lib.wm_stem_weights_prepare(ptr(wd), k, ptr(krsc), stream_ptr()), "wm_stem_weights_prepare")
                 crsk = None
             else:
                 k, c, r, s = w.shape if kind == "conv" else (w.shape[0], w.shape[1], 1, 1)
-                krsc = torch.empty((k, r, s, c), dtype=torch.bfloat16, device=w.device)
-                crsk = torch.empty((c, r, s, k), dtype=torch.bfloat16, device=w.device) if need_crsk else None
+                krsc = old_k if old_k is not None else torch.empty((k, r, s, c), dtype=torch.bfloat16, device=w.device)
+                need_crsk = need_crsk or old_c is not None
+                crsk = old_c if old_c is not None else (
+                    torch.empty((c, r, s, k), dtype=torch.bfloat16, device=w.device) if need_crsk else None)
                 check(lib.wm_weights_prepare(ptr(wd), k, c, r, s, ptr(krsc), ptr(crsk), stream_ptr()),
                       "wm_weights_prepare")
             ent = (tag, krsc, crsk)
@@ -139,6 +143,26 @@ class _WeightCache:
 
 
 _WCACHE = _WeightCache()
+
+
+def _wgrad_accumulator(weight: torch.Tensor, shape) -> torch.Tensor:
+    """Persistent f32 [K][R][S][C] accumulator of one parameter (zeroed once; wm_wgrad_finalize
+    clears it as it reads it)."""
+    ws = getattr(weight, "_hip_wgrad_ws", None)
+    if ws is None or tuple(ws.shape) != tuple(shape) or ws.device != weight.device:
+        ws = torch.zeros(shape, dtype=torch.float32, device=weight.device)
+        weight._hip_wgrad_ws = ws
+    return ws
+
+
+def _arena_grad(p: torch.Tensor):
+    """The parameter's gradient slot when a fused optimiser owns it (a view of the flat gradient
+    arena, zeroed by optimizer.zero_grad): backward kernels then accumulate straight into it and
+    autograd receives None, which skips one tiny AccumulateGrad add per parameter per step."""
+    g = p.grad
+    if g is not None and getattr(p, "_hip_arena_grad", False) and g.is_contiguous():
+        return g
+    return None
 
 
 def _out_hw(h, w, r, s, stride, pad):
@@ -179,11 +203,15 @@ class _Conv2d(torch.autograd.Function):
             check(_run("conv_dgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_dgrad, dy.data_ptr(), ptr(crsk),
                        dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_dgrad")
         if ctx.needs_input_grad[1]:
-            ws = torch.zeros((k, r, s, c), dtype=torch.float32, device=dy.device)
+            ws = _wgrad_accumulator(weight, (k, r, s, c))
             check(_run("conv_wgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_wgrad, dy.data_ptr(), x.data_ptr(),
                        ptr(ws), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_wgrad")
-            dw = torch.empty((k, c, r, s), dtype=torch.float32, device=dy.device)
-            check(lib.wm_wgrad_finalize(ptr(ws), k, c, r, s, ptr(dw), 0, stream_ptr()), "wm_wgrad_finalize")
+            slot = _arena_grad(weight)
+            if slot is not None:
+                check(lib.wm_wgrad_finalize(ptr(ws), k, c, r, s, ptr(slot), 1, stream_ptr()), "wm_wgrad_finalize")
+            else:
+                dw = torch.empty((k, c, r, s), dtype=torch.float32, device=dy.device)
+                check(lib.wm_wgrad_finalize(ptr(ws), k, c, r, s, ptr(dw), 0, stream_ptr()), "wm_wgrad_finalize")
         return dx, dw, None, None
 
 
@@ -219,6 +247,7 @@ class _StemConv(torch.autograd.Function):
         check(_run("conv_fwd", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_fwd, ptr(xs), ptr(ws2d), y.data_ptr(), n, h2, w2,
                    16, k, 4, 4, h2, w2, 1, 2, stream_ptr()), "wm_conv2d_fwd(stem)")
         ctx.save_for_backward(xs)
+        ctx.weight = weight
         ctx.geom = (n, h2, w2, k)
         return y
 
@@ -228,9 +257,13 @@ class _StemConv(torch.autograd.Function):
         n, h2, w2, k = ctx.geom
         dy = _as_nhwc(dy)
         lib = _lib.load()
-        ws = torch.zeros((k, 4, 4, 16), dtype=torch.float32, device=dy.device)
+        ws = _wgrad_accumulator(ctx.weight, (k, 4, 4, 16))
         check(_run("conv_wgrad", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_wgrad, dy.data_ptr(), ptr(xs), ptr(ws), n, h2,
                    w2, 16, k, 4, 4, h2, w2, 1, 2, stream_ptr()), "wm_conv2d_wgrad(stem)")
+        slot = _arena_grad(ctx.weight)
+        if slot is not None:
+            check(lib.wm_stem_wgrad_finalize(ptr(ws), k, ptr(slot), 1, stream_ptr()), "wm_stem_wgrad_finalize")
+            return None, None
         dw = torch.empty((k, 3, 7, 7), dtype=torch.float32, device=dy.device)
         check(lib.wm_stem_wgrad_finalize(ptr(ws), k, ptr(dw), 0, stream_ptr()), "wm_stem_wgrad_finalize")
         return None, dw
@@ -293,7 +326,8 @@ class _BatchNorm(torch.autograd.Function):
                                       ptr(running_mean), ptr(running_var), rows, c, groups, eps, momentum, int(relu),
                                       ptr(mean), ptr(invstd), out.data_ptr(), ptr(ws), ws.numel(), stream_ptr()),
                   "wm_bn_train_fwd")
-            ctx.save_for_backward(y, out if relu else None, gamma, mean, invstd)
+            ctx.save_for_backward(y, out if relu else None, mean, invstd)
+            ctx.affine = (gamma, beta)
             ctx.meta = (rows, c, groups, relu, residual is not None)
         else:
             check(lib.wm_bn_eval_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma), ptr(beta),
@@ -306,18 +340,23 @@ class _BatchNorm(torch.autograd.Function):
     def backward(ctx, dout):
         if ctx.meta is None:
             raise NotImplementedError("batch_norm: backward through eval-mode statistics is not implemented")
-        y, out, gamma, mean, invstd = ctx.saved_tensors
+        y, out, mean, invstd = ctx.saved_tensors
+        gamma, beta = ctx.affine
         rows, c, groups, relu, has_res = ctx.meta
         dout = _as_act(dout)
         lib = _lib.load()
         dy = torch.empty_like(y)
         dz = torch.empty_like(y) if has_res else None
-        dgamma = torch.empty((c,), dtype=torch.float32, device=y.device)
-        dbeta = torch.empty_like(dgamma)
+        sg, sb = _arena_grad(gamma), _arena_grad(beta)
+        direct = sg is not None and sb is not None
+        dgamma = sg if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
+        dbeta = sb if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
         ws = _bn_workspace(rows, c, groups, y.device)
         check(lib.wm_bn_train_bwd(y.data_ptr(), dout.data_ptr(), out.data_ptr() if relu else 0, ptr(gamma), ptr(mean),
-                                  ptr(invstd), rows, c, groups, ptr(dgamma), ptr(dbeta), 0, dy.data_ptr(),
+                                  ptr(invstd), rows, c, groups, ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(),
                                   dz.data_ptr() if has_res else 0, ptr(ws), ws.numel(), stream_ptr()), "wm_bn_train_bwd")
+        if direct:
+            return dy, dz, None, None, None, None, None, None, None, None, None
         return dy, dz, dgamma, dbeta, None, None, None, None, None, None, None
 
 
@@ -420,9 +459,11 @@ class _Linear(torch.autograd.Function):
             check(lib.wm_conv2d_dgrad(ptr(dy), ptr(crsk), ptr(dx), b, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
                   "wm_conv2d_dgrad(linear)")
         if ctx.needs_input_grad[1]:
-            dw = torch.zeros((k, c), dtype=torch.float32, device=dy.device)  # [K][1][1][C] == OIHW for 1x1
-            check(lib.wm_conv2d_wgrad(ptr(dy), ptr(x), ptr(dw), b, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
+            slot = _arena_grad(weight)  # [K][1][1][C] == [K][C]: the atomics can land in the arena itself
+            tgt = slot if slot is not None else torch.zeros((k, c), dtype=torch.float32, device=dy.device)
+            check(lib.wm_conv2d_wgrad(ptr(dy), ptr(x), ptr(tgt), b, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
                   "wm_conv2d_wgrad(linear)")
+            dw = None if slot is not None else tgt
         return dx, dw
 
 

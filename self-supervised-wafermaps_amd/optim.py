@@ -39,6 +39,7 @@ class _Arena:
                 self.params[o:o + n].copy_(p.detach().reshape(-1))
                 p.data = self.params[o:o + n].view(p.shape)
                 p.grad = self.grads[o:o + n].view(p.shape)
+                p._hip_arena_grad = True  # backward kernels may accumulate straight into p.grad
         self.offsets = offs
 
 

@@ -261,7 +261,7 @@ _FMT = {"nchw_f32": _lib.WM_IMG_NCHW_F32, "nhwc_bf16": _lib.WM_IMG_NHWC_BF16, "u
 def augment_views(store: WaferStore, params: np.ndarray, img_size: int = 224, out_size: int = 224,
                   fmt: str = "nchw_f32", normalize: bool = True, mean: float = NORMALIZE_STATS["mean"][0],
                   std: float = NORMALIZE_STATS["std"][0], n_slots: Optional[int] = None,
-                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+                  out: Optional[torch.Tensor] = None, params_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """Run the fused augmentation kernel for `len(params)` views.
 
     fmt "nchw_f32": float32 [n,3,O,O] (the reference's batch tensor);
@@ -284,12 +284,18 @@ def augment_views(store: WaferStore, params: np.ndarray, img_size: int = 224, ou
             out = torch.empty((n_slots, out_size, out_size), dtype=torch.uint8, device=dev)
         else:
             raise ValueError(f"unknown fmt {fmt}")
-    pbytes = torch.from_numpy(np.ascontiguousarray(params).view(np.uint8).reshape(-1))
-    pdev = pbytes.to(dev, non_blocking=False)
+    if params_dev is not None:
+        # caller-managed static device buffer (graph capture): it must already hold `params`
+        if params_dev.numel() * params_dev.element_size() < n * PARAM_DTYPE.itemsize or params_dev.device != dev:
+            raise ValueError("params_dev too small or on the wrong device")
+        pdev = params_dev
+    else:
+        pbytes = torch.from_numpy(np.ascontiguousarray(params).view(np.uint8).reshape(-1))
+        pdev = pbytes.to(dev, non_blocking=False)
     check(_lib.load().wm_augment_views(ptr(store.bytes), ptr(store.offsets), ptr(store.heights), ptr(store.widths),
                                        len(store), store.max_elems, ptr(pdev), n, img_size, out_size, _FMT[fmt],
                                        int(bool(normalize)), float(mean), float(std), out.data_ptr(), stream_ptr()),
           "wm_augment_views")
-    # pdev must outlive the launch: record it on the current stream
-    pdev.record_stream(torch.cuda.current_stream())
+    if params_dev is None:  # pdev must outlive the launch: record it on the current stream
+        pdev.record_stream(torch.cuda.current_stream())
     return out

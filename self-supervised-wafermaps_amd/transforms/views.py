@@ -27,31 +27,47 @@ class MultiViewTransform:
     def __init__(self, transforms: Sequence[ViewSpec]):
         self.transforms = list(transforms)
 
-    def __call__(self, store: WaferStore, sample_idx: np.ndarray, rng: np.random.Generator,
-                 fmt: str = "nhwc_bf16") -> Views:
-        n = len(sample_idx)
-        out = Views()
-        # consecutive views with the same geometry share a launch
-        i = 0
+    def groups(self):
+        """Runs of consecutive views that share a launch: [(first view, one past last)]."""
+        out, i = [], 0
         while i < len(self.transforms):
             spec = self.transforms[i]
+            key = (spec.img_size, spec.out_size, spec.normalize)
             j = i
             while j < len(self.transforms) and (self.transforms[j].img_size, self.transforms[j].out_size,
-                                                  self.transforms[j].normalize) == (spec.img_size, spec.out_size,
-                                                                                    spec.normalize):
+                                                  self.transforms[j].normalize) == key:
                 j += 1
-            params = np.concatenate([
-                sample_view_params(self.transforms[v], sample_idx, store.heights_np, store.widths_np, rng,
-                                   out_slot_base=(v - i) * n) for v in range(i, j)])
-            batch = augment_views(store, params, img_size=spec.img_size, out_size=spec.out_size, fmt=fmt,
-                                  normalize=spec.normalize, mean=NORMALIZE_STATS["mean"][0],
-                                  std=NORMALIZE_STATS["std"][0], n_slots=(j - i) * n)
-            for v in range(j - i):
-                out.append(batch[v * n:(v + 1) * n])
-            if i == 0 and j == len(self.transforms):
-                out.stacked = batch
+            out.append((i, j))
             i = j
         return out
+
+    def sample(self, store: WaferStore, sample_idx: np.ndarray, rng: np.random.Generator):
+        """Every random decision of the batch: one PARAM_DTYPE array per launch group."""
+        n = len(sample_idx)
+        return [np.concatenate([sample_view_params(self.transforms[v], sample_idx, store.heights_np, store.widths_np,
+                                                   rng, out_slot_base=(v - i) * n) for v in range(i, j)])
+                for i, j in self.groups()]
+
+    def launch(self, store: WaferStore, params_per_group, n: int, fmt: str = "nhwc_bf16", params_dev=None) -> Views:
+        """Run the kernels for already-sampled decisions.  `params_dev`: optional list of static
+        device buffers already holding the parameters (hipGraph capture)."""
+        out = Views()
+        groups = self.groups()
+        for gi, ((i, j), params) in enumerate(zip(groups, params_per_group)):
+            spec = self.transforms[i]
+            batch = augment_views(store, params, img_size=spec.img_size, out_size=spec.out_size, fmt=fmt,
+                                  normalize=spec.normalize, mean=NORMALIZE_STATS["mean"][0],
+                                  std=NORMALIZE_STATS["std"][0], n_slots=(j - i) * n,
+                                  params_dev=None if params_dev is None else params_dev[gi])
+            for v in range(j - i):
+                out.append(batch[v * n:(v + 1) * n])
+            if len(groups) == 1:
+                out.stacked = batch
+        return out
+
+    def __call__(self, store: WaferStore, sample_idx: np.ndarray, rng: np.random.Generator,
+                 fmt: str = "nhwc_bf16") -> Views:
+        return self.launch(store, self.sample(store, np.asarray(sample_idx), rng), len(sample_idx), fmt)
 
 
 class BaseViewTransform(MultiViewTransform):
