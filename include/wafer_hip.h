@@ -169,6 +169,13 @@ int wm_ntxent_bwd(const float* zn, const float* zall, const float* lse_all, int 
  * (the space-to-depth stem).  A Linear layer is the 1x1 convolution with H = W = P = Q = 1. */
 int wm_conv2d_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
                   int R, int S, int P, int Q, int stride, int pad, void* stream);
+/* The same convolution, also accumulating the per-channel (sum, sum of squares) of its bf16 outputs
+ * into stat_part [G][stat_buckets][2][K] f32 (G = N*P*Q / rows_per_group row groups; f32 atomics into
+ * bucket (tile % stat_buckets)); rows_per_group % 128 == 0.  stat_part must be zero on entry;
+ * wm_bn_train_fwd_from_stats clears it again as it reads it. */
+int wm_conv2d_fwd_stats(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
+                        int R, int S, int P, int Q, int stride, int pad, float* stat_part,
+                        int stat_buckets, int rows_per_group, void* stream);
 /* dx = conv_transpose(dy, w): w_crsk bf16 [C][R][S][K]; C % 64 == 0. */
 int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W, int C, int K,
                     int R, int S, int P, int Q, int stride, int pad, void* stream);
@@ -203,15 +210,23 @@ int wm_bn_train_fwd(const void* y, const void* residual, const float* gamma, con
                     float* running_mean, float* running_var, long long rows, int C, int G, float eps,
                     float momentum, int relu, float* save_mean, float* save_invstd, void* out,
                     void* workspace, size_t workspace_bytes, void* stream);
+/* Training forward whose statistics were accumulated by wm_conv2d_fwd_stats. */
+int wm_bn_train_fwd_from_stats(const void* y, const void* residual, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, long long rows, int C, int G,
+                               float eps, float momentum, int relu, float* save_mean, float* save_invstd,
+                               void* out, float* stat_part, int stat_buckets, void* workspace,
+                               size_t workspace_bytes, void* stream);
 int wm_bn_eval_fwd(const void* y, const void* residual, const float* gamma, const float* beta,
                    const float* running_mean, const float* running_var, long long rows, int C, float eps,
                    int relu, void* out, void* workspace, size_t workspace_bytes, void* stream);
-/* dz = dout * (out_relu > 0) (out_relu NULL: no ReLU); dy = dBN(dz); dgamma/dbeta (= or +=);
- * dz is also written when non-NULL (the gradient of the residual branch). */
-int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, const float* gamma,
-                    const float* save_mean, const float* save_invstd, long long rows, int C, int G,
-                    float* dgamma, float* dbeta, int accumulate, void* dy, void* dz, void* workspace,
-                    size_t workspace_bytes, void* stream);
+/* dz = dout * mask; dy = dBN(dz); dgamma/dbeta (= or +=); dz is also written when non-NULL (the
+ * gradient of the residual branch).  mask: (out_relu > 0) when out_relu is given; else, when
+ * relu_from_y != 0, recomputed from y as bf16(y*gamma*invstd + beta - mean*gamma*invstd) > 0 (valid
+ * for a ReLU'd BN without residual; saves reading its output); else no ReLU. */
+int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, int relu_from_y,
+                    const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
+                    long long rows, int C, int G, float* dgamma, float* dbeta, int accumulate, void* dy,
+                    void* dz, void* workspace, size_t workspace_bytes, void* stream);
 int wm_add_bf16(const void* a, const void* b, long long n, void* out, void* stream);
 
 /* MaxPool2d(3, stride 2, padding 1) with recorded window positions (uint8, first maximum in scan

@@ -33,12 +33,17 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
 
 // Two per-channel sums over a row range -> part[((g*nblk + blk)*2 + which)*C + c].
 // MODE 0: (sum y, sum y^2).  MODE 1: (sum dz, sum dz*xhat) with dz = dout*(out>0 | no mask).
+// MODE 1 with `out` NULL and gamma_m non-NULL: the ReLU mask is recomputed from y as
+// bf16(y*scale + shift) > 0 with scale = gamma*invstd, shift = beta - mean*scale (the forward's own
+// arithmetic), which saves reading `out` when the BN had no residual input.
 template <int MODE>
 __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restrict__ y,
                                                         const uint16_t* __restrict__ dout,
                                                         const uint16_t* __restrict__ out,
                                                         const float* __restrict__ mean,
                                                         const float* __restrict__ invstd,
+                                                        const float* __restrict__ gamma_m,
+                                                        const float* __restrict__ beta_m,
                                                         int rows_per_group, int C, int rows_per_block,
                                                         float* __restrict__ part) {
   extern __shared__ float red[];  // [2][rpp][C]
@@ -56,12 +61,18 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restri
   if (tpr <= BN_THREADS) {
     const int rpp = BN_THREADS / tpr;
     const int cidx = tid % tpr, rr = tid / tpr;
-    float mu[8], is[8];
+    float mu[8], is[8], msc[8], msh[8];
+    const bool remask = MODE == 1 && out == nullptr && gamma_m != nullptr;
     if (MODE == 1) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
         mu[e] = mean[(size_t)g * C + cidx * 8 + e];
         is[e] = invstd[(size_t)g * C + cidx * 8 + e];
+        msc[e] = msh[e] = 0.f;
+        if (remask) {
+          msc[e] = gamma_m[cidx * 8 + e] * is[e];
+          msh[e] = beta_m[cidx * 8 + e] - mu[e] * msc[e];
+        }
       }
     }
     if (rr < rpp) {
@@ -83,6 +94,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restri
             unpack8(*reinterpret_cast<const uint4*>(out + off), fo);
 #pragma unroll
             for (int e = 0; e < 8; ++e) fd[e] = fo[e] > 0.f ? fd[e] : 0.f;
+          } else if (remask) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) fd[e] = bf2f(f2bf(fmaf(fy[e], msc[e], msh[e]))) > 0.f ? fd[e] : 0.f;
           }
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -116,13 +130,20 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restri
 
 // Reduce the [nblk] partial sums of one (group, channel) pair: 32 lanes of a 1024-thread block
 // stride over the partials of 32 adjacent channels (128-byte coalesced rows), then combine in LDS.
-__device__ __forceinline__ void finalize_sums(const float* __restrict__ part, int nblk, int g, int C, int c,
-                                              int bl, int cl, double (*red)[32][33], double& s, double& ss) {
+__device__ __forceinline__ void finalize_sums(float* __restrict__ part, int nblk, int g, int C, int c,
+                                              int bl, int cl, double (*red)[32][33], double& s, double& ss,
+                                              bool clear = false) {
   double a = 0.0, b = 0.0;
   if (c < C) {
     for (int k = bl; k < nblk; k += 32) {
-      a += (double)part[((size_t)(g * nblk + k) * 2 + 0) * C + c];
-      b += (double)part[((size_t)(g * nblk + k) * 2 + 1) * C + c];
+      float* p0 = part + ((size_t)(g * nblk + k) * 2 + 0) * C + c;
+      float* p1 = part + ((size_t)(g * nblk + k) * 2 + 1) * C + c;
+      a += (double)*p0;
+      b += (double)*p1;
+      if (clear) {  // read-and-clear: the conv epilogue's atomics start from zero next step
+        *p0 = 0.f;
+        *p1 = 0.f;
+      }
     }
   }
   __syncthreads();  // previous group's readers are done with `red`
@@ -141,7 +162,7 @@ __device__ __forceinline__ void finalize_sums(const float* __restrict__ part, in
 
 // Forward finalize: grid = ceil(C/32) blocks of 1024 threads.
 __global__ __launch_bounds__(1024) void bn_fwd_finalize(
-    const float* __restrict__ part, int nblk, int G, int C, int rows_per_group,
+    float* __restrict__ part, int nblk, int G, int C, int rows_per_group, int clear,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean,
     float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
@@ -156,7 +177,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize(
   }
   for (int g = 0; g < G; ++g) {
     double s, ss;
-    finalize_sums(part, nblk, g, C, c, bl, cl, red, s, ss);
+    finalize_sums(part, nblk, g, C, c, bl, cl, red, s, ss, clear != 0);
     if (owner) {
       const double m = s / rows_per_group;
       double var = ss / rows_per_group - m * m;
@@ -231,11 +252,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply(const uint16_t* __restric
 }
 
 // Backward finalize: dgamma/dbeta and the per-(group, channel) coefficients of the apply pass.
-// coef[(g*5 + t)*C + c]: t = 0 mean, 1 invstd, 2 gamma*invstd, 3 s1/M, 4 s2/M.
+// coef[(g*7 + t)*C + c]: t = 0 mean, 1 invstd, 2 gamma*invstd, 3 s1/M, 4 s2/M, 5/6 scale/shift of the
+// forward (for the recomputed ReLU mask).
 __global__ __launch_bounds__(1024) void bn_bwd_finalize(
-    const float* __restrict__ part, int nblk, int G, int C, int rows_per_group,
-    const float* __restrict__ gamma, const float* __restrict__ mean, const float* __restrict__ invstd,
-    float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate, float* __restrict__ coef) {
+    float* __restrict__ part, int nblk, int G, int C, int rows_per_group,
+    const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
+    const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
+    float* __restrict__ coef) {
   __shared__ double red[2][32][33];
   const int bl = threadIdx.x >> 5, cl = threadIdx.x & 31;
   const int c = blockIdx.x * 32 + cl;
@@ -248,11 +271,15 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize(
       tb += s1;
       tg += s2;
       const float is = invstd[(size_t)g * C + c];
-      coef[((size_t)g * 5 + 0) * C + c] = mean[(size_t)g * C + c];
-      coef[((size_t)g * 5 + 1) * C + c] = is;
-      coef[((size_t)g * 5 + 2) * C + c] = (gamma ? gamma[c] : 1.f) * is;
-      coef[((size_t)g * 5 + 3) * C + c] = (float)(s1 / rows_per_group);
-      coef[((size_t)g * 5 + 4) * C + c] = (float)(s2 / rows_per_group);
+      const float mu = mean[(size_t)g * C + c];
+      const float sc = (gamma ? gamma[c] : 1.f) * is;
+      coef[((size_t)g * 7 + 0) * C + c] = mu;
+      coef[((size_t)g * 7 + 1) * C + c] = is;
+      coef[((size_t)g * 7 + 2) * C + c] = sc;
+      coef[((size_t)g * 7 + 3) * C + c] = (float)(s1 / rows_per_group);
+      coef[((size_t)g * 7 + 4) * C + c] = (float)(s2 / rows_per_group);
+      coef[((size_t)g * 7 + 5) * C + c] = sc;
+      coef[((size_t)g * 7 + 6) * C + c] = (beta ? beta[c] : 0.f) - mu * sc;
     }
   }
   if (owner) {
@@ -266,7 +293,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __res
                                                            const uint16_t* __restrict__ out,
                                                            const float* __restrict__ coef,
                                                            long long rows, int C, int rows_per_group,
-                                                           uint16_t* __restrict__ dy,
+                                                           int remask, uint16_t* __restrict__ dy,
                                                            uint16_t* __restrict__ dz) {
   const int cpr = C >> 3;
   const long long total = rows * cpr;
@@ -285,8 +312,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __res
 #pragma unroll
       for (int e = 0; e < 8; ++e) fd[e] = fo[e] > 0.f ? fd[e] : 0.f;
     }
+    const float* cf = coef + (size_t)g * 7 * C + c0;
+    if (!out && remask) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fd[e] = bf2f(f2bf(fmaf(fy[e], cf[5 * C + e], cf[6 * C + e]))) > 0.f ? fd[e] : 0.f;
+    }
     if (dz) *reinterpret_cast<uint4*>(dz + off) = pack8(fd);
-    const float* cf = coef + (size_t)g * 5 * C + c0;
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -339,8 +370,8 @@ int bn_shape_check(long long rows, int C, int G) {
 extern "C" size_t wm_bn_workspace_bytes(long long rows, int C, int G) {
   if (rows <= 0 || C <= 0 || G <= 0 || C % 8) return 0;
   const int nblk = reduce_blocks((int)(rows / G), C);
-  // partial sums + the 5 backward coefficient planes
-  return ((size_t)G * nblk * 2 * C + (size_t)G * 5 * C) * sizeof(float) + 256;
+  // partial sums + the 7 backward coefficient planes
+  return ((size_t)G * nblk * 2 * C + (size_t)G * 7 * C) * sizeof(float) + 256;
 }
 
 extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float* gamma,
@@ -360,15 +391,42 @@ extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float*
   float* shift = scale + (size_t)G * C;
   const int tpr = C >> 3, rpp = BN_THREADS / tpr;
   const size_t lds = (size_t)2 * rpp * C * sizeof(float);
-  bn_reduce<0><<<dim3(nblk, G), BN_THREADS, lds, st>>>(static_cast<const uint16_t*>(y), nullptr, nullptr,
-                                                       nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk), part);
+  bn_reduce<0><<<dim3(nblk, G), BN_THREADS, lds, st>>>(static_cast<const uint16_t*>(y), nullptr, nullptr, nullptr,
+                                                       nullptr, nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk), part);
   WM_LAUNCH_CHECK();
-  bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, beta, eps, momentum, running_mean,
+  bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, 0, gamma, beta, eps, momentum, running_mean,
                                                    running_var, save_mean, save_invstd, scale, shift);
   WM_LAUNCH_CHECK();
   bn_apply<<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(static_cast<const uint16_t*>(y),
                                                            static_cast<const uint16_t*>(residual), scale, shift,
                                                            rows, C, rpg, relu, static_cast<uint16_t*>(out));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+// Forward when the producing convolution already accumulated the statistics
+// (wm_conv2d_fwd_stats): finalize (and clear) stat_part [G][stat_buckets][2][C], then apply.
+extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, const float* gamma,
+                                          const float* beta, float* running_mean, float* running_var,
+                                          long long rows, int C, int G, float eps, float momentum, int relu,
+                                          float* save_mean, float* save_invstd, void* out, float* stat_part,
+                                          int stat_buckets, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+  WM_REQUIRE(y && out && save_mean && save_invstd && workspace && stat_part, WM_EINVAL);
+  WM_REQUIRE(stat_buckets > 0, WM_EINVAL);
+  const int rc = bn_shape_check(rows, C, G);
+  if (rc != WM_OK) return rc;
+  WM_REQUIRE(workspace_bytes >= (size_t)2 * G * C * sizeof(float), WM_EWORKSPACE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rpg = (int)(rows / G);
+  float* scale = static_cast<float*>(workspace);
+  float* shift = scale + (size_t)G * C;
+  bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(stat_part, stat_buckets, G, C, rpg, 1, gamma, beta, eps, momentum,
+                                                   running_mean, running_var, save_mean, save_invstd, scale, shift);
+  WM_LAUNCH_CHECK();
+  bn_apply<<<stream_grid(rows * (C >> 3)), BN_THREADS, 0, st>>>(static_cast<const uint16_t*>(y),
+                                                                static_cast<const uint16_t*>(residual), scale, shift,
+                                                                rows, C, rpg, relu, static_cast<uint16_t*>(out));
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -394,10 +452,11 @@ extern "C" int wm_bn_eval_fwd(const void* y, const void* residual, const float* 
   return WM_OK;
 }
 
-extern "C" int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, const float* gamma,
-                               const float* save_mean, const float* save_invstd, long long rows, int C,
-                               int G, float* dgamma, float* dbeta, int accumulate, void* dy, void* dz,
-                               void* workspace, size_t workspace_bytes, void* stream) {
+extern "C" int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, int relu_from_y,
+                               const float* gamma, const float* beta, const float* save_mean,
+                               const float* save_invstd, long long rows, int C, int G, float* dgamma,
+                               float* dbeta, int accumulate, void* dy, void* dz, void* workspace,
+                               size_t workspace_bytes, void* stream) {
   WM_REQUIRE(y && dout && save_mean && save_invstd && dy && workspace, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
   if (rc != WM_OK) return rc;
@@ -409,16 +468,18 @@ extern "C" int wm_bn_train_bwd(const void* y, const void* dout, const void* out_
   float* coef = part + (size_t)G * nblk * 2 * C;
   const int tpr = C >> 3, rpp = BN_THREADS / tpr;
   const size_t lds = (size_t)2 * rpp * C * sizeof(float);
+  const bool remask = relu_from_y && !out_relu;
+  WM_REQUIRE(!remask || (gamma && beta), WM_EINVAL);
   bn_reduce<1><<<dim3(nblk, G), BN_THREADS, lds, st>>>(
       static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
-      save_mean, save_invstd, rpg, C, wm_cdiv(rpg, nblk), part);
+      save_mean, save_invstd, remask ? gamma : nullptr, remask ? beta : nullptr, rpg, C, wm_cdiv(rpg, nblk), part);
   WM_LAUNCH_CHECK();
-  bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, save_mean, save_invstd, dgamma, dbeta,
-                                                   accumulate, coef);
+  bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, beta, save_mean, save_invstd, dgamma,
+                                                   dbeta, accumulate, coef);
   WM_LAUNCH_CHECK();
   bn_bwd_apply<<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
       static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
-      coef, rows, C, rpg, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz));
+      coef, rows, C, rpg, remask ? 1 : 0, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz));
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

@@ -42,6 +42,10 @@ struct ConvArgs {
   const uint16_t* wt;   // [DC][R][S][SC]
   uint16_t* dst;        // [N][DH][DW][DC]
   int N, SH, SW, SC, DH, DW, DC, R, S, stride, pad, M, nkt;
+  // optional fused BatchNorm statistics (forward only): per-channel (sum, sum of squares) of the
+  // bf16-rounded outputs, added into bucket (tile % stat_nb) of the tile's row group
+  float* stat;          // [G][stat_nb][2][DC] f32, or NULL
+  int stat_nb, stat_rpg;
 };
 
 // 128 zero bytes: the global_load_lds source of padded / out-of-range taps
@@ -57,26 +61,31 @@ __device__ __attribute__((aligned(256))) uint16_t conv_zero_page[128];
 // parity class (h&1, w&1): all 128 rows of a tile then share the set of taps that hit a source
 // pixel (r = r0 + 2 jr, s = s0 + 2 js), so only those k-tiles are executed — 9/4 instead of 9 per
 // pixel for 3x3, and three of four classes of the 1x1 downsample just store zeros.
-template <int BN, int CPT, int MODE>
+template <int BM, int BN, int CPT, int MODE>
 __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   constexpr bool DGRAD = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) uint8_t cv_smem[];
-  constexpr int A_BYTES = CV_BM * CV_ROW;
+  // BM x BN tile, 4 waves: 2 x 2 waves of 64 px x BN/2 ch for BM = 128; 4 x 1 waves of 64 px x BN ch
+  // for BM = 256 (measured no faster than 128 x 64 on the 64-channel layers: those are bound by the
+  // 9-fold re-read of the input through L2, not by MFMA issue; kept as a template option)
+  constexpr int WN = BM == 128 ? 2 : 1;
+  constexpr int A_BYTES = BM * CV_ROW;
   constexpr int B_BYTES = BN * CV_ROW;
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int NB = BN / 32;  // weight rows fetched per thread
-  constexpr int NJ = BN / 32;  // 16-channel fragments per wave (a wave owns BN/2 channels)
+  constexpr int NR = BM / 32;          // pixel rows fetched per thread
+  constexpr int NB = BN / 32;          // weight rows fetched per thread
+  constexpr int NJ = BN / WN / 16;     // 16-channel fragments per wave
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * CV_BM, n0 = blockIdx.y * BN;
+  const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
+  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
   const int rowl = tid >> 3;                   // rows rowl + 32 i; (rowl + 32 i) & 7 == rowl & 7
   const int chunk = (tid & 7) ^ (rowl & 7);    // logical 16-byte chunk this lane fetches
 
-  int bh[4], bw[4], nb[4];
-  bool mv[4];
-  const uint16_t* p0[4];
+  int bh[NR], bw[NR], nb[NR];
+  bool mv[NR];
+  const uint16_t* p0[NR];
   const int dhw = a.DH * a.DW;
   // MODE 2: parity class of this tile and its valid-tap grid
   int r0 = 0, s0 = 0, nr = 0, ns = 0, nkt = a.nkt;
@@ -91,7 +100,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
     nkt = nr * ns * (a.SC >> 6);
     const int h2w2 = (a.DH >> 1) * (a.DW >> 1);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const int m = m0 + rowl + 32 * i - pc * cls;  // index inside the class
       mv[i] = true;                                   // class size % 128 == 0 (host-checked)
       const int n = m / h2w2, rem = m - n * h2w2;
@@ -104,7 +113,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
     }
   } else {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
       const int m = m0 + rowl + 32 * i;
       mv[i] = m < a.M;
       const int mm = mv[i] ? m : 0;
@@ -139,7 +148,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
       s = js;
       koff = (long long)(-jr * a.SW - js) * a.SC + c0;
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
+      for (int i = 0; i < NR; ++i) {
         const int sh = bh[i] - jr, sw = bw[i] - js;
         const bool ok = (unsigned)sh < (unsigned)a.SH && (unsigned)sw < (unsigned)a.SW;
         const uint16_t* src = ok ? p0[i] + koff : conv_zero_page + chunk * 8;
@@ -164,7 +173,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
       koff = (long long)r * a.SW * a.SC;
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < NR; ++i) {
       bool ok = mv[i];
       const uint16_t* src;
       if constexpr (!DGRAD) {
@@ -212,7 +221,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
       }
 #pragma unroll
       for (int j = 0; j < NJ; ++j) {
-        const int row = wn * (BN / 2) + j * 16 + fr;
+        const int row = wn * (BN / WN) + j * 16 + fr;
         wf[j] = *reinterpret_cast<const bf16x8_t*>(buf + A_BYTES + row * CV_ROW + ((c ^ (row & 7)) << 4));
       }
 #pragma unroll
@@ -239,13 +248,33 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int pix = wm * 64 + i * 16 + fr;
-      const int ch = wn * (BN / 2) + j * 16 + fg * 4;
+      const int ch = wn * (BN / WN) + j * 16 + fg * 4;
       const uint2 v = make_uint2(pack_bf2(acc[j][i][0], acc[j][i][1]), pack_bf2(acc[j][i][2], acc[j][i][3]));
       *reinterpret_cast<uint2*>(cv_smem + pix * CS + ch * 2) = v;
     }
   __syncthreads();
+  if constexpr (MODE == 0) {
+    if (a.stat != nullptr) {
+      // column sums of the staged tile: BN channels x (256/BN) row slices; rows_per_group % BM == 0,
+      // so the whole tile belongs to one statistics group
+      constexpr int TPC = CV_THREADS / BN;
+      const int c = tid % BN, part = tid / BN;
+      float sm = 0.f, sq = 0.f;
+      for (int rr = part * (BM / TPC); rr < (part + 1) * (BM / TPC); ++rr) {
+        if (m0 + rr < a.M) {
+          const float v = bf2f(*reinterpret_cast<const uint16_t*>(cv_smem + rr * CS + c * 2));
+          sm += v;
+          sq = fmaf(v, v, sq);
+        }
+      }
+      const int g = m0 / a.stat_rpg;
+      float* base = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 2) * a.DC + n0 + c;
+      atomicAdd(base, sm);
+      atomicAdd(base + a.DC, sq);
+    }
+  }
   constexpr int CPR = BN / 8;
-  for (int p = tid; p < CV_BM * CPR; p += CV_THREADS) {
+  for (int p = tid; p < BM * CPR; p += CV_THREADS) {
     const int row = p / CPR, ch = p - row * CPR;
     size_t pix = (size_t)(m0 + row);
     if constexpr (MODE == 2) {  // class-ordered row -> pixel (n, 2 h2 + ph, 2 w2 + pw)
@@ -457,17 +486,17 @@ int set_lds(K kernel, int bytes) {
   return e == hipSuccess ? WM_OK : (int)e;
 }
 
-template <int BN, int CPT, int MODE>
+template <int BM, int BN, int CPT, int MODE>
 int launch_igemm(const ConvArgs& a, hipStream_t st) {
-  constexpr int lds = 2 * (CV_BM * CV_ROW + BN * CV_ROW);
+  constexpr int lds = 2 * (BM * CV_ROW + BN * CV_ROW);
   static bool attr = false;
   if (!attr) {
-    const int rc = set_lds(&conv_igemm<BN, CPT, MODE>, lds);
+    const int rc = set_lds(&conv_igemm<BM, BN, CPT, MODE>, lds);
     if (rc != WM_OK) return rc;
     attr = true;
   }
-  dim3 grid(wm_cdiv(a.M, CV_BM), a.DC / BN);
-  conv_igemm<BN, CPT, MODE><<<grid, CV_THREADS, lds, st>>>(a);
+  dim3 grid(wm_cdiv(a.M, BM), a.DC / BN);
+  conv_igemm<BM, BN, CPT, MODE><<<grid, CV_THREADS, lds, st>>>(a);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -514,8 +543,27 @@ static int conv_check(int N, int H, int W, int C, int K, int R, int S, int P, in
   return WM_OK;
 }
 
+static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int R,
+                         int S, int P, int Q, int stride, int pad, float* stat, int stat_nb, int stat_rpg,
+                         void* stream);
+
 extern "C" int wm_conv2d_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C,
                              int K, int R, int S, int P, int Q, int stride, int pad, void* stream) {
+  return conv_fwd_impl(x, w_krsc, y, N, H, W, C, K, R, S, P, Q, stride, pad, nullptr, 0, 0, stream);
+}
+
+extern "C" int wm_conv2d_fwd_stats(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C,
+                                   int K, int R, int S, int P, int Q, int stride, int pad, float* stat_part,
+                                   int stat_buckets, int rows_per_group, void* stream) {
+  WM_REQUIRE(stat_part && stat_buckets > 0 && rows_per_group > 0, WM_EINVAL);
+  WM_REQUIRE(rows_per_group % 128 == 0 && ((long long)N * P * Q) % rows_per_group == 0, WM_EUNSUPPORTED);
+  return conv_fwd_impl(x, w_krsc, y, N, H, W, C, K, R, S, P, Q, stride, pad, stat_part, stat_buckets,
+                       rows_per_group, stream);
+}
+
+static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int R,
+                         int S, int P, int Q, int stride, int pad, float* stat, int stat_nb, int stat_rpg,
+                         void* stream) {
   WM_REQUIRE(x && w_krsc && y, WM_EINVAL);
   const int rc = conv_check(N, H, W, C, K, R, S, P, Q, stride, pad);
   if (rc != WM_OK) return rc;
@@ -526,13 +574,14 @@ extern "C" int wm_conv2d_fwd(const void* x, const void* w_krsc, void* y, int N, 
   a.dst = static_cast<uint16_t*>(y);
   a.N = N; a.SH = H; a.SW = W; a.SC = C; a.DH = P; a.DW = Q; a.DC = K;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.M = N * P * Q;
+  a.stat = stat; a.stat_nb = stat_nb; a.stat_rpg = stat_rpg;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (C == 16) {
     a.nkt = R;
-    return K % 128 == 0 ? launch_igemm<128, 2, 0>(a, st) : launch_igemm<64, 2, 0>(a, st);
+    return K % 128 == 0 ? launch_igemm<128, 128, 2, 0>(a, st) : launch_igemm<128, 64, 2, 0>(a, st);
   }
   a.nkt = R * S * (C / 64);
-  return K % 128 == 0 ? launch_igemm<128, 8, 0>(a, st) : launch_igemm<64, 8, 0>(a, st);
+  return K % 128 == 0 ? launch_igemm<128, 128, 8, 0>(a, st) : launch_igemm<128, 64, 8, 0>(a, st);
 }
 
 extern "C" int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W,
@@ -549,12 +598,16 @@ extern "C" int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int
   a.dst = static_cast<uint16_t*>(dx);
   a.N = N; a.SH = P; a.SW = Q; a.SC = K; a.DH = H; a.DW = W; a.DC = C;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.M = N * H * W;
+  a.stat = nullptr; a.stat_nb = 0; a.stat_rpg = 1;
   a.nkt = R * S * (K / 64);
   hipStream_t st = static_cast<hipStream_t>(stream);
   // stride 2 with even image sides and class size % 128 == 0: parity-class ordering (no wasted taps)
-  if (stride == 2 && H % 2 == 0 && W % 2 == 0 && ((long long)N * (H / 2) * (W / 2)) % CV_BM == 0)
-    return C % 128 == 0 ? launch_igemm<128, 8, 2>(a, st) : launch_igemm<64, 8, 2>(a, st);
-  return C % 128 == 0 ? launch_igemm<128, 8, 1>(a, st) : launch_igemm<64, 8, 1>(a, st);
+  const long long cls = (long long)N * (H / 2) * (W / 2);
+  if (stride == 2 && H % 2 == 0 && W % 2 == 0) {
+    if (C % 128 == 0 && cls % 128 == 0) return launch_igemm<128, 128, 8, 2>(a, st);
+    if (C % 128 != 0 && cls % 128 == 0) return launch_igemm<128, 64, 8, 2>(a, st);
+  }
+  return C % 128 == 0 ? launch_igemm<128, 128, 8, 1>(a, st) : launch_igemm<128, 64, 8, 1>(a, st);
 }
 
 extern "C" int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_krsc, int N, int H, int W,

@@ -10,6 +10,16 @@ from .. import nn as hnn
 from .. import ops
 
 
+def conv_bn(conv, bn, x, relu=False, residual=None):
+    """conv -> BatchNorm (+residual) (+ReLU); in training the convolution's epilogue accumulates the
+    BN statistics so the tensor is not re-read for them."""
+    if bn.training:
+        g = ops.current_bn_groups()
+        st = bn.stats_buffer(g)
+        return bn(conv(x, stats=st, groups=g), residual=residual, relu=relu, stats=st)
+    return bn(conv(x), residual=residual, relu=relu)
+
+
 class BasicBlock(nn.Module):
     expansion = 1
 
@@ -26,11 +36,10 @@ class BasicBlock(nn.Module):
 
     def forward(self, x):
         shortcut = x
-        out = self.bn1(self.conv1(x), relu=True)
-        out = self.conv2(out)
+        out = conv_bn(self.conv1, self.bn1, x, relu=True)
         if self.downsample is not None:
-            shortcut = self.downsample[1](self.downsample[0](x))
-        return self.bn2(out, residual=shortcut, relu=True)
+            shortcut = conv_bn(self.downsample[0], self.downsample[1], x)
+        return conv_bn(self.conv2, self.bn2, out, relu=True, residual=shortcut)
 
 
 class ResNet18(nn.Module):
@@ -48,7 +57,7 @@ class ResNet18(nn.Module):
         self.layer4 = nn.Sequential(BasicBlock(256, 512, 2), BasicBlock(512, 512))
 
     def forward_features(self, x):
-        x = self.bn1(self.conv1(x), relu=True)
+        x = conv_bn(self.conv1, self.bn1, x, relu=True)
         x = ops.max_pool3x3s2(x)
         x = self.layer1(x)
         x = self.layer2(x)

@@ -19,8 +19,8 @@ class Conv2d(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")  # timm resnet init
 
-    def forward(self, x):
-        return ops.conv2d(x, self.weight, self.stride, self.padding)
+    def forward(self, x, stats=None, groups=1):
+        return ops.conv2d(x, self.weight, self.stride, self.padding, stats=stats, groups=groups)
 
 
 class StemConv(Conv2d):
@@ -29,8 +29,8 @@ class StemConv(Conv2d):
     def __init__(self, out_channels=64):
         super().__init__(3, out_channels, 7, 2, 3)
 
-    def forward(self, x):
-        return ops.stem_conv(x, self.weight)
+    def forward(self, x, stats=None, groups=1):
+        return ops.stem_conv(x, self.weight, stats=stats, groups=groups)
 
 
 class _BatchNorm(nn.Module):
@@ -43,11 +43,21 @@ class _BatchNorm(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def forward(self, x, residual=None, relu=False):
+    def stats_buffer(self, groups: int):
+        """Persistent zeroed [groups, STAT_BUCKETS, 2, C] buffer for statistics fused into the producing
+        convolution's epilogue (the BN finalize kernel clears it again as it reads it)."""
+        buf = getattr(self, "_stat_buf", None)
+        if buf is None or buf.shape[0] != groups or buf.device != self.weight.device:
+            buf = torch.zeros((groups, ops.STAT_BUCKETS, 2, self.num_features), dtype=torch.float32,
+                              device=self.weight.device)
+            self._stat_buf = buf
+        return buf
+
+    def forward(self, x, residual=None, relu=False, stats=None):
         if self.training:
             self.num_batches_tracked += ops.current_bn_groups()
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                              residual=residual, relu=relu, eps=self.eps, momentum=self.momentum)
+                              residual=residual, relu=relu, eps=self.eps, momentum=self.momentum, stats=stats)
 
 
 class BatchNorm2d(_BatchNorm):

@@ -165,13 +165,22 @@ def _arena_grad(p: torch.Tensor):
     return None
 
 
+STAT_BUCKETS = 64  # partial-sum buckets per statistics group in the fused conv epilogue
+
+
+def stats_fusable(rows: int, groups: int) -> bool:
+    """The conv epilogue can accumulate BatchNorm statistics when every 128-row tile lies inside one
+    statistics group."""
+    return groups > 0 and rows % groups == 0 and (rows // groups) % 128 == 0
+
+
 def _out_hw(h, w, r, s, stride, pad):
     return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
 
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, stride, pad):
+    def forward(ctx, x, weight, stride, pad, stats=None, groups=1):
         _need_cuda(x, "conv2d")
         x = _as_nhwc(x)
         n, c, h, w = x.shape
@@ -182,8 +191,13 @@ class _Conv2d(torch.autograd.Function):
         train = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
         krsc, _ = _WCACHE.get(weight, need_crsk=train and x.requires_grad)
         y = _empty_nhwc(n, k, p, q, x.device)
-        check(_run("conv_fwd", 2.0 * n * p * q * k * r * s * c, _lib.load().wm_conv2d_fwd, ptr(x), ptr(krsc),
-                   y.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_fwd")
+        if stats is not None and stats_fusable(n * p * q, groups):
+            check(_run("conv_fwd", 2.0 * n * p * q * k * r * s * c, _lib.load().wm_conv2d_fwd_stats, ptr(x), ptr(krsc),
+                       y.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, ptr(stats), STAT_BUCKETS,
+                       n * p * q // groups, stream_ptr()), "wm_conv2d_fwd_stats")
+        else:
+            check(_run("conv_fwd", 2.0 * n * p * q * k * r * s * c, _lib.load().wm_conv2d_fwd, ptr(x), ptr(krsc),
+                       y.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_fwd")
         ctx.save_for_backward(x)
         ctx.weight = weight
         ctx.geom = (n, h, w, c, k, r, s, p, q, stride, pad)
@@ -212,12 +226,15 @@ class _Conv2d(torch.autograd.Function):
             else:
                 dw = torch.empty((k, c, r, s), dtype=torch.float32, device=dy.device)
                 check(lib.wm_wgrad_finalize(ptr(ws), k, c, r, s, ptr(dw), 0, stream_ptr()), "wm_wgrad_finalize")
-        return dx, dw, None, None
+        return dx, dw, None, None, None, None
 
 
-def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0) -> torch.Tensor:
-    """bias-free conv2d; x bf16 NHWC (converted if not), weight float32 [K, C, R, S]."""
-    return _Conv2d.apply(x, weight, int(stride), int(padding))
+def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0,
+           stats: Optional[torch.Tensor] = None, groups: int = 1) -> torch.Tensor:
+    """bias-free conv2d; x bf16 NHWC (converted if not), weight float32 [K, C, R, S].
+    `stats`: zeroed float32 [groups, STAT_BUCKETS, 2, K] buffer into which the epilogue accumulates the
+    BatchNorm statistics of the output (used when `stats_fusable(rows, groups)`)."""
+    return _Conv2d.apply(x, weight, int(stride), int(padding), stats, int(groups))
 
 
 class _StemConv(torch.autograd.Function):
@@ -225,7 +242,7 @@ class _StemConv(torch.autograd.Function):
     space-to-depth image (16 channels, 12 used) so every reduction tile is 128 contiguous bytes."""
 
     @staticmethod
-    def forward(ctx, x, weight):
+    def forward(ctx, x, weight, stats=None, groups=1):
         _need_cuda(x, "stem_conv")
         n, c, h, w = x.shape
         k = weight.shape[0]
@@ -244,8 +261,13 @@ class _StemConv(torch.autograd.Function):
         check(lib.wm_image_to_s2d(x.data_ptr(), fmt, n, h, w, ptr(xs), stream_ptr()), "wm_image_to_s2d")
         ws2d, _ = _WCACHE.get(weight, kind="stem")
         y = _empty_nhwc(n, k, h2, w2, x.device)
-        check(_run("conv_fwd", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_fwd, ptr(xs), ptr(ws2d), y.data_ptr(), n, h2, w2,
-                   16, k, 4, 4, h2, w2, 1, 2, stream_ptr()), "wm_conv2d_fwd(stem)")
+        if stats is not None and stats_fusable(n * h2 * w2, groups):
+            check(_run("conv_fwd", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_fwd_stats, ptr(xs), ptr(ws2d), y.data_ptr(),
+                       n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2, ptr(stats), STAT_BUCKETS, n * h2 * w2 // groups,
+                       stream_ptr()), "wm_conv2d_fwd_stats(stem)")
+        else:
+            check(_run("conv_fwd", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_fwd, ptr(xs), ptr(ws2d), y.data_ptr(), n, h2,
+                       w2, 16, k, 4, 4, h2, w2, 1, 2, stream_ptr()), "wm_conv2d_fwd(stem)")
         ctx.save_for_backward(xs)
         ctx.weight = weight
         ctx.geom = (n, h2, w2, k)
@@ -263,14 +285,14 @@ class _StemConv(torch.autograd.Function):
         slot = _arena_grad(ctx.weight)
         if slot is not None:
             check(lib.wm_stem_wgrad_finalize(ptr(ws), k, ptr(slot), 1, stream_ptr()), "wm_stem_wgrad_finalize")
-            return None, None
+            return None, None, None, None
         dw = torch.empty((k, 3, 7, 7), dtype=torch.float32, device=dy.device)
         check(lib.wm_stem_wgrad_finalize(ptr(ws), k, ptr(dw), 0, stream_ptr()), "wm_stem_wgrad_finalize")
-        return None, dw
+        return None, dw, None, None
 
 
-def stem_conv(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-    return _StemConv.apply(x, weight)
+def stem_conv(x: torch.Tensor, weight: torch.Tensor, stats: Optional[torch.Tensor] = None, groups: int = 1) -> torch.Tensor:
+    return _StemConv.apply(x, weight, stats, int(groups))
 
 
 _BN_WS = {}
@@ -306,7 +328,8 @@ def _as_act(x: torch.Tensor) -> torch.Tensor:
 
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, y, residual, gamma, beta, running_mean, running_var, training, groups, eps, momentum, relu):
+    def forward(ctx, y, residual, gamma, beta, running_mean, running_var, training, groups, eps, momentum, relu,
+                stats=None):
         _need_cuda(y, "batch_norm")
         y = _as_act(y)
         if residual is not None:
@@ -322,13 +345,22 @@ class _BatchNorm(torch.autograd.Function):
                 raise ValueError("batch_norm: rows not divisible by groups")
             mean = torch.empty((groups, c), dtype=torch.float32, device=y.device)
             invstd = torch.empty_like(mean)
-            check(lib.wm_bn_train_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma), ptr(beta),
-                                      ptr(running_mean), ptr(running_var), rows, c, groups, eps, momentum, int(relu),
-                                      ptr(mean), ptr(invstd), out.data_ptr(), ptr(ws), ws.numel(), stream_ptr()),
-                  "wm_bn_train_fwd")
-            ctx.save_for_backward(y, out if relu else None, mean, invstd)
+            if stats is not None and stats_fusable(rows, groups):
+                check(lib.wm_bn_train_fwd_from_stats(y.data_ptr(), ptr(residual) if residual is not None else 0,
+                                                     ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), rows, c,
+                                                     groups, eps, momentum, int(relu), ptr(mean), ptr(invstd),
+                                                     out.data_ptr(), ptr(stats), STAT_BUCKETS, ptr(ws), ws.numel(),
+                                                     stream_ptr()), "wm_bn_train_fwd_from_stats")
+            else:
+                check(lib.wm_bn_train_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma),
+                                          ptr(beta), ptr(running_mean), ptr(running_var), rows, c, groups, eps, momentum,
+                                          int(relu), ptr(mean), ptr(invstd), out.data_ptr(), ptr(ws), ws.numel(),
+                                          stream_ptr()), "wm_bn_train_fwd")
+            # a ReLU'd BN without residual recomputes its mask from y in the backward: `out` is not needed
+            mask_from_y = relu and residual is None and gamma is not None and beta is not None
+            ctx.save_for_backward(y, out if (relu and not mask_from_y) else None, mean, invstd)
             ctx.affine = (gamma, beta)
-            ctx.meta = (rows, c, groups, relu, residual is not None)
+            ctx.meta = (rows, c, groups, relu, residual is not None, mask_from_y)
         else:
             check(lib.wm_bn_eval_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma), ptr(beta),
                                      ptr(running_mean), ptr(running_var), rows, c, eps, int(relu), out.data_ptr(),
@@ -342,7 +374,7 @@ class _BatchNorm(torch.autograd.Function):
             raise NotImplementedError("batch_norm: backward through eval-mode statistics is not implemented")
         y, out, mean, invstd = ctx.saved_tensors
         gamma, beta = ctx.affine
-        rows, c, groups, relu, has_res = ctx.meta
+        rows, c, groups, relu, has_res, mask_from_y = ctx.meta
         dout = _as_act(dout)
         lib = _lib.load()
         dy = torch.empty_like(y)
@@ -352,20 +384,22 @@ class _BatchNorm(torch.autograd.Function):
         dgamma = sg if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
         dbeta = sb if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
         ws = _bn_workspace(rows, c, groups, y.device)
-        check(lib.wm_bn_train_bwd(y.data_ptr(), dout.data_ptr(), out.data_ptr() if relu else 0, ptr(gamma), ptr(mean),
-                                  ptr(invstd), rows, c, groups, ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(),
-                                  dz.data_ptr() if has_res else 0, ptr(ws), ws.numel(), stream_ptr()), "wm_bn_train_bwd")
+        check(lib.wm_bn_train_bwd(y.data_ptr(), dout.data_ptr(), out.data_ptr() if (relu and not mask_from_y) else 0,
+                                  int(mask_from_y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), rows, c, groups,
+                                  ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(), dz.data_ptr() if has_res else 0,
+                                  ptr(ws), ws.numel(), stream_ptr()), "wm_bn_train_bwd")
         if direct:
-            return dy, dz, None, None, None, None, None, None, None, None, None
-        return dy, dz, dgamma, dbeta, None, None, None, None, None, None, None
+            return dy, dz, None, None, None, None, None, None, None, None, None, None
+        return dy, dz, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def batch_norm(y, gamma, beta, running_mean, running_var, training: bool, residual=None, relu: bool = False,
-               eps: float = 1e-5, momentum: float = 0.1, groups: Optional[int] = None):
-    """out = relu?(BN(y) (+ residual)) on bf16 [N,C,H,W] (NHWC) or [B,C]."""
+               eps: float = 1e-5, momentum: float = 0.1, groups: Optional[int] = None, stats=None):
+    """out = relu?(BN(y) (+ residual)) on bf16 [N,C,H,W] (NHWC) or [B,C].  `stats`: the buffer the
+    producing conv2d(..., stats=) accumulated into (same `groups`)."""
     g = current_bn_groups() if groups is None else groups
     return _BatchNorm.apply(y, residual, gamma, beta, running_mean, running_var, bool(training), int(g), float(eps),
-                            float(momentum), bool(relu))
+                            float(momentum), bool(relu), stats)
 
 
 class _MaxPool(torch.autograd.Function):

@@ -258,3 +258,29 @@ def test_resnet18_forward_backward_matches_oracle():
     # running statistics were updated twice (two groups), as two reference forwards do
     torch.testing.assert_close(backbone.bn1.running_mean.cpu(), params["backbone.bn1.running_mean"], atol=2e-3, rtol=2e-2)
     assert int(backbone.bn1.num_batches_tracked) == 2
+
+
+def test_conv_bn_fused_statistics_match_unfused():
+    """conv epilogue statistics + finalize-from-stats == separate statistics pass; and the buffer is
+    clean again afterwards (read-and-clear)."""
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    x = ops.to_nhwc_bf16(torch.randn(8, 64, 16, 16, generator=g).to(DEV))
+    w = (torch.randn(128, 64, 3, 3, generator=g) * 0.05).to(DEV)
+    gamma, beta = (torch.rand(128, generator=g) + 0.5).to(DEV), (torch.randn(128, generator=g) * 0.1).to(DEV)
+    groups = 2
+    assert ops.stats_fusable(8 * 16 * 16, groups)
+    st = torch.zeros(groups, ops.STAT_BUCKETS, 2, 128, device=DEV)
+    rm1, rv1 = torch.zeros(128, device=DEV), torch.ones(128, device=DEV)
+    rm2, rv2 = torch.zeros(128, device=DEV), torch.ones(128, device=DEV)
+    y1 = ops.conv2d(x, w, 1, 1, stats=st, groups=groups)
+    assert float(st.abs().sum()) > 0
+    o1 = ops.batch_norm(y1, gamma, beta, rm1, rv1, True, relu=True, groups=groups, stats=st)
+    assert float(st.abs().sum()) == 0.0
+    y2 = ops.conv2d(x, w, 1, 1)
+    o2 = ops.batch_norm(y2, gamma, beta, rm2, rv2, True, relu=True, groups=groups)
+    assert torch.equal(y1, y2)
+    _close(o1, o2.float().cpu(), rel=4e-3, what="fused-stats bn out")
+    torch.testing.assert_close(rm1, rm2, atol=1e-5, rtol=1e-4)
+    torch.testing.assert_close(rv1, rv2, atol=1e-5, rtol=1e-4)
