@@ -4,3 +4,7 @@ from .augmentations import (  # noqa: F401
 )
 from .utils import NORMALIZE_STATS  # noqa: F401
 from .views import BaseViewTransform, InferenceTransform, MultiCropTransform, MultiViewTransform, Views  # noqa: F401
+from .collate import (  # noqa: F401
+    BaseCollateFunction, MultiViewCollateFunction, WaferDINOCOllateFunction, WaferImageCollateFunction,
+    WaferMAECollateFunction2, WaferMSNCollateFunction, WaferSwaVCollateFunction, rgb_scale,
+)

@@ -146,3 +146,17 @@ def test_bad_params_are_rejected_on_the_host(ref_vectors):
     bad = p.copy(); bad["out_slot"][2] = bad["out_slot"][3]
     with pytest.raises(ValueError):
         augment_views(store, bad)
+
+
+def test_collate_function_returns_reference_triple(ref_vectors):
+    from ssl_wafermap_amd.transforms import WaferDINOCOllateFunction, WaferImageCollateFunction, WaferMAECollateFunction2
+
+    wafers = load_ragged(ref_vectors, "wafer")
+    store = _store(wafers)
+    batch = [(i, i % 3, f"w{i}.png") for i in range(6)]
+    (x0, x1), labels, fnames = WaferImageCollateFunction(denoise=True).bind(store, np.random.default_rng(0), fmt="nchw_f32")(batch)
+    assert x0.shape == x1.shape == (6, 3, 224, 224) and labels.tolist() == [0, 1, 2, 0, 1, 2] and fnames[3] == "w3.png"
+    views, _, _ = WaferDINOCOllateFunction().bind(store, np.random.default_rng(1))(batch)
+    assert [tuple(v.shape) for v in views] == [(6, 3, 224, 224)] * 2 + [(6, 3, 96, 96)] * 6
+    x, _, _ = WaferMAECollateFunction2().bind(store, np.random.default_rng(2))(batch)
+    assert x.shape == (6, 3, 224, 224)

@@ -167,3 +167,25 @@ def test_oracle_resnet_matches_torch_modules():
     y = nn.functional.conv2d(x, sd["conv1.weight"], None, 2, 3)
     assert y.shape == (2, 64, 32, 32)
     assert block("layer2.0", 64, 128, 2)(torch.randn(1, 64, 16, 16)).shape == (1, 128, 8, 8)
+
+
+def test_collate_functions_have_the_reference_view_structure():
+    from ssl_wafermap_amd import transforms as T
+
+    assert len(T.WaferImageCollateFunction().transform.transforms) == 2
+    d = T.WaferDINOCOllateFunction()
+    assert [v.out_size for v in d.transform.transforms] == [224, 224] + [96] * 6
+    assert d.transform.transforms[0].crop_scale == (0.6, 1.0) and d.transform.transforms[-1].crop_scale == (0.1, 0.4)
+    assert len(T.WaferMAECollateFunction2(denoise=True).transform.transforms) == 1
+    m = T.WaferMSNCollateFunction()
+    assert [v.out_size for v in m.transform.transforms] == [224] * 2 + [96] * 10 and m.transform.transforms[0].vf_prob == 0.0
+    s = T.WaferSwaVCollateFunction(crop_counts=[2, 4])
+    assert [v.out_size for v in s.transform.transforms] == [224, 224, 96, 96, 96, 96]
+    with pytest.raises(ValueError):
+        T.WaferSwaVCollateFunction(crop_sizes=[224])
+    with pytest.raises(RuntimeError):
+        T.WaferImageCollateFunction()([(0, 1, "a")])
+    denoise = T.WaferImageCollateFunction(denoise=True).transform.transforms[0].stage1.transforms
+    assert isinstance(denoise[1], T.MedianFilter)  # denoise=True -> RandomOneOf{DieNoise | MedianFilter}
+    x = T.rgb_scale(np.array([[0.0, 0.5], [1.0, 0.25]]))
+    assert x.dtype == np.uint8 and x.tolist() == [[0, 128], [255, 64]]
