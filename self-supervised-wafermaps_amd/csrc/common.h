@@ -68,4 +68,15 @@ __device__ __forceinline__ void glds16(const void* gsrc, uint32_t lds_base) {
       : "memory");
 }
 
+// Same, non-temporal (streamed-once data: does not displace re-used lines from L2 / Infinity Cache).
+__device__ __forceinline__ void glds16_nt(const void* gsrc, uint32_t lds_base) {
+  uint32_t keep;
+  const uint32_t base = __builtin_amdgcn_readfirstlane(lds_base);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc), "s"(base)
+      : "memory");
+}
+
 static inline int wm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

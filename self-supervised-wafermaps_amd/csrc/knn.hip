@@ -25,6 +25,7 @@
 // (value descending, bank index ascending).
 #include "common.h"
 #include <limits.h>
+#include <stdlib.h>
 
 namespace {
 
@@ -65,8 +66,8 @@ __device__ __attribute__((aligned(256))) uint8_t knn_zero_page[256];
 
 // Streaming kernel.  The bank slice flows HBM -> LDS by global_load_lds (16 B per lane, 1 KiB per
 // wave instruction, no VGPR staging) into a ring of S 32-KB stages; S-1 chunks stay in flight
-// behind a counted s_waitcnt vmcnt and a raw s_barrier (cdna_hip_programming.md "Pipelining across
-// barriers").  LDS rows are 256 B; the DMA destination is lane-linear, so the XOR swizzle is
+// behind a counted s_waitcnt vmcnt (cdna_hip_programming.md "Pipelining across barriers"); every
+// wave fetches its own 32 rows, so the loop needs no barrier.  LDS rows are 256 B; the DMA destination is lane-linear, so the XOR swizzle is
 // applied to the per-lane SOURCE chunk and again on the fragment reads.
 template <int DT, int QT, int K, int S, bool QREG>
 __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
@@ -74,6 +75,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
     int rowbytes, int chunks_per_slice, int nslices, float* __restrict__ part_sim,
     int* __restrict__ part_idx) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int dbg = chunks_per_slice >> 24;  // timing-only ablation bits (WM_KNN_DEBUG); 0 in production
   constexpr int QB = QT * 32;
   constexpr int PER_STAGE = 8;  // global_load_lds instructions per thread per stage
   const int tid = threadIdx.x;
@@ -85,7 +87,9 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
   const int slice = blockIdx.x;
 
   uint8_t* ring = smem;                  // S x KNN_BUF
-  uint8_t* qbuf = smem + S * KNN_BUF;    // QB x rowbytes
+  // register-resident query fragments: the tile is only staged through LDS once, inside the last
+  // ring stage (first written by the DMA of iteration 0, after the fragments were read)
+  uint8_t* qbuf = QREG ? smem + (S - 1) * KNN_BUF : smem + S * KNN_BUF;  // QB x rowbytes
 
   // Block b owns chunks b, b + nslices, b + 2*nslices, ...: at any instant the resident blocks read
   // a contiguous window of the bank, which spreads over all HBM channels (contiguous per-block
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
   int soff[PER_STAGE];  // byte offset of the lane's 16-byte piece inside a zero page / slab
 #pragma unroll
   for (int i = 0; i < PER_STAGE; ++i) {
-    const int row = i * 16 + wave * 4 + drow;
+    const int row = wave * 32 + i * 4 + drow;  // a wave fetches exactly the 32 rows it multiplies
     soff[i] = (dpc ^ (row & 15)) * 16;  // logical chunk that lands at physical slot dpc
     srcp[i] = bank + ((size_t)slice * KNN_ROWS + row) * rowbytes + soff[i];
   }
@@ -117,10 +121,10 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
     uint8_t* stage = ring + (it % S) * KNN_BUF;
 #pragma unroll
     for (int i = 0; i < PER_STAGE; ++i) {
-      const int row0 = i * 16 + wave * 4;  // wave-uniform first row of this instruction
+      const int row0 = wave * 32 + i * 4;  // wave-uniform first row of this instruction
       const uint8_t* src = srcp[i] + (size_t)slab * KNN_SLAB;
       if (tail && nb + row0 + drow >= n) src = knn_zero_page + soff[i];
-      glds16(src, lds_addr(stage + row0 * KNN_SLAB));
+      glds16_nt(src, lds_addr(stage + row0 * KNN_SLAB));
     }
     if (slab == nslab - 1) {
 #pragma unroll
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
   // prologue: S-1 stages in flight, then the query tile (plain loads; drained before the loop)
 #pragma unroll
   for (int p = 0; p < S - 1; ++p)
-    if (p < iters) issue(p);
+    if (p < iters && !(dbg & 2)) issue(p);
   {
     const int ppr = rowbytes >> 4;
     const int total = QB * ppr;
@@ -165,6 +169,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
   // pairs, so when a row is a single 256-byte slab the query fragments live in registers for the
   // whole kernel and the 8 bank fragments of an iteration are fetched up front.
   uint4 qreg[QREG ? QT : 1][8];
+  if constexpr (!QREG) __syncthreads();  // query tile staged (read from LDS throughout)
   if constexpr (QREG) {
     __syncthreads();  // query tile staged
 #pragma unroll
@@ -173,22 +178,29 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
       for (int s8 = 0; s8 < 8; ++s8)
         qreg[t][s8] = *reinterpret_cast<const uint4*>(qbuf + (size_t)(t * 32 + r) * rowbytes +
                                                       (((2 * s8 + h) ^ (r & 15)) << 4));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();  // every wave has its fragments: the stage may now be overwritten
   }
 
   for (int it = 0; it < iters; ++it) {
     // stage `it` must have landed: in steady state S-2 younger stages may still be in flight
     if (it + S - 1 < iters) {
-      if constexpr (S == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+      if constexpr (S == 5) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+      else if constexpr (S == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
       else if constexpr (S == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the query tile's ds_writes (first pass)
-    __builtin_amdgcn_s_barrier();
-    if (it + S - 1 < iters) issue(it + S - 1);  // reuses the stage consumed in iteration it-1
+    // No barrier: a wave DMA-fetches exactly the rows it consumes, so its own counted vmcnt orders the
+    // data for its own ds_reads, and lgkmcnt(0) retires last iteration's fragment reads before the
+    // DMA below may overwrite that stage.  The four waves of a block (and all blocks) drift apart,
+    // which spreads the HBM requests instead of issuing them in block-wide bursts.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (it + S - 1 < iters && !(dbg & 2)) issue(it + S - 1);  // reuses the stage consumed in iteration it-1
+    if (dbg & 1) continue;
     const int slab = QREG ? 0 : it % nslab;
-    if (QREG || slab == 0) {
+    if (!QREG && slab == 0) {
 #pragma unroll
       for (int t = 0; t < QT; ++t)
 #pragma unroll
@@ -204,8 +216,10 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
 #pragma unroll
         for (int t = 0; t < QT; ++t) {
           if constexpr (DT == WM_BF16) {
+            const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[s8]),
-                                                             __builtin_bit_cast(bf16x8_t, qreg[t][s8]), acc[t], 0, 0, 0);
+                                                             __builtin_bit_cast(bf16x8_t, qreg[t][s8]),
+                                                             s8 == 0 ? zero : acc[t], 0, 0, 0);
           } else {
             const f32x4_t af = __builtin_bit_cast(f32x4_t, a[s8]);
             const f32x4_t bf = __builtin_bit_cast(f32x4_t, qreg[t][s8]);
@@ -240,12 +254,22 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
     if (QREG || slab == nslab - 1) {
       const int crel = it / nslab;  // chunk index inside this slice
       const int nb = (slice + crel * nslices) * KNN_ROWS + wave * 32;
+      if (nb + 32 <= n) {  // wave-uniform: every row of this wave's sub-tile is a real bank row
 #pragma unroll
-      for (int t = 0; t < QT; ++t) {
-        float m = gmax[t];
+        for (int t = 0; t < QT; ++t) {
+          float m = gmax[t];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) m = fmaxf(m, (nb + acc_row(e, h) < n) ? acc[t][e] : -INFINITY);
-        gmax[t] = m;
+          for (int e = 0; e < 16; ++e) m = fmaxf(m, acc[t][e]);
+          gmax[t] = m;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          float m = gmax[t];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) m = fmaxf(m, (nb + acc_row(e, h) < n) ? acc[t][e] : -INFINITY);
+          gmax[t] = m;
+        }
       }
       if ((crel & 3) == 3 || it == iters - 1) {  // group of 4 chunks complete (or slice ends)
         const int gid = ((slice + (crel & ~3) * nslices) << 3) | (wave << 1) | h;
@@ -467,7 +491,7 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
   const int sub = tid & 3, slot = tid >> 2;
   const int pieces = rowbytes >> 4;  // 16-byte pieces per row
   constexpr int EPP = DT == WM_BF16 ? 8 : 4;  // elements per piece
-  constexpr int PASSES = 4;
+  constexpr int PASSES = K == 8 ? 8 : 4;
   for (int c0p = 0; c0p < K * 64; c0p += 64 * PASSES) {
     int rows[PASSES];
     float accs[PASSES];
@@ -615,7 +639,7 @@ inline KnnPlan make_plan(int nq, int n, int rowbytes, int k) {
   p.qt = pick_qt(rowbytes, nq, p.kt);
   p.qtiles = wm_cdiv(nq, p.qt * 32);
   const int total_chunks = wm_cdiv(n, KNN_ROWS);
-  int want = 256 / p.qtiles;  // one resident block per CU (the LDS ring fills a CU)
+  int want = 512 / p.qtiles;  // two resident blocks per CU
   if (want < 1) want = 1;
   if (want > 512) want = 512;
   p.nslices = total_chunks < want ? total_chunks : want;
@@ -624,10 +648,19 @@ inline KnnPlan make_plan(int nq, int n, int rowbytes, int k) {
   return p;
 }
 
+inline int knn_debug_bits() {
+  static int bits = -1;
+  if (bits < 0) {
+    const char* e = getenv("WM_KNN_DEBUG");
+    bits = e ? atoi(e) & 3 : 0;
+  }
+  return bits;
+}
+
 template <int DT, int QT, int K, int S, bool QREG>
 int launch_stream(const KnnPlan& p, const void* query, const void* bank, int nq, int n, int rowbytes,
                   float* ps, int* pi, hipStream_t st) {
-  const size_t lds = (size_t)S * KNN_BUF + (size_t)QT * 32 * rowbytes;
+  const size_t lds = QREG ? (size_t)S * KNN_BUF : (size_t)S * KNN_BUF + (size_t)QT * 32 * rowbytes;
   static bool attr_set = false;  // idempotent; a race only repeats the call
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream<DT, QT, K, S, QREG>),
@@ -638,7 +671,7 @@ int launch_stream(const KnnPlan& p, const void* query, const void* bank, int nq,
   dim3 grid(p.nslices, p.qtiles);
   knn_stream<DT, QT, K, S, QREG><<<grid, KNN_THREADS, lds, st>>>(
       static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), nq, n, rowbytes,
-      p.chunks_per_slice, p.nslices, ps, pi);
+      p.chunks_per_slice | (knn_debug_bits() << 24), p.nslices, ps, pi);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -650,7 +683,7 @@ template <int DT, int QT, int K>
 int launch_block(const KnnPlan& p, const void* query, const void* bank, int nq, int n, int rowbytes,
                  float* ps, int* pi, hipStream_t st) {
   if constexpr (DT == WM_BF16) {
-    if (rowbytes == KNN_SLAB) return launch_stream<DT, QT, K, 4, true>(p, query, bank, nq, n, rowbytes, ps, pi, st);
+    if (rowbytes == KNN_SLAB) return launch_stream<DT, QT, K, 2, true>(p, query, bank, nq, n, rowbytes, ps, pi, st);
   }
   return launch_stream<DT, QT, K, 3, false>(p, query, bank, nq, n, rowbytes, ps, pi, st);
 }
