@@ -30,6 +30,7 @@
 //
 // Roofline: MFMA (dense bf16), 2*M*K*R*S*C FLOP per launch.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -325,15 +326,21 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   constexpr int STAGE = A_BYTES + NT * X_BYTES;
   constexpr int NA = A_BYTES / 4096;  // dY DMA instructions per wave (1 KiB each, 4 waves)
   constexpr int RPI_A = 1024 / RA;    // rows per dY instruction (4 or 8)
-  constexpr int MJ = 2;               // 16-channel fragments per wave along K
-  constexpr int NJ = BMO == 128 ? 4 : 2;  // 16-column fragments per wave per tile
+  // wave tiling.  SQ (BMO = 128, NT = 2): 2 x 2 waves, each 64 channels x ONE 64-column tile
+  // (4 x 4 fragments: 16 transposed reads per 16 MFMAs).  Otherwise: BMO = 128 -> 4 waves x 32
+  // channels x all NT tiles; BMO = 64 -> 2 x 2 waves of 32 channels x 32 columns of every tile.
+  constexpr bool SQ = BMO == 128 && NT == 2;
+  constexpr int MJ = SQ ? 4 : 2;               // 16-channel fragments per wave along K
+  constexpr int NJ = BMO == 128 ? 4 : 2;       // 16-column fragments per wave per tile
+  constexpr int WT = SQ ? 1 : NT;              // tiles a wave multiplies
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int ct0 = blockIdx.x * NT;  // first 64-column tile
   const int k0 = blockIdx.y * BMO;
-  const int cout_w = BMO == 128 ? wave * 32 : (wave >> 1) * 32;
+  const int cout_w = SQ ? (wave >> 1) * 64 : (BMO == 128 ? wave * 32 : (wave >> 1) * 32);
   const int col_w = BMO == 128 ? 0 : (wave & 1) * 32;
+  const int tile_w = SQ ? (wave & 1) : 0;  // first tile this wave multiplies
 
   // ---- DMA lane geometry
   const int a_ro = RA == 256 ? (lane >> 4) : (lane >> 3);  // row inside a dY instruction
@@ -409,11 +416,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
     }
   };
 
-  f32x4_t acc[MJ][NT * NJ];
+  f32x4_t acc[MJ][WT * NJ];
 #pragma unroll
   for (int i = 0; i < MJ; ++i)
 #pragma unroll
-    for (int j = 0; j < NT * NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < WT * NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 
   // transposed-read geometry: 16-lane group g, lane (q, p) inside it; MFMA k-slot (g, e) holds
   // pixel 4g + e (e < 4) or 16 + 4g + (e - 4) of the 32-pixel k-step — same map for both operands.
@@ -435,8 +442,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
         af[i] = __builtin_bit_cast(bf16x8_t, v);
       }
 #pragma unroll
-      for (int t = 0; t < NT; ++t) {
-        const uint8_t* xb = buf + A_BYTES + t * X_BYTES;
+      for (int t = 0; t < WT; ++t) {
+        const uint8_t* xb = buf + A_BYTES + (tile_w + t) * X_BYTES;
         bf16x8_t bfr[NJ];
 #pragma unroll
         for (int j = 0; j < NJ; ++j) {
@@ -468,13 +475,13 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
 #pragma unroll
   for (int i = 0; i < MJ; ++i)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int t = 0; t < WT; ++t)
 #pragma unroll
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int kk = k0 + cout_w + i * 16 + fg * 4 + e;
-          const int col = (ct0 + t) * 64 + col_w + j * 16 + fr;
+          const int col = (ct0 + tile_w + t) * 64 + col_w + j * 16 + fr;
           atomicAdd(a.dw + (size_t)kk * rsc + col, acc[i][t * NJ + j][e]);
         }
 }
@@ -513,7 +520,14 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
   const int colgroups = a.R * a.S * a.C / 64 / NT;
   const int ktiles = a.K / BMO;
   a.total_chunks = wm_cdiv(a.M, WG_PIX);
-  int nsplit = (NT == 1 ? 2048 : 1536) / (colgroups * ktiles);
+  // split-K factor: enough blocks to fill the chip (2 resident per CU), no more — every block ends
+  // with one f32 atomic per accumulator element, so the atomic traffic grows with the split count
+  static int target = 0;
+  if (target == 0) {
+    const char* e = getenv("WM_WGRAD_BLOCKS");
+    target = e ? atoi(e) : 512;
+  }
+  int nsplit = target / (colgroups * ktiles);
   if (nsplit < 1) nsplit = 1;
   if (nsplit > a.total_chunks) nsplit = a.total_chunks;
   a.chunks_per_split = wm_cdiv(a.total_chunks, nsplit);

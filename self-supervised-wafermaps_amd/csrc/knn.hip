@@ -639,7 +639,7 @@ inline KnnPlan make_plan(int nq, int n, int rowbytes, int k) {
   p.qt = pick_qt(rowbytes, nq, p.kt);
   p.qtiles = wm_cdiv(nq, p.qt * 32);
   const int total_chunks = wm_cdiv(n, KNN_ROWS);
-  int want = 512 / p.qtiles;  // two resident blocks per CU
+  int want = (p.qt == 4 ? 256 : 512) / p.qtiles;  // resident blocks per CU: 1 (128-query tiles) or 2
   if (want < 1) want = 1;
   if (want > 512) want = 512;
   p.nslices = total_chunks < want ? total_chunks : want;
@@ -683,7 +683,12 @@ template <int DT, int QT, int K>
 int launch_block(const KnnPlan& p, const void* query, const void* bank, int nq, int n, int rowbytes,
                  float* ps, int* pi, hipStream_t st) {
   if constexpr (DT == WM_BF16) {
-    if (rowbytes == KNN_SLAB) return launch_stream<DT, QT, K, 2, true>(p, query, bank, nq, n, rowbytes, ps, pi, st);
+    // 64-query tiles: 2-stage ring, two blocks per CU (2 waves/SIMD overlap issue and waits);
+    // 128-query tiles need ~400 registers per lane, i.e. one block per CU: 4-stage ring instead
+    if (rowbytes == KNN_SLAB) {
+      if constexpr (QT == 4) return launch_stream<DT, QT, K, 4, true>(p, query, bank, nq, n, rowbytes, ps, pi, st);
+      else return launch_stream<DT, QT, K, 2, true>(p, query, bank, nq, n, rowbytes, ps, pi, st);
+    }
   }
   return launch_stream<DT, QT, K, 3, false>(p, query, bank, nq, n, rowbytes, ps, pi, st);
 }

