@@ -179,6 +179,11 @@ int wm_conv2d_fwd_stats(const void* x, const void* w_krsc, void* y, int N, int H
 /* dx = conv_transpose(dy, w): w_crsk bf16 [C][R][S][K]; C % 64 == 0. */
 int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W, int C, int K,
                     int R, int S, int P, int Q, int stride, int pad, void* stream);
+/* dx = conv_transpose(dy, w) + residual: `residual` (bf16, shape of dx) is the gradient that reached
+ * the same input through another path (the identity shortcut of a residual block); adding it in the
+ * epilogue replaces a separate three-pass elementwise add. */
+int wm_conv2d_dgrad_add(const void* dy, const void* w_crsk, const void* residual, void* dx, int N, int H,
+                        int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, void* stream);
 /* dw_krsc (f32 [K][R][S][C]) += sum over pixels of dy (x) x; split-K partials are combined with
  * f32 atomics, so the caller zeroes dw_krsc first and the low bits depend on arrival order. */
 int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_krsc, int N, int H, int W, int C, int K,

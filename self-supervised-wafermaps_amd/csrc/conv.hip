@@ -47,6 +47,9 @@ struct ConvArgs {
   // bf16-rounded outputs, added into bucket (tile % stat_nb) of the tile's row group
   float* stat;          // [G][stat_nb][2][DC] f32, or NULL
   int stat_nb, stat_rpg;
+  // optional tensor added to the result in the epilogue (dgrad: the gradient that reached the same
+  // input through a second path, e.g. the identity shortcut of a residual block), same shape as dst
+  const uint16_t* res;
 };
 
 // 128 zero bytes: the global_load_lds source of padded / out-of-range taps
@@ -287,9 +290,20 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
       const int h2 = rem / (a.DW >> 1), w2 = rem - h2 * (a.DW >> 1);
       pix = ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
     }
-    if (m0 + row < a.M)
-      *reinterpret_cast<uint4*>(a.dst + pix * a.DC + n0 + ch * 8) =
-          *reinterpret_cast<const uint4*>(cv_smem + row * CS + ch * 16);
+    if (m0 + row < a.M) {
+      uint4 v = *reinterpret_cast<const uint4*>(cv_smem + row * CS + ch * 16);
+      if (a.res != nullptr) {
+        const uint4 r4 = *reinterpret_cast<const uint4*>(a.res + pix * a.DC + n0 + ch * 8);
+        const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          o[e] = pack_bf2(bf2f((uint16_t)(vv[e] & 0xffff)) + bf2f((uint16_t)(rr[e] & 0xffff)),
+                          bf2f((uint16_t)(vv[e] >> 16)) + bf2f((uint16_t)(rr[e] >> 16)));
+        v = make_uint4(o[0], o[1], o[2], o[3]);
+      }
+      *reinterpret_cast<uint4*>(a.dst + pix * a.DC + n0 + ch * 8) = v;
+    }
   }
 }
 
@@ -588,7 +602,7 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   a.dst = static_cast<uint16_t*>(y);
   a.N = N; a.SH = H; a.SW = W; a.SC = C; a.DH = P; a.DW = Q; a.DC = K;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.M = N * P * Q;
-  a.stat = stat; a.stat_nb = stat_nb; a.stat_rpg = stat_rpg;
+  a.stat = stat; a.stat_nb = stat_nb; a.stat_rpg = stat_rpg; a.res = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (C == 16) {
     a.nkt = R;
@@ -598,9 +612,25 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   return K % 128 == 0 ? launch_igemm<128, 128, 8, 0>(a, st) : launch_igemm<128, 64, 8, 0>(a, st);
 }
 
+static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const void* residual, int N, int H,
+                           int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, void* stream);
+
 extern "C" int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W,
                                int C, int K, int R, int S, int P, int Q, int stride, int pad,
                                void* stream) {
+  return conv_dgrad_impl(dy, w_crsk, dx, nullptr, N, H, W, C, K, R, S, P, Q, stride, pad, stream);
+}
+
+extern "C" int wm_conv2d_dgrad_add(const void* dy, const void* w_crsk, const void* residual, void* dx, int N,
+                                   int H, int W, int C, int K, int R, int S, int P, int Q, int stride, int pad,
+                                   void* stream) {
+  WM_REQUIRE(residual, WM_EINVAL);
+  WM_REQUIRE((reinterpret_cast<uintptr_t>(residual) & 15) == 0, WM_EALIGN);
+  return conv_dgrad_impl(dy, w_crsk, dx, residual, N, H, W, C, K, R, S, P, Q, stride, pad, stream);
+}
+
+static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const void* residual, int N, int H,
+                           int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, void* stream) {
   WM_REQUIRE(dy && w_crsk && dx, WM_EINVAL);
   const int rc = conv_check(N, H, W, C, K, R, S, P, Q, stride, pad);
   if (rc != WM_OK) return rc;
@@ -613,6 +643,7 @@ extern "C" int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int
   a.N = N; a.SH = P; a.SW = Q; a.SC = K; a.DH = H; a.DW = W; a.DC = C;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.M = N * H * W;
   a.stat = nullptr; a.stat_nb = 0; a.stat_rpg = 1;
+  a.res = static_cast<const uint16_t*>(residual);
   a.nkt = R * S * (K / 64);
   hipStream_t st = static_cast<hipStream_t>(stream);
   // stride 2 with even image sides and class size % 128 == 0: parity-class ordering (no wasted taps)

@@ -35,10 +35,19 @@ class BasicBlock(nn.Module):
         nn.init.zeros_(self.bn2.weight)  # timm zero_init_last
 
     def forward(self, x):
-        shortcut = x
-        out = conv_bn(self.conv1, self.bn1, x, relu=True)
         if self.downsample is not None:
+            out = conv_bn(self.conv1, self.bn1, x, relu=True)
             shortcut = conv_bn(self.downsample[0], self.downsample[1], x)
+        elif torch.is_grad_enabled() and x.requires_grad:
+            # identity shortcut: conv1 hands its input back as the residual so that the shortcut's
+            # gradient is added in conv1's dgrad epilogue (no separate add kernel in the backward)
+            g = ops.current_bn_groups()
+            st = self.bn1.stats_buffer(g) if self.bn1.training else None
+            y, shortcut = self.conv1(x, stats=st, groups=g, passthrough=True)
+            out = self.bn1(y, relu=True, stats=st)
+        else:
+            out = conv_bn(self.conv1, self.bn1, x, relu=True)
+            shortcut = x
         return conv_bn(self.conv2, self.bn2, out, relu=True, residual=shortcut)
 
 

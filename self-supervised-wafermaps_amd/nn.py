@@ -19,7 +19,9 @@ class Conv2d(nn.Module):
         self.weight = nn.Parameter(torch.empty(out_channels, in_channels, kernel_size, kernel_size))
         nn.init.kaiming_normal_(self.weight, mode="fan_out", nonlinearity="relu")  # timm resnet init
 
-    def forward(self, x, stats=None, groups=1):
+    def forward(self, x, stats=None, groups=1, passthrough=False):
+        if passthrough:
+            return ops.conv2d_passthrough(x, self.weight, self.stride, self.padding, stats=stats, groups=groups)
         return ops.conv2d(x, self.weight, self.stride, self.padding, stats=stats, groups=groups)
 
 

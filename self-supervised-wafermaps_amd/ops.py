@@ -180,7 +180,7 @@ def _out_hw(h, w, r, s, stride, pad):
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, stats=None, groups=1):
+    def forward(ctx, x, weight, stride, pad, stats=None, groups=1, pass_input=False):
         _need_cuda(x, "conv2d")
         x = _as_nhwc(x)
         n, c, h, w = x.shape
@@ -201,10 +201,14 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x)
         ctx.weight = weight
         ctx.geom = (n, h, w, c, k, r, s, p, q, stride, pad)
+        if pass_input:
+            # second output: the input itself (identity).  Its gradient comes back to THIS backward,
+            # which adds it inside the dgrad epilogue instead of leaving a separate add to autograd.
+            return y, x.view_as(x)
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dres=None):
         (x,) = ctx.saved_tensors
         weight = ctx.weight
         n, h, w, c, k, r, s, p, q, stride, pad = ctx.geom
@@ -214,8 +218,14 @@ class _Conv2d(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, crsk = _WCACHE.get(weight, need_crsk=True)
             dx = _empty_nhwc(n, c, h, w, dy.device)
-            check(_run("conv_dgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_dgrad, dy.data_ptr(), ptr(crsk),
-                       dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_dgrad")
+            if dres is not None:
+                dres = _as_nhwc(dres)
+                check(_run("conv_dgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_dgrad_add, dy.data_ptr(),
+                           ptr(crsk), dres.data_ptr(), dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad,
+                           stream_ptr()), "wm_conv2d_dgrad_add")
+            else:
+                check(_run("conv_dgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_dgrad, dy.data_ptr(), ptr(crsk),
+                           dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_dgrad")
         if ctx.needs_input_grad[1]:
             ws = _wgrad_accumulator(weight, (k, r, s, c))
             check(_run("conv_wgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_wgrad, dy.data_ptr(), x.data_ptr(),
@@ -226,7 +236,7 @@ class _Conv2d(torch.autograd.Function):
             else:
                 dw = torch.empty((k, c, r, s), dtype=torch.float32, device=dy.device)
                 check(lib.wm_wgrad_finalize(ptr(ws), k, c, r, s, ptr(dw), 0, stream_ptr()), "wm_wgrad_finalize")
-        return dx, dw, None, None, None, None
+        return dx, dw, None, None, None, None, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0,
@@ -234,7 +244,15 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int 
     """bias-free conv2d; x bf16 NHWC (converted if not), weight float32 [K, C, R, S].
     `stats`: zeroed float32 [groups, STAT_BUCKETS, 2, K] buffer into which the epilogue accumulates the
     BatchNorm statistics of the output (used when `stats_fusable(rows, groups)`)."""
-    return _Conv2d.apply(x, weight, int(stride), int(padding), stats, int(groups))
+    return _Conv2d.apply(x, weight, int(stride), int(padding), stats, int(groups), False)
+
+
+def conv2d_passthrough(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0,
+                       stats: Optional[torch.Tensor] = None, groups: int = 1):
+    """conv2d that also hands back its input as a second (identity) output: use that output for the
+    residual path of a block, and the gradient of the shortcut is added inside the dgrad kernel's
+    epilogue (wm_conv2d_dgrad_add) instead of by a separate elementwise kernel."""
+    return _Conv2d.apply(x, weight, int(stride), int(padding), stats, int(groups), True)
 
 
 class _StemConv(torch.autograd.Function):

@@ -284,3 +284,24 @@ def test_conv_bn_fused_statistics_match_unfused():
     _close(o1, o2.float().cpu(), rel=4e-3, what="fused-stats bn out")
     torch.testing.assert_close(rm1, rm2, atol=1e-5, rtol=1e-4)
     torch.testing.assert_close(rv1, rv2, atol=1e-5, rtol=1e-4)
+
+
+def test_conv_passthrough_adds_shortcut_gradient_in_dgrad():
+    """y, xr = conv2d_passthrough(x, w): d/dx of f(y) + g(xr) equals dgrad + dg, added in the dgrad epilogue."""
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    x = _bf(torch.randn(4, 64, 12, 12, generator=g))
+    w = _bf(torch.randn(64, 64, 3, 3, generator=g) * 0.05)
+    dy = _bf(torch.randn(4, 64, 12, 12, generator=g))
+    dr = _bf(torch.randn(4, 64, 12, 12, generator=g))
+    xr_ = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr_, w, None, 1, 1)
+    (yr * dy).sum().backward(retain_graph=False)
+    ref = xr_.grad + dr
+    xd = ops.to_nhwc_bf16(x.to(DEV)).requires_grad_(True)
+    wd = w.to(DEV).requires_grad_(True)
+    y, xres = ops.conv2d_passthrough(xd, wd, 1, 1)
+    assert torch.equal(xres, xd)
+    torch.autograd.backward([y, xres], [ops.to_nhwc_bf16(dy.to(DEV)), ops.to_nhwc_bf16(dr.to(DEV))])
+    _close(xd.grad, ref, what="dgrad + shortcut gradient")
