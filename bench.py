@@ -13,9 +13,10 @@ libwafer_hip.so; inputs (the ragged uint8 wafer store) are resident in HBM befor
 Prints ONE JSON line (rank 0): metric imgs/sec = wafers (not views) per second, whole job.
   roofline     : the conv implicit-GEMM kernels (fwd + dgrad + wgrad), algorithmic FLOPs / the summed
                  HIP-event durations of those launches, vs dense bf16 MFMA peak.  The events are
-                 recorded INSIDE the timed region on the launch stream, on every `--timer-every`-th
-                 step only (a timing event is a barrier packet on ROCm: bracketing all ~60 conv
-                 launches of every step costs ~20 % throughput, so it is sampled).
+                 recorded INSIDE the timed region on the launch stream, on the LAST timed step only
+                 (or every `--timer-every`-th): a timing event is a barrier packet on ROCm and
+                 bracketing all ~60 conv launches of every step costs ~20 % throughput, so the
+                 bracketed step runs eagerly and the others replay the captured hipGraph.
   cpu_baseline : the torch-CPU oracle (oracle/) running BASELINE configs[0] (bs 32, fp32) on the
                  host cores for a bounded number of steps (rank 0, N = 1 only).
 """
@@ -101,7 +102,8 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="wafers per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--timer-every", type=int, default=10, help="bracket the conv launches on every n-th timed step")
+    ap.add_argument("--timer-every", type=int, default=0,
+                    help="bracket the conv launches on every n-th timed step (0: on the last timed step only)")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
     args = ap.parse_args()
 
@@ -172,7 +174,10 @@ def main():
     fence()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        sample = timer is not None and (i % args.timer_every == args.timer_every - 1 or args.steps < args.timer_every and i == args.steps - 1)
+        if args.timer_every > 0:
+            sample = timer is not None and i % args.timer_every == args.timer_every - 1
+        else:
+            sample = timer is not None and i == args.steps - 1
         ops.TIMER = timer if sample else None
         timed_steps += int(sample)
         loss = step(args.warmup + i)

@@ -221,6 +221,14 @@ int wm_bn_train_fwd_from_stats(const void* y, const void* residual, const float*
                                float eps, float momentum, int relu, float* save_mean, float* save_invstd,
                                void* out, float* stat_part, int stat_buckets, void* workspace,
                                size_t workspace_bytes, void* stream);
+/* Statistics only: mean / invstd / running stats and the [G][C] scale, shift of the normalisation, for a
+ * consumer that applies it itself (the fused stem below).  stat_part NULL: computed from y here. */
+int wm_bn_train_stats(const void* y, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, long long rows, int C, int G, float eps, float momentum,
+                      float* save_mean, float* save_invstd, float* scale, float* shift, float* stat_part,
+                      int stat_buckets, void* workspace, size_t workspace_bytes, void* stream);
+int wm_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                           const float* running_var, int C, float eps, float* scale, float* shift, void* stream);
 int wm_bn_eval_fwd(const void* y, const void* residual, const float* gamma, const float* beta,
                    const float* running_mean, const float* running_var, long long rows, int C, float eps,
                    int relu, void* out, void* workspace, size_t workspace_bytes, void* stream);
@@ -237,6 +245,10 @@ int wm_add_bf16(const void* a, const void* b, long long n, void* out, void* stre
 /* MaxPool2d(3, stride 2, padding 1) with recorded window positions (uint8, first maximum in scan
  * order as torch does), and global average pooling [N][HW][C] -> [N][C]. */
 int wm_maxpool3x3s2_fwd(const void* x, int N, int H, int W, int C, void* y, void* idx, void* stream);
+/* ResNet stem: maxpool(relu(x*scale + shift)) in one pass (scale/shift [G][C], G groups of N/G
+ * images); the normalised 112x112 activation is never materialised.  Same idx semantics. */
+int wm_bn_relu_maxpool3x3s2_fwd(const void* x, const float* scale, const float* shift, int N, int H, int W, int C,
+                                int G, void* y, void* idx, void* stream);
 int wm_maxpool3x3s2_bwd(const void* dy, const void* idx, int N, int H, int W, int C, void* dx, void* stream);
 int wm_gap_fwd(const void* x, int N, int HW, int C, void* y, void* stream);
 int wm_gap_bwd(const void* dy, int N, int HW, int C, void* dx, void* stream);

@@ -98,6 +98,12 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_float,
          c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
     ),
+    "wm_bn_train_stats": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_float, c_void_p,
+         c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
+    ),
+    "wm_bn_eval_scale_shift": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "wm_bn_eval_fwd": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_float, c_int, c_void_p,
@@ -110,6 +116,8 @@ SIGNATURES = {
     ),
     "wm_add_bf16": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),
     "wm_maxpool3x3s2_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "wm_bn_relu_maxpool3x3s2_fwd": (
+        c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "wm_maxpool3x3s2_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_gap_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_gap_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

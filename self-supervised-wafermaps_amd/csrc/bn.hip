@@ -431,6 +431,49 @@ extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, c
   return WM_OK;
 }
 
+// Statistics only (no apply pass): mean/invstd/running stats + per-(group, channel) scale and shift
+// [G][C] each, for a consumer that applies the normalisation itself (wm_bn_relu_maxpool3x3s2_fwd).
+// stat_part non-NULL: statistics were fused into the producing convolution; else they are computed here.
+extern "C" int wm_bn_train_stats(const void* y, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, long long rows, int C, int G, float eps, float momentum,
+                                 float* save_mean, float* save_invstd, float* scale, float* shift, float* stat_part,
+                                 int stat_buckets, void* workspace, size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(y && save_mean && save_invstd && scale && shift && workspace, WM_EINVAL);
+  const int rc = bn_shape_check(rows, C, G);
+  if (rc != WM_OK) return rc;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rpg = (int)(rows / G);
+  if (stat_part) {
+    WM_REQUIRE(stat_buckets > 0, WM_EINVAL);
+    bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(stat_part, stat_buckets, G, C, rpg, 1, gamma, beta, eps, momentum,
+                                                     running_mean, running_var, save_mean, save_invstd, scale, shift);
+  } else {
+    WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
+    const int nblk = reduce_blocks(rpg, C);
+    float* part = static_cast<float*>(workspace);
+    const int tpr = C >> 3, rpp = BN_THREADS / tpr;
+    const size_t lds = (size_t)2 * rpp * C * sizeof(float);
+    bn_reduce<0><<<dim3(nblk, G), BN_THREADS, lds, st>>>(static_cast<const uint16_t*>(y), nullptr, nullptr, nullptr,
+                                                         nullptr, nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk), part);
+    WM_LAUNCH_CHECK();
+    bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, 0, gamma, beta, eps, momentum, running_mean,
+                                                     running_var, save_mean, save_invstd, scale, shift);
+  }
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+// Eval-mode scale/shift [C] from the running statistics (for the fused stem in eval mode).
+extern "C" int wm_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
+                                      const float* running_var, int C, float eps, float* scale, float* shift,
+                                      void* stream) {
+  WM_REQUIRE(running_mean && running_var && scale && shift && C > 0, WM_EINVAL);
+  bn_eval_params<<<1, C < 1024 ? ((C + 63) / 64) * 64 : 1024, 0, static_cast<hipStream_t>(stream)>>>(
+      gamma, beta, running_mean, running_var, eps, C, scale, shift);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
 extern "C" int wm_bn_eval_fwd(const void* y, const void* residual, const float* gamma, const float* beta,
                               const float* running_mean, const float* running_var, long long rows, int C,
                               float eps, int relu, void* out, void* workspace, size_t workspace_bytes,

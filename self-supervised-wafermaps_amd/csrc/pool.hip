@@ -66,6 +66,69 @@ __global__ __launch_bounds__(PL_THREADS) void maxpool_fwd(const uint16_t* __rest
   }
 }
 
+// Stem: relu(y*scale + shift) is pooled on the fly, so the 112x112x64 activation (the largest tensor
+// of the network) is never written or re-read.  scale/shift are [G][C]; a row group = N/G images.
+__global__ __launch_bounds__(PL_THREADS) void bn_relu_maxpool_fwd(const uint16_t* __restrict__ x,
+                                                                  const float* __restrict__ scale,
+                                                                  const float* __restrict__ shift, int N,
+                                                                  int H, int W, int C, int P, int Q,
+                                                                  int imgs_per_group,
+                                                                  uint16_t* __restrict__ y,
+                                                                  uint8_t* __restrict__ idx) {
+  const int cpr = C >> 3;
+  const long long total = (long long)N * P * Q * cpr;
+  for (long long t = (long long)blockIdx.x * PL_THREADS + threadIdx.x; t < total;
+       t += (long long)gridDim.x * PL_THREADS) {
+    const int c0 = (int)(t % cpr) * 8;
+    long long pix = t / cpr;
+    const int q = (int)(pix % Q);
+    pix /= Q;
+    const int p = (int)(pix % P), n = (int)(pix / P);
+    const int g = n / imgs_per_group;
+    float sc[8], sh[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      sc[e] = scale[(size_t)g * C + c0 + e];
+      sh[e] = shift[(size_t)g * C + c0 + e];
+    }
+    float best[8];
+    int bi[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      best[e] = -INFINITY;
+      bi[e] = 0;
+    }
+    bool first = true;
+#pragma unroll
+    for (int kh = 0; kh < 3; ++kh)
+#pragma unroll
+      for (int kw = 0; kw < 3; ++kw) {
+        const int h = p * 2 - 1 + kh, w = q * 2 - 1 + kw;
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) {
+          float f[8];
+          up8(*reinterpret_cast<const uint4*>(x + ((size_t)(n * H + h) * W + w) * C + c0), f);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            // exactly what bn_apply would have stored: bf16(relu(fma(y, scale, shift)))
+            const float v = bf2f(f2bf(fmaxf(fmaf(f[e], sc[e], sh[e]), 0.f)));
+            if (first || v > best[e]) {
+              best[e] = v;
+              bi[e] = kh * 3 + kw;
+            }
+          }
+          first = false;
+        }
+      }
+    const size_t o = ((size_t)(n * P + p) * Q + q) * C + c0;
+    *reinterpret_cast<uint4*>(y + o) = make_uint4(pack_bf2(best[0], best[1]), pack_bf2(best[2], best[3]),
+                                                  pack_bf2(best[4], best[5]), pack_bf2(best[6], best[7]));
+    uint2 pk;
+    pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
+    pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
+    *reinterpret_cast<uint2*>(idx + o) = pk;
+  }
+}
+
 __global__ __launch_bounds__(PL_THREADS) void maxpool_bwd(const uint16_t* __restrict__ dy,
                                                           const uint8_t* __restrict__ idx, int N, int H,
                                                           int W, int C, int P, int Q,
@@ -161,6 +224,19 @@ extern "C" int wm_maxpool3x3s2_fwd(const void* x, int N, int H, int W, int C, vo
   const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
   maxpool_fwd<<<grid_for((long long)N * P * Q * (C >> 3)), PL_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
       static_cast<const uint16_t*>(x), N, H, W, C, P, Q, static_cast<uint16_t*>(y), static_cast<uint8_t*>(idx));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_bn_relu_maxpool3x3s2_fwd(const void* x, const float* scale, const float* shift, int N, int H,
+                                           int W, int C, int G, void* y, void* idx, void* stream) {
+  WM_REQUIRE(x && scale && shift && y && idx, WM_EINVAL);
+  WM_REQUIRE(N > 0 && H > 1 && W > 1 && C > 0 && G > 0, WM_EINVAL);
+  WM_REQUIRE(C % 8 == 0 && N % G == 0, WM_EUNSUPPORTED);
+  const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
+  bn_relu_maxpool_fwd<<<grid_for((long long)N * P * Q * (C >> 3)), PL_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(x), scale, shift, N, H, W, C, P, Q, N / G, static_cast<uint16_t*>(y),
+      static_cast<uint8_t*>(idx));
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

@@ -66,8 +66,13 @@ class ResNet18(nn.Module):
         self.layer4 = nn.Sequential(BasicBlock(256, 512, 2), BasicBlock(512, 512))
 
     def forward_features(self, x):
-        x = conv_bn(self.conv1, self.bn1, x, relu=True)
-        x = ops.max_pool3x3s2(x)
+        # stem: conv (+ fused BN statistics) -> BN + ReLU + max-pool in one pass
+        if self.bn1.training:
+            g = ops.current_bn_groups()
+            st = self.bn1.stats_buffer(g)
+            x = self.bn1.forward_relu_maxpool(self.conv1(x, stats=st, groups=g), stats=st)
+        else:
+            x = self.bn1.forward_relu_maxpool(self.conv1(x))
         x = self.layer1(x)
         x = self.layer2(x)
         x = self.layer3(x)

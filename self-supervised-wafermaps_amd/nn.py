@@ -63,7 +63,12 @@ class _BatchNorm(nn.Module):
 
 
 class BatchNorm2d(_BatchNorm):
-    pass
+    def forward_relu_maxpool(self, x, stats=None):
+        """maxpool3x3s2(relu(self(x))) fused (ResNet stem)."""
+        if self.training:
+            self.num_batches_tracked += ops.current_bn_groups()
+        return ops.bn_relu_maxpool(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
+                                   eps=self.eps, momentum=self.momentum, stats=stats)
 
 
 class BatchNorm1d(_BatchNorm):

@@ -420,6 +420,79 @@ def batch_norm(y, gamma, beta, running_mean, running_var, training: bool, residu
                             float(momentum), bool(relu), stats)
 
 
+class _BnReluMaxPool(torch.autograd.Function):
+    """ResNet stem tail: maxpool3x3s2(relu(BN(y))) without materialising the normalised activation."""
+
+    @staticmethod
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, groups, eps, momentum, stats=None):
+        _need_cuda(y, "bn_relu_maxpool")
+        y = _as_nhwc(y)
+        n, c, h, w = y.shape
+        rows = n * h * w
+        lib = _lib.load()
+        g = groups if training else 1
+        if n % g:
+            raise ValueError("bn_relu_maxpool: batch not divisible by the statistics groups")
+        scale = torch.empty((g, c), dtype=torch.float32, device=y.device)
+        shift = torch.empty_like(scale)
+        if training:
+            mean, invstd = torch.empty_like(scale), torch.empty_like(scale)
+            ws = _bn_workspace(rows, c, g, y.device)
+            fused = stats is not None and stats_fusable(rows, g)
+            check(lib.wm_bn_train_stats(y.data_ptr(), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), rows, c, g,
+                                        eps, momentum, ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
+                                        ptr(stats) if fused else 0, STAT_BUCKETS, ptr(ws), ws.numel(), stream_ptr()),
+                  "wm_bn_train_stats")
+            ctx.save_for_backward(y, mean, invstd)
+        else:
+            check(lib.wm_bn_eval_scale_shift(ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), c, eps,
+                                             ptr(scale), ptr(shift), stream_ptr()), "wm_bn_eval_scale_shift")
+        p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        out = _empty_nhwc(n, c, p, q, y.device)
+        idx = torch.empty((n, p, q, c), dtype=torch.uint8, device=y.device)
+        check(lib.wm_bn_relu_maxpool3x3s2_fwd(y.data_ptr(), ptr(scale), ptr(shift), n, h, w, c, g, out.data_ptr(), ptr(idx),
+                                              stream_ptr()), "wm_bn_relu_maxpool3x3s2_fwd")
+        ctx.training = training
+        ctx.idx = idx
+        ctx.affine = (gamma, beta)
+        ctx.meta = (n, c, h, w, g)
+        return out
+
+    @staticmethod
+    def backward(ctx, dpooled):
+        if not ctx.training:
+            raise NotImplementedError("bn_relu_maxpool: backward through eval-mode statistics is not implemented")
+        y, mean, invstd = ctx.saved_tensors
+        gamma, beta = ctx.affine
+        n, c, h, w, g = ctx.meta
+        rows = n * h * w
+        lib = _lib.load()
+        dpooled = _as_nhwc(dpooled)
+        dout = _empty_nhwc(n, c, h, w, y.device)
+        check(lib.wm_maxpool3x3s2_bwd(dpooled.data_ptr(), ptr(ctx.idx), n, h, w, c, dout.data_ptr(), stream_ptr()),
+              "wm_maxpool3x3s2_bwd")
+        dy = torch.empty_like(y)
+        sg, sb = _arena_grad(gamma), _arena_grad(beta)
+        direct = sg is not None and sb is not None
+        dgamma = sg if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
+        dbeta = sb if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
+        ws = _bn_workspace(rows, c, g, y.device)
+        check(lib.wm_bn_train_bwd(y.data_ptr(), dout.data_ptr(), 0, 1, ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), rows,
+                                  c, g, ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(), 0, ptr(ws), ws.numel(),
+                                  stream_ptr()), "wm_bn_train_bwd")
+        if direct:
+            return dy, None, None, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None
+
+
+def bn_relu_maxpool(y, gamma, beta, running_mean, running_var, training: bool, eps: float = 1e-5,
+                    momentum: float = 0.1, groups: Optional[int] = None, stats=None):
+    """max_pool3x3s2(relu(batch_norm(y))) in one pass over y (ResNet stem)."""
+    g = current_bn_groups() if groups is None else groups
+    return _BnReluMaxPool.apply(y, gamma, beta, running_mean, running_var, bool(training), int(g), float(eps),
+                                float(momentum), stats)
+
+
 class _MaxPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):

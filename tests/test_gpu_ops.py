@@ -305,3 +305,32 @@ def test_conv_passthrough_adds_shortcut_gradient_in_dgrad():
     assert torch.equal(xres, xd)
     torch.autograd.backward([y, xres], [ops.to_nhwc_bf16(dy.to(DEV)), ops.to_nhwc_bf16(dr.to(DEV))])
     _close(xd.grad, ref, what="dgrad + shortcut gradient")
+
+
+@pytest.mark.parametrize("groups,training", [(1, True), (2, True), (1, False)])
+def test_bn_relu_maxpool_fused_matches_unfused(groups, training):
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(groups)
+    y = ops.to_nhwc_bf16((torch.randn(4, 64, 18, 22, generator=g) * 2 + 0.3).to(DEV))
+    gamma, beta = (torch.rand(64, generator=g) + 0.5).to(DEV), (torch.randn(64, generator=g) * 0.2).to(DEV)
+    dp = ops.to_nhwc_bf16(torch.randn(4, 64, 9, 11, generator=g).to(DEV))
+    res = []
+    for fused in (False, True):
+        yy = y.clone().requires_grad_(True)
+        ga, be = gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+        rm, rv = torch.zeros(64, device=DEV) + 0.1, torch.ones(64, device=DEV) * 1.5
+        if fused:
+            out = ops.bn_relu_maxpool(yy, ga, be, rm, rv, training, groups=groups)
+        else:
+            out = ops.max_pool3x3s2(ops.batch_norm(yy, ga, be, rm, rv, training, relu=True, groups=groups))
+        if training:
+            out.backward(dp)
+        res.append((out.detach(), yy.grad, ga.grad, be.grad, rm, rv))
+    a, b = res
+    assert torch.equal(a[0], b[0])
+    if training:
+        _close(b[1], a[1].float().cpu(), rel=1e-3, what="dy")
+        torch.testing.assert_close(b[2], a[2], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(b[3], a[3], rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(b[4], a[4]); torch.testing.assert_close(b[5], a[5])
