@@ -240,6 +240,12 @@ int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, int r
                     const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                     long long rows, int C, int G, float* dgamma, float* dbeta, int accumulate, void* dy,
                     void* dz, void* workspace, size_t workspace_bytes, void* stream);
+/* Backward of the fused stem tail max_pool3x3s2(relu(BN(y))): y [N][H][W][C]; the gradient entering
+ * the BN is gathered from pooled_dy / pool_idx [N][P][Q][C] inside the two BN backward passes. */
+int wm_bn_relu_maxpool_bwd(const void* y, const void* pooled_dy, const void* pool_idx, int N, int H, int W,
+                           int C, const float* gamma, const float* beta, const float* save_mean,
+                           const float* save_invstd, int G, float* dgamma, float* dbeta, int accumulate,
+                           void* dy, void* workspace, size_t workspace_bytes, void* stream);
 int wm_add_bf16(const void* a, const void* b, long long n, void* out, void* stream);
 
 /* MaxPool2d(3, stride 2, padding 1) with recorded window positions (uint8, first maximum in scan

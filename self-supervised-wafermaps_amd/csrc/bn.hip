@@ -31,6 +31,55 @@ __device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
   return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
 }
 
+// Optional gradient source for the stem: instead of a materialised dout [rows][C], the gradient of
+// max_pool3x3s2 is gathered on the fly from the POOLED gradient and the recorded window positions
+// (what maxpool_bwd would have written): dout(n,h,w,c) = sum over the <= 4 windows covering (h,w)
+// of [idx == position] * dyp.  Saves writing and twice re-reading the 112x112x64 tensor.
+struct PoolSrc {
+  const uint16_t* dy;   // [N][P][Q][C] pooled gradient, or NULL
+  const uint8_t* idx;   // [N][P][Q][C] window positions
+  int H, W, P, Q;
+};
+
+__device__ __forceinline__ void pool_grad8(const PoolSrc& ps, uint32_t row, int C, int c0, float (&g)[8]) {
+  // rows < 2^31 (checked by the entry point): 32-bit divisions only
+  const uint32_t hw = (uint32_t)(ps.H * ps.W);
+  const int n = (int)(row / hw);
+  const uint32_t rem = row - (uint32_t)n * hw;
+  const int h = (int)(rem / (uint32_t)ps.W), w = (int)(rem - (uint32_t)h * (uint32_t)ps.W);
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g[e] = 0.f;
+  // the (at most) 2 x 2 covering windows, fully unrolled with clamped addresses so that all eight
+  // loads are in flight together; an invalid window gets a code that never matches
+  const int p_lo = h >> 1, q_lo = w >> 1;
+  uint2 pk[4];
+  uint4 dv[4];
+  int code[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int p = p_lo + (j >> 1), q = q_lo + (j & 1);
+    const bool ok = ((j >> 1) == 0 || (h & 1)) && ((j & 1) == 0 || (w & 1)) && p < ps.P && q < ps.Q;
+    const int pc = p < ps.P ? p : ps.P - 1, qc = q < ps.Q ? q : ps.Q - 1;
+    code[j] = ok ? (h - (2 * p - 1)) * 3 + (w - (2 * q - 1)) : 255;
+    const size_t o = ((size_t)(n * ps.P + pc) * ps.Q + qc) * C + c0;
+    pk[j] = *reinterpret_cast<const uint2*>(ps.idx + o);
+    dv[j] = *reinterpret_cast<const uint4*>(ps.dy + o);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    float d[8];
+    unpack8(dv[j], d);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int ie = (int)(((e < 4 ? pk[j].x : pk[j].y) >> (8 * (e & 3))) & 0xff);
+      g[e] += ie == code[j] ? d[e] : 0.f;
+    }
+  }
+  // maxpool_bwd stores bf16: round like it does so that both paths see identical gradients
+#pragma unroll
+  for (int e = 0; e < 8; ++e) g[e] = bf2f(f2bf(g[e]));
+}
+
 // Two per-channel sums over a row range -> part[((g*nblk + blk)*2 + which)*C + c].
 // MODE 0: (sum y, sum y^2).  MODE 1: (sum dz, sum dz*xhat) with dz = dout*(out>0 | no mask).
 // MODE 1 with `out` NULL and gamma_m non-NULL: the ReLU mask is recomputed from y as
@@ -45,7 +94,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restri
                                                         const float* __restrict__ gamma_m,
                                                         const float* __restrict__ beta_m,
                                                         int rows_per_group, int C, int rows_per_block,
-                                                        float* __restrict__ part) {
+                                                        float* __restrict__ part, const PoolSrc ps) {
   extern __shared__ float red[];  // [2][rpp][C]
   const int tid = threadIdx.x;
   const int tpr = C >> 3;  // threads per row
@@ -88,7 +137,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restri
           }
         } else {
           float fd[8];
-          unpack8(*reinterpret_cast<const uint4*>(dout + off), fd);
+          if (ps.dy != nullptr) pool_grad8(ps, (uint32_t)(gbase + r), C, cidx * 8, fd);
+          else unpack8(*reinterpret_cast<const uint4*>(dout + off), fd);
           if (out) {
             float fo[8];
             unpack8(*reinterpret_cast<const uint4*>(out + off), fo);
@@ -294,7 +344,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __res
                                                            const float* __restrict__ coef,
                                                            long long rows, int C, int rows_per_group,
                                                            int remask, uint16_t* __restrict__ dy,
-                                                           uint16_t* __restrict__ dz) {
+                                                           uint16_t* __restrict__ dz, const PoolSrc ps) {
   const int cpr = C >> 3;
   const long long total = rows * cpr;
   for (long long p = (long long)blockIdx.x * BN_THREADS + threadIdx.x; p < total;
@@ -305,7 +355,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __res
     const size_t off = row * C + c0;
     float fy[8], fd[8];
     unpack8(*reinterpret_cast<const uint4*>(y + off), fy);
-    unpack8(*reinterpret_cast<const uint4*>(dout + off), fd);
+    if (ps.dy != nullptr) pool_grad8(ps, (uint32_t)row, C, c0, fd);
+    else unpack8(*reinterpret_cast<const uint4*>(dout + off), fd);
     if (out) {
       float fo[8];
       unpack8(*reinterpret_cast<const uint4*>(out + off), fo);
@@ -392,7 +443,7 @@ extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float*
   const int tpr = C >> 3, rpp = BN_THREADS / tpr;
   const size_t lds = (size_t)2 * rpp * C * sizeof(float);
   bn_reduce<0><<<dim3(nblk, G), BN_THREADS, lds, st>>>(static_cast<const uint16_t*>(y), nullptr, nullptr, nullptr,
-                                                       nullptr, nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk), part);
+                                                       nullptr, nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk), part, PoolSrc{});
   WM_LAUNCH_CHECK();
   bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, 0, gamma, beta, eps, momentum, running_mean,
                                                    running_var, save_mean, save_invstd, scale, shift);
@@ -454,7 +505,7 @@ extern "C" int wm_bn_train_stats(const void* y, const float* gamma, const float*
     const int tpr = C >> 3, rpp = BN_THREADS / tpr;
     const size_t lds = (size_t)2 * rpp * C * sizeof(float);
     bn_reduce<0><<<dim3(nblk, G), BN_THREADS, lds, st>>>(static_cast<const uint16_t*>(y), nullptr, nullptr, nullptr,
-                                                         nullptr, nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk), part);
+                                                         nullptr, nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk), part, PoolSrc{});
     WM_LAUNCH_CHECK();
     bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, 0, gamma, beta, eps, momentum, running_mean,
                                                      running_var, save_mean, save_invstd, scale, shift);
@@ -495,12 +546,42 @@ extern "C" int wm_bn_eval_fwd(const void* y, const void* residual, const float* 
   return WM_OK;
 }
 
+static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, int relu_from_y, const float* gamma,
+                       const float* beta, const float* save_mean, const float* save_invstd, long long rows, int C,
+                       int G, float* dgamma, float* dbeta, int accumulate, void* dy, void* dz, void* workspace,
+                       size_t workspace_bytes, void* stream, const PoolSrc ps);
+
 extern "C" int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, int relu_from_y,
                                const float* gamma, const float* beta, const float* save_mean,
                                const float* save_invstd, long long rows, int C, int G, float* dgamma,
                                float* dbeta, int accumulate, void* dy, void* dz, void* workspace,
                                size_t workspace_bytes, void* stream) {
-  WM_REQUIRE(y && dout && save_mean && save_invstd && dy && workspace, WM_EINVAL);
+  WM_REQUIRE(dout, WM_EINVAL);
+  return bn_bwd_impl(y, dout, out_relu, relu_from_y, gamma, beta, save_mean, save_invstd, rows, C, G, dgamma, dbeta,
+                     accumulate, dy, dz, workspace, workspace_bytes, stream, PoolSrc{});
+}
+
+// Backward of max_pool3x3s2(relu(BN(y))) (the fused stem): the gradient entering the BN is gathered
+// from the pooled gradient + window positions instead of being materialised by wm_maxpool3x3s2_bwd.
+extern "C" int wm_bn_relu_maxpool_bwd(const void* y, const void* pooled_dy, const void* pool_idx, int N, int H,
+                                      int W, int C, const float* gamma, const float* beta, const float* save_mean,
+                                      const float* save_invstd, int G, float* dgamma, float* dbeta, int accumulate,
+                                      void* dy, void* workspace, size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(pooled_dy && pool_idx && gamma && beta, WM_EINVAL);
+  WM_REQUIRE(N > 0 && H > 1 && W > 1 && (long long)N * H * W < (1ll << 31), WM_EINVAL);
+  PoolSrc ps;
+  ps.dy = static_cast<const uint16_t*>(pooled_dy);
+  ps.idx = static_cast<const uint8_t*>(pool_idx);
+  ps.H = H; ps.W = W; ps.P = (H + 2 - 3) / 2 + 1; ps.Q = (W + 2 - 3) / 2 + 1;
+  return bn_bwd_impl(y, nullptr, nullptr, 1, gamma, beta, save_mean, save_invstd, (long long)N * H * W, C, G, dgamma,
+                     dbeta, accumulate, dy, nullptr, workspace, workspace_bytes, stream, ps);
+}
+
+static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, int relu_from_y, const float* gamma,
+                       const float* beta, const float* save_mean, const float* save_invstd, long long rows, int C,
+                       int G, float* dgamma, float* dbeta, int accumulate, void* dy, void* dz, void* workspace,
+                       size_t workspace_bytes, void* stream, const PoolSrc ps) {
+  WM_REQUIRE(y && (dout || ps.dy) && save_mean && save_invstd && dy && workspace, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
   if (rc != WM_OK) return rc;
   WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
@@ -515,14 +596,14 @@ extern "C" int wm_bn_train_bwd(const void* y, const void* dout, const void* out_
   WM_REQUIRE(!remask || (gamma && beta), WM_EINVAL);
   bn_reduce<1><<<dim3(nblk, G), BN_THREADS, lds, st>>>(
       static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
-      save_mean, save_invstd, remask ? gamma : nullptr, remask ? beta : nullptr, rpg, C, wm_cdiv(rpg, nblk), part);
+      save_mean, save_invstd, remask ? gamma : nullptr, remask ? beta : nullptr, rpg, C, wm_cdiv(rpg, nblk), part, ps);
   WM_LAUNCH_CHECK();
   bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, beta, save_mean, save_invstd, dgamma,
                                                    dbeta, accumulate, coef);
   WM_LAUNCH_CHECK();
   bn_bwd_apply<<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
       static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
-      coef, rows, C, rpg, remask ? 1 : 0, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz));
+      coef, rows, C, rpg, remask ? 1 : 0, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz), ps);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

@@ -468,18 +468,16 @@ class _BnReluMaxPool(torch.autograd.Function):
         rows = n * h * w
         lib = _lib.load()
         dpooled = _as_nhwc(dpooled)
-        dout = _empty_nhwc(n, c, h, w, y.device)
-        check(lib.wm_maxpool3x3s2_bwd(dpooled.data_ptr(), ptr(ctx.idx), n, h, w, c, dout.data_ptr(), stream_ptr()),
-              "wm_maxpool3x3s2_bwd")
         dy = torch.empty_like(y)
         sg, sb = _arena_grad(gamma), _arena_grad(beta)
         direct = sg is not None and sb is not None
         dgamma = sg if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
         dbeta = sb if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
         ws = _bn_workspace(rows, c, g, y.device)
-        check(lib.wm_bn_train_bwd(y.data_ptr(), dout.data_ptr(), 0, 1, ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), rows,
-                                  c, g, ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(), 0, ptr(ws), ws.numel(),
-                                  stream_ptr()), "wm_bn_train_bwd")
+        # the pooled gradient is scattered back inside the two BN backward passes (no 112x112 dout tensor)
+        check(lib.wm_bn_relu_maxpool_bwd(y.data_ptr(), dpooled.data_ptr(), ptr(ctx.idx), n, h, w, c, ptr(gamma), ptr(beta),
+                                         ptr(mean), ptr(invstd), g, ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(),
+                                         ptr(ws), ws.numel(), stream_ptr()), "wm_bn_relu_maxpool_bwd")
         if direct:
             return dy, None, None, None, None, None, None, None, None, None
         return dy, dgamma, dbeta, None, None, None, None, None, None, None

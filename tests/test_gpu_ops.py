@@ -307,14 +307,16 @@ def test_conv_passthrough_adds_shortcut_gradient_in_dgrad():
     _close(xd.grad, ref, what="dgrad + shortcut gradient")
 
 
-@pytest.mark.parametrize("groups,training", [(1, True), (2, True), (1, False)])
-def test_bn_relu_maxpool_fused_matches_unfused(groups, training):
+@pytest.mark.parametrize("groups,training,hw", [(1, True, (18, 22)), (2, True, (18, 22)), (1, False, (18, 22)),
+                                                (2, True, (17, 21))])
+def test_bn_relu_maxpool_fused_matches_unfused(groups, training, hw):
     from ssl_wafermap_amd import ops
 
     g = torch.Generator().manual_seed(groups)
-    y = ops.to_nhwc_bf16((torch.randn(4, 64, 18, 22, generator=g) * 2 + 0.3).to(DEV))
+    h, w = hw
+    y = ops.to_nhwc_bf16((torch.randn(4, 64, h, w, generator=g) * 2 + 0.3).to(DEV))
     gamma, beta = (torch.rand(64, generator=g) + 0.5).to(DEV), (torch.randn(64, generator=g) * 0.2).to(DEV)
-    dp = ops.to_nhwc_bf16(torch.randn(4, 64, 9, 11, generator=g).to(DEV))
+    dp = ops.to_nhwc_bf16(torch.randn(4, 64, (h - 1) // 2 + 1, (w - 1) // 2 + 1, generator=g).to(DEV))
     res = []
     for fused in (False, True):
         yy = y.clone().requires_grad_(True)
