@@ -34,6 +34,13 @@
 
 namespace {
 
+// Compile-time ablation for profiling builds (-DWM_CONV_ABLATE=1: no tile fetches after the first,
+// =2: no MFMA phase).  A run-time switch costs ~30 %: it makes hipcc shuttle the accumulators
+// between AGPRs and VGPRs around the branch on every k-step.
+#ifndef WM_CONV_ABLATE
+#define WM_CONV_ABLATE 0
+#endif
+
 constexpr int CV_THREADS = 256;
 constexpr int CV_BM = 128;
 constexpr int CV_ROW = 128;  // bytes per LDS row of an operand tile (64 bf16)
@@ -240,8 +247,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt have landed
     __builtin_amdgcn_s_barrier();                     // ... everyone's; and compute(kt-1) is over
-    if (kt + 1 < nkt) issue(kt + 1, cv_smem + ((kt + 1) & 1) * STAGE);
-    compute(cv_smem + (kt & 1) * STAGE);
+    if (kt + 1 < nkt && !(WM_CONV_ABLATE & 1)) issue(kt + 1, cv_smem + ((kt + 1) & 1) * STAGE);
+    if (!(WM_CONV_ABLATE & 2)) compute(cv_smem + (kt & 1) * STAGE);
   }
   __syncthreads();
 
@@ -480,8 +487,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   for (int it = 0; it < iters; ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (it + 1 < iters) issue(it + 1, wg_smem + ((it + 1) & 1) * STAGE);
-    compute(wg_smem + (it & 1) * STAGE);
+    if (it + 1 < iters && !(WM_CONV_ABLATE & 1)) issue(it + 1, wg_smem + ((it + 1) & 1) * STAGE);
+    if (!(WM_CONV_ABLATE & 2)) compute(wg_smem + (it & 1) * STAGE);
   }
 
   const size_t rsc = (size_t)a.R * a.S * a.C;
