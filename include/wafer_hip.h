@@ -265,6 +265,76 @@ int wm_gap_bwd(const void* dy, int N, int HW, int C, void* dx, void* stream);
 int wm_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, const float* hyper,
                 void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Vision-transformer path (SURVEY §8 a13 DINOViT, a14 MAE).
+ * Replaces, in the reference: the facebookresearch/dino `dino_vits16` backbone called at
+ * scripts/WM811k_benchmark.py:548-550,566-576 (MixedWM38_pretrain.py:141-143), torchvision's
+ * vit_b_32 inside lightly's MAEBackbone/MAEDecoder (:881-899, :903-947), lightly.loss.DINOLoss
+ * (:564,586), lightly.models.utils.update_momentum (:579-581), torch.optim.AdamW (:591-598) and
+ * torch.nn.MSELoss on the masked patches (:900,949-954).
+ * Activations are bf16 [rows][C] (rows = tokens, token-major); parameters float32.
+ * ------------------------------------------------------------------------------------------- */
+
+/* nn.LayerNorm over the last dim (biased variance, two-pass in registers).  C % 8 == 0, C <= 2048.
+ * mean / rstd [rows] are saved for the backward.  dgamma / dbeta are ACCUMULATED (f32 atomics). */
+int wm_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps, long long rows, int C,
+                     void* y, float* mean, float* rstd, void* stream);
+int wm_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
+                     long long rows, int C, void* dx, float* dgamma, float* dbeta, void* stream);
+
+/* y = act(x + bias) (+ residual).  act: 0 identity, 1 exact GELU (erf).  bias / residual may be NULL. */
+#define WM_ACT_NONE 0
+#define WM_ACT_GELU 1
+int wm_bias_act_fwd(const void* x, const float* bias, const void* residual, int act, long long rows, int C,
+                    void* y, void* stream);
+/* dx = dy * act'(x + bias) (dx may be NULL for act 0: only the bias gradient is wanted);
+ * dbias[C] += column sums of dx (NULL: skipped). */
+int wm_bias_act_bwd(const void* x, const float* bias, const void* dy, int act, long long rows, int C, void* dx,
+                    float* dbias, void* stream);
+/* out[C] (+)= sum over rows of x[rows][C] (bf16 in, f32 out). */
+int wm_colsum_bf16(const void* x, long long rows, int C, float* out, int accumulate, void* stream);
+
+/* tokens[n][0] = cls + pos[0]; tokens[n][1+i] = patches[n][i] + pos[1+i]  (cls [D], pos [1+np][D] f32). */
+int wm_tokens_assemble(const void* patches, const float* cls, const float* pos, int N, int np, int D, void* tokens,
+                       void* stream);
+/* images [N][S][S][3] bf16 -> rows [N*(S/p)^2][p*p*3] in (ph, pw, c) order: the patch-embedding
+ * convolution (kernel = stride = p) becomes a GEMM against the [D][p][p][3] weight layout. */
+int wm_patchify(const void* images, int N, int S, int p, void* rows, void* stream);
+
+/* Multi-head self-attention, head dim 64, S <= 256, softmax(scale * q k^T) v.
+ * qkv [B][S][3][H][64] (the qkv Linear's output as is), out / dout [B][S][H][64], lse [B][H][S] f32.
+ * bwd writes dqkv in the layout of qkv. */
+int wm_attention_fwd(const void* qkv, int B, int S, int H, float scale, void* out, float* lse, void* stream);
+int wm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int S, int H,
+                     float scale, void* dqkv, void* stream);
+
+/* Row gather / scatter on [B][S][C] bf16 by per-batch token indices idx [B][K] (int64, as
+ * torch.argsort returns): lightly's get_at_index / set_at_index.  scatter writes only the indexed
+ * rows (caller pre-fills the rest). */
+int wm_gather_rows(const void* x, const long long* idx, int B, int S, int K, int C, void* out, void* stream);
+int wm_scatter_rows(const void* src, const long long* idx, int B, int S, int K, int C, void* dst, void* stream);
+
+/* MSE over n elements: loss[0] = mean((pred - target)^2); dpred = 2 (pred - target) / n (bf16).
+ * loss must be zeroed by the caller. */
+int wm_mse_fwd_bwd(const void* pred, const void* target, long long n, float* loss, void* dpred, void* stream);
+
+/* DINO loss (lightly.loss.DINOLoss).  teacher [Vt*B][D] bf16 -> probs f32 = softmax((t - center)/temp_t). */
+int wm_dino_teacher_probs(const void* teacher, const float* center, float temp_t, long long rows, int D,
+                          float* probs, void* stream);
+/* student [Vs][B][D] bf16, probs [Vt][B][D]: loss[0] += sum_{t != s} -<probs_t, log_softmax(student_s/temp_s)>
+ * / (n_terms * B); dstudent = d loss / d student (bf16).  Views with equal index are the same crop. */
+int wm_dino_loss_fwd_bwd(const void* student, const float* probs, int Vs, int Vt, int B, int D, float temp_s,
+                         float* loss, void* dstudent, void* stream);
+/* center = momentum * center + (1 - momentum) * mean over rows of teacher[rows][D]. */
+int wm_dino_center_update(const void* teacher, long long rows, int D, float momentum, float* center, void* stream);
+
+/* torch.optim.AdamW step over flat f32 arenas; hyper = DEVICE {lr, beta1, beta2, eps, weight_decay,
+ * bias_correction1, bias_correction2, grad_scale}. */
+int wm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                  const float* hyper, void* stream);
+/* lightly update_momentum: ema = ema * m + p * (1 - m). */
+int wm_ema_update(float* ema, const float* params, long long n, float m, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -127,6 +127,28 @@ SIGNATURES = {
     "wm_gap_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_gap_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),
+    # ---- vision-transformer path
+    "wm_layernorm_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p, c_void_p, c_void_p,
+                                 c_void_p]),
+    "wm_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p,
+                                 c_void_p, c_void_p]),
+    "wm_bias_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p]),
+    "wm_bias_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
+    "wm_colsum_bf16": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_void_p]),
+    "wm_tokens_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_attention_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "wm_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+                                 c_void_p]),
+    "wm_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_scatter_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_mse_fwd_bwd": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
+    "wm_dino_teacher_probs": (c_int, [c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p, c_void_p]),
+    "wm_dino_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
+                                     c_void_p]),
+    "wm_dino_center_update": (c_int, [c_void_p, c_longlong, c_int, c_float, c_void_p, c_void_p]),
+    "wm_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),
+    "wm_ema_update": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p]),
 }
 
 _lib = None

@@ -1,0 +1,351 @@
+// Multi-head self-attention for short sequences (ViT-S/16: 197 / 37 tokens, ViT-B/32: 50 / 13),
+// head dim 64, on MFMA.
+//
+// Replaces the Attention.forward of facebookresearch/dino's vision_transformer (q k^T * scale ->
+// softmax -> @ v, as run by scripts/WM811k_benchmark.py:566-576) and torch.nn.MultiheadAttention
+// inside torchvision's vit_b_32 encoder blocks (MAE, :903-947), and their autograd backward.
+//
+// One block (4 waves) per (image, head).  Q, K, V (and dO in the backward) of the head sit in LDS as
+// [token][64] bf16 rows padded to 144 B: a ds_read_b128 fragment read (16 rows x one 16-byte column)
+// then touches 16 distinct 4-bank groups.  A wave owns 16-row strips.
+//
+//   forward, strip of 16 queries:  S^T tile = mfma(A = K rows, B = Q rows): lane (fr, fg) holds the
+//   scores of query fr against keys 16 t + 4 fg + e.  Softmax: lane-local over (t, e), then across
+//   the four lanes fr + 16 fg.  The probabilities are already in the layout of an MFMA B operand
+//   whose k-slot (fg, e8) means key 32 kk + 4 fg + e8 (e8 < 4) / 32 kk + 16 + 4 fg + e8 - 4: the A
+//   operand V^T is read with ds_read_b64_tr_b16 using that same slot <-> key map, so P never goes
+//   through LDS.  O^T tile = mfma(A = V^T, B = P): lane holds 4 consecutive d of query fr.
+//
+//   backward: pass A (query strips) recomputes P and dP = dO V^T the same way, forms
+//   dS = P (dP - delta) scale in registers and dQ^T = mfma(A = K^T (tr read), B = dS).
+//   Pass B (key strips) recomputes the transposed tiles S[q][key] = mfma(A = Q rows, B = K rows), so
+//   that P^T / dS^T are B operands with k = query, and dV^T = mfma(A = dO^T (tr), B = P^T),
+//   dK^T = mfma(A = Q^T (tr), B = dS^T).  No atomics, no transposes through LDS; S and dP are
+//   computed twice (cheap at these lengths).
+//
+// Roofline: MFMA-issue/LDS bound, but ~8 % of a ViT-S block's FLOPs (4 S^2 64 per head vs the
+// 24 S 384^2 of its four Linear layers at S = 197): correctness first, tuning later.
+#include "common.h"
+
+namespace {
+
+constexpr int AT_THREADS = 256;
+constexpr int AT_ROWB = 144;  // LDS bytes per token row: 64 bf16 + 16 B pad
+
+__device__ __forceinline__ bf16x8_t frag_rows(const uint8_t* base, int row, int ks, int fg) {
+  return *reinterpret_cast<const bf16x8_t*>(base + row * AT_ROWB + ks * 64 + fg * 16);
+}
+
+// Operand with k running along the ROWS of the LDS image: 32 rows from row0, the 16 columns of
+// block blk.  k-slot (fg, e) <-> row0 + 4 fg + e (e < 4) / row0 + 16 + 4 fg + (e - 4).
+__device__ __forceinline__ bf16x8_t frag_cols(const uint8_t* base, int row0, int blk, int lane) {
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  const uint8_t* p = base + (row0 + 4 * tg + tq) * AT_ROWB + blk * 32 + 8 * tp;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+  const s16x4_t hi =
+      __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p + 16 * AT_ROWB));
+  const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+__device__ __forceinline__ bf16x8_t pack_slots(const f32x4_t a, const f32x4_t b) {
+  const s16x8_t v = {(short)f2bf(a[0]), (short)f2bf(a[1]), (short)f2bf(a[2]), (short)f2bf(a[3]),
+                     (short)f2bf(b[0]), (short)f2bf(b[1]), (short)f2bf(b[2]), (short)f2bf(b[3])};
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
+// rows [0, S) of one [token][64] operand of (image b, head h) -> LDS; rows [S, SP) zero
+__device__ __forceinline__ void stage_rows(const uint16_t* src, size_t row_stride, int S, int SP, uint8_t* dst) {
+  for (int i = threadIdx.x; i < SP * 8; i += AT_THREADS) {
+    const int r = i >> 3, c = i & 7;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (r < S) v = *reinterpret_cast<const uint4*>(src + (size_t)r * row_stride + c * 8);
+    *reinterpret_cast<uint4*>(dst + r * AT_ROWB + c * 16) = v;
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(AT_THREADS) void attn_fwd(const uint16_t* __restrict__ qkv, int S, int H, float scale,
+                                                       uint16_t* __restrict__ out, float* __restrict__ lse) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t at_smem[];
+  constexpr int SP = NT * 16;
+  uint8_t* sq = at_smem;
+  uint8_t* sk = sq + SP * AT_ROWB;
+  uint8_t* sv = sk + SP * AT_ROWB;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const size_t rs = (size_t)3 * H * 64;
+  const uint16_t* base = qkv + (size_t)b * S * rs + h * 64;
+  stage_rows(base, rs, S, SP, sq);
+  stage_rows(base + (size_t)H * 64, rs, S, SP, sk);
+  stage_rows(base + (size_t)2 * H * 64, rs, S, SP, sv);
+  __syncthreads();
+
+  for (int qs = wave; qs < NT; qs += 4) {
+    const int q = qs * 16 + fr;
+    const bf16x8_t qf0 = frag_rows(sq, q, 0, fg), qf1 = frag_rows(sq, q, 1, fg);
+    f32x4_t sc[NT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      f32x4_t a = {0.f, 0.f, 0.f, 0.f};
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sk, t * 16 + fr, 0, fg), qf0, a, 0, 0, 0);
+      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sk, t * 16 + fr, 1, fg), qf1, a, 0, 0, 0);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int key = t * 16 + 4 * fg + e;
+        a[e] = key < S ? a[e] * scale : -INFINITY;
+        m = fmaxf(m, a[e]);
+      }
+      sc[t] = a;
+    }
+    m = fmaxf(m, __shfl_xor(m, 16, 64));
+    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    float l = 0.f;
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        sc[t][e] = expf(sc[t][e] - m);
+        l += sc[t][e];
+      }
+    l += __shfl_xor(l, 16, 64);
+    l += __shfl_xor(l, 32, 64);
+    f32x4_t o[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NT / 2; ++kk) {
+      const bf16x8_t pf = pack_slots(sc[2 * kk], sc[2 * kk + 1]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(sv, kk * 32, j, lane), pf, o[j], 0, 0, 0);
+    }
+    if (q < S) {
+      const float inv = 1.f / l;
+      uint16_t* dst = out + ((size_t)(b * S + q) * H + h) * 64 + 4 * fg;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<uint2*>(dst + j * 16) =
+            make_uint2(pack_bf2(o[j][0] * inv, o[j][1] * inv), pack_bf2(o[j][2] * inv, o[j][3] * inv));
+      if (fg == 0) lse[((size_t)b * H + h) * S + q] = m + logf(l);
+    }
+  }
+}
+
+template <int NT>
+__global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+                                                       const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                       int S, int H, float scale, uint16_t* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t at_smem[];
+  constexpr int SP = NT * 16;
+  uint8_t* sq = at_smem;
+  uint8_t* sk = sq + SP * AT_ROWB;
+  uint8_t* sv = sk + SP * AT_ROWB;
+  uint8_t* sdo = sv + SP * AT_ROWB;
+  float* s_lse = reinterpret_cast<float*>(sdo + SP * AT_ROWB);
+  float* s_delta = s_lse + SP;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  const size_t rs = (size_t)3 * H * 64, os = (size_t)H * 64;
+  const uint16_t* base = qkv + (size_t)b * S * rs + h * 64;
+  const uint16_t* obase = out + (size_t)b * S * os + h * 64;
+  const uint16_t* dobase = dout + (size_t)b * S * os + h * 64;
+  stage_rows(base, rs, S, SP, sq);
+  stage_rows(base + (size_t)H * 64, rs, S, SP, sk);
+  stage_rows(base + (size_t)2 * H * 64, rs, S, SP, sv);
+  // dO -> LDS and delta[q] = sum_d dO[q][d] O[q][d] (8 lanes per row)
+  for (int i = threadIdx.x; i < SP * 8; i += AT_THREADS) {
+    const int r = i >> 3, c = i & 7;
+    uint4 dv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+    if (r < S) {
+      dv = *reinterpret_cast<const uint4*>(dobase + (size_t)r * os + c * 8);
+      ov = *reinterpret_cast<const uint4*>(obase + (size_t)r * os + c * 8);
+    }
+    *reinterpret_cast<uint4*>(sdo + r * AT_ROWB + c * 16) = dv;
+    const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d = fmaf(bf2f((uint16_t)(dw[e] & 0xffff)), bf2f((uint16_t)(ow[e] & 0xffff)), d);
+      d = fmaf(bf2f((uint16_t)(dw[e] >> 16)), bf2f((uint16_t)(ow[e] >> 16)), d);
+    }
+    d += __shfl_xor(d, 1, 64);
+    d += __shfl_xor(d, 2, 64);
+    d += __shfl_xor(d, 4, 64);
+    if (c == 0) {
+      s_delta[r] = d;
+      s_lse[r] = r < S ? lse[((size_t)b * H + h) * S + r] : 0.f;
+    }
+  }
+  __syncthreads();
+
+  uint16_t* dq_base = dqkv + (size_t)b * S * rs + h * 64;
+  // ---- pass A: dQ, by query strips
+  for (int qs = wave; qs < NT; qs += 4) {
+    const int q = qs * 16 + fr;
+    const bf16x8_t qf0 = frag_rows(sq, q, 0, fg), qf1 = frag_rows(sq, q, 1, fg);
+    const bf16x8_t df0 = frag_rows(sdo, q, 0, fg), df1 = frag_rows(sdo, q, 1, fg);
+    const float lq = s_lse[q], dl = s_delta[q];
+    bf16x8_t dsf[NT / 2];
+#pragma unroll
+    for (int kk = 0; kk < NT / 2; ++kk) {
+      f32x4_t ds2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * kk + u;
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sk, t * 16 + fr, 0, fg), qf0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sk, t * 16 + fr, 1, fg), qf1, a, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sv, t * 16 + fr, 0, fg), df0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sv, t * 16 + fr, 1, fg), df1, dp, 0, 0, 0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int key = t * 16 + 4 * fg + e;
+          const float p = key < S ? expf(a[e] * scale - lq) : 0.f;
+          ds2[u][e] = p * (dp[e] - dl) * scale;
+        }
+      }
+      dsf[kk] = pack_slots(ds2[0], ds2[1]);
+    }
+    f32x4_t dq[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dq[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NT / 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        dq[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(sk, kk * 32, j, lane), dsf[kk], dq[j], 0, 0, 0);
+    if (q < S) {
+      uint16_t* dst = dq_base + (size_t)q * rs + 4 * fg;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        *reinterpret_cast<uint2*>(dst + j * 16) =
+            make_uint2(pack_bf2(dq[j][0], dq[j][1]), pack_bf2(dq[j][2], dq[j][3]));
+    }
+  }
+  // ---- pass B: dK, dV, by key strips (transposed tiles: lane = key fr, registers = queries)
+  for (int ksn = wave; ksn < NT; ksn += 4) {
+    const int key = ksn * 16 + fr;
+    const bool keyok = key < S;
+    const bf16x8_t kf0 = frag_rows(sk, key, 0, fg), kf1 = frag_rows(sk, key, 1, fg);
+    const bf16x8_t vf0 = frag_rows(sv, key, 0, fg), vf1 = frag_rows(sv, key, 1, fg);
+    bf16x8_t pf[NT / 2], dsf[NT / 2];
+#pragma unroll
+    for (int kk = 0; kk < NT / 2; ++kk) {
+      f32x4_t p2[2], ds2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * kk + u;
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sq, t * 16 + fr, 0, fg), kf0, a, 0, 0, 0);
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sq, t * 16 + fr, 1, fg), kf1, a, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sdo, t * 16 + fr, 0, fg), vf0, dp, 0, 0, 0);
+        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sdo, t * 16 + fr, 1, fg), vf1, dp, 0, 0, 0);
+        const int q0 = t * 16 + 4 * fg;
+        const f32x4_t lq = *reinterpret_cast<const f32x4_t*>(s_lse + q0);
+        const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(s_delta + q0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = (keyok && q0 + e < S) ? expf(a[e] * scale - lq[e]) : 0.f;
+          p2[u][e] = p;
+          ds2[u][e] = p * (dp[e] - dl[e]) * scale;
+        }
+      }
+      pf[kk] = pack_slots(p2[0], p2[1]);
+      dsf[kk] = pack_slots(ds2[0], ds2[1]);
+    }
+    f32x4_t dv[4], dk[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) dv[j] = dk[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NT / 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        dv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(sdo, kk * 32, j, lane), pf[kk], dv[j], 0, 0, 0);
+        dk[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(sq, kk * 32, j, lane), dsf[kk], dk[j], 0, 0, 0);
+      }
+    if (keyok) {
+      uint16_t* dkp = dq_base + (size_t)key * rs + (size_t)H * 64 + 4 * fg;
+      uint16_t* dvp = dkp + (size_t)H * 64;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        *reinterpret_cast<uint2*>(dkp + j * 16) = make_uint2(pack_bf2(dk[j][0], dk[j][1]), pack_bf2(dk[j][2], dk[j][3]));
+        *reinterpret_cast<uint2*>(dvp + j * 16) = make_uint2(pack_bf2(dv[j][0], dv[j][1]), pack_bf2(dv[j][2], dv[j][3]));
+      }
+    }
+  }
+}
+
+template <typename K>
+int at_set_lds(K kernel, int bytes) {
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                     bytes);
+  return e == hipSuccess ? WM_OK : (int)e;
+}
+
+template <int NT>
+int launch_fwd(const void* qkv, int B, int S, int H, float scale, void* out, float* lse, hipStream_t st) {
+  constexpr int lds = 3 * NT * 16 * AT_ROWB;
+  static bool attr = false;
+  if (!attr) {
+    const int rc = at_set_lds(&attn_fwd<NT>, lds);
+    if (rc != WM_OK) return rc;
+    attr = true;
+  }
+  attn_fwd<NT><<<B * H, AT_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), S, H, scale,
+                                               static_cast<uint16_t*>(out), lse);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+template <int NT>
+int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int S, int H, float scale,
+               void* dqkv, hipStream_t st) {
+  constexpr int lds = 4 * NT * 16 * AT_ROWB + 2 * NT * 16 * 4;
+  static bool attr = false;
+  if (!attr) {
+    const int rc = at_set_lds(&attn_bwd<NT>, lds);
+    if (rc != WM_OK) return rc;
+    attr = true;
+  }
+  attn_bwd<NT><<<B * H, AT_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), static_cast<const uint16_t*>(out),
+                                               static_cast<const uint16_t*>(dout), lse, S, H, scale,
+                                               static_cast<uint16_t*>(dqkv));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+inline bool at_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int wm_attention_fwd(const void* qkv, int B, int S, int H, float scale, void* out, float* lse,
+                                void* stream) {
+  WM_REQUIRE(qkv && out && lse, WM_EINVAL);
+  WM_REQUIRE(B > 0 && S > 0 && H > 0 && (long long)B * H < (1ll << 31), WM_EINVAL);
+  WM_REQUIRE(S <= 256, WM_EUNSUPPORTED);
+  WM_REQUIRE(at_al16(qkv) && at_al16(out), WM_EALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (S <= 32) return launch_fwd<2>(qkv, B, S, H, scale, out, lse, st);
+  if (S <= 64) return launch_fwd<4>(qkv, B, S, H, scale, out, lse, st);
+  if (S <= 128) return launch_fwd<8>(qkv, B, S, H, scale, out, lse, st);
+  if (S <= 224) return launch_fwd<14>(qkv, B, S, H, scale, out, lse, st);
+  return launch_fwd<16>(qkv, B, S, H, scale, out, lse, st);
+}
+
+extern "C" int wm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int S,
+                                int H, float scale, void* dqkv, void* stream) {
+  WM_REQUIRE(qkv && out && dout && lse && dqkv, WM_EINVAL);
+  WM_REQUIRE(B > 0 && S > 0 && H > 0 && (long long)B * H < (1ll << 31), WM_EINVAL);
+  WM_REQUIRE(S <= 256, WM_EUNSUPPORTED);
+  WM_REQUIRE(at_al16(qkv) && at_al16(out) && at_al16(dout) && at_al16(dqkv), WM_EALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (S <= 32) return launch_bwd<2>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  if (S <= 64) return launch_bwd<4>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  if (S <= 128) return launch_bwd<8>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  if (S <= 224) return launch_bwd<14>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  return launch_bwd<16>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+}

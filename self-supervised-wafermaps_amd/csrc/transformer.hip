@@ -1,0 +1,742 @@
+// Row-wise / elementwise kernels of the vision-transformer path (DINO ViT-S/16, MAE ViT-B/32).
+//
+// Replaces the torch.nn.LayerNorm / GELU / bias adds inside facebookresearch/dino's
+// VisionTransformer blocks and torchvision's vit_b_32 encoder blocks as the reference runs them
+// (scripts/WM811k_benchmark.py:548-550,566-588 DINOViT; :881-957 MAE), lightly's
+// get_at_index / set_at_index / patchify helpers (:911-947), torch.optim.AdamW (:591-598),
+// lightly.models.utils.update_momentum (:579-581) and torch.nn.MSELoss (:900).
+//
+// Activations are bf16 [rows][C] with rows = tokens; every kernel moves 16 bytes per lane.
+// Roofline: HBM (one read + one write of the activation per pass; reductions finish with f32 atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int TF_THREADS = 256;
+
+__device__ __forceinline__ void unpack8(const uint4 v, float (&f)[8]) {
+  f[0] = bf2f((uint16_t)(v.x & 0xffff)); f[1] = bf2f((uint16_t)(v.x >> 16));
+  f[2] = bf2f((uint16_t)(v.y & 0xffff)); f[3] = bf2f((uint16_t)(v.y >> 16));
+  f[4] = bf2f((uint16_t)(v.z & 0xffff)); f[5] = bf2f((uint16_t)(v.z >> 16));
+  f[6] = bf2f((uint16_t)(v.w & 0xffff)); f[7] = bf2f((uint16_t)(v.w >> 16));
+}
+__device__ __forceinline__ uint4 pack8(const float (&f)[8]) {
+  return make_uint4(pack_bf2(f[0], f[1]), pack_bf2(f[2], f[3]), pack_bf2(f[4], f[5]), pack_bf2(f[6], f[7]));
+}
+__device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
+  const float4 a = *reinterpret_cast<const float4*>(p), b = *reinterpret_cast<const float4*>(p + 4);
+  f[0] = a.x; f[1] = a.y; f[2] = a.z; f[3] = a.w; f[4] = b.x; f[5] = b.y; f[6] = b.z; f[7] = b.w;
+}
+
+// ------------------------------------------------------------------------------------ LayerNorm
+// One wave per row; a lane owns chunks lane, lane + 64, ... of 8 channels (C <= 2048 -> <= 4 chunks),
+// the row stays in registers between the mean, the variance and the output pass.
+constexpr int LN_MAXV = 4;
+
+__global__ __launch_bounds__(TF_THREADS) void ln_fwd(const uint16_t* __restrict__ x, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps, long long rows,
+                                                     int C, uint16_t* __restrict__ y, float* __restrict__ mean,
+                                                     float* __restrict__ rstd) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  const float inv_c = 1.f / (float)C;
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+    float v[LN_MAXV][8];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        unpack8(*reinterpret_cast<const uint4*>(x + row * C + ch * 8), v[i]);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += v[i][e];
+      }
+    }
+    const float mu = wave_sum(s) * inv_c;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      if (lane + 64 * i < nch) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = v[i][e] - mu;
+          q = fmaf(d, d, q);
+        }
+      }
+    }
+    const float r = rsqrtf(wave_sum(q) * inv_c + eps);
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float g[8], b[8], o[8];
+        load8f(gamma + ch * 8, g);
+        load8f(beta + ch * 8, b);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = fmaf((v[i][e] - mu) * r, g[e], b[e]);
+        *reinterpret_cast<uint4*>(y + row * C + ch * 8) = pack8(o);
+      }
+    }
+    if (lane == 0) {
+      mean[row] = mu;
+      rstd[row] = r;
+    }
+  }
+}
+
+__global__ __launch_bounds__(TF_THREADS) void ln_bwd(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
+                                                     const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, long long rows, int C,
+                                                     uint16_t* __restrict__ dx, float* __restrict__ dgamma,
+                                                     float* __restrict__ dbeta) {
+  __shared__ float red[2 * 2048];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 3;
+  const float inv_c = 1.f / (float)C;
+  float dg[LN_MAXV][8], db[LN_MAXV][8], gm[LN_MAXV][8];
+#pragma unroll
+  for (int i = 0; i < LN_MAXV; ++i) {
+    const int ch = lane + 64 * i;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = gm[i][e] = 0.f;
+    if (ch < nch) load8f(gamma + ch * 8, gm[i]);
+  }
+  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
+    const float mu = mean[row], r = rstd[row];
+    float xh[LN_MAXV][8], g[LN_MAXV][8];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float fx[8], fd[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + row * C + ch * 8), fx);
+        unpack8(*reinterpret_cast<const uint4*>(dy + row * C + ch * 8), fd);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          xh[i][e] = (fx[e] - mu) * r;
+          g[i][e] = fd[e] * gm[i][e];
+          s1 += g[i][e];
+          s2 = fmaf(g[i][e], xh[i][e], s2);
+          dg[i][e] = fmaf(fd[e], xh[i][e], dg[i][e]);
+          db[i][e] += fd[e];
+        }
+      }
+    }
+    const float c1 = wave_sum(s1) * inv_c, c2 = wave_sum(s2) * inv_c;
+#pragma unroll
+    for (int i = 0; i < LN_MAXV; ++i) {
+      const int ch = lane + 64 * i;
+      if (ch < nch) {
+        float o[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = r * (g[i][e] - c1 - xh[i][e] * c2);
+        *reinterpret_cast<uint4*>(dx + row * C + ch * 8) = pack8(o);
+      }
+    }
+  }
+  // per-channel sums: the four waves fold into LDS one after the other, then one atomic per channel
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < LN_MAXV; ++i) {
+        const int ch = lane + 64 * i;
+        if (ch < nch) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int c = ch * 8 + e;
+            red[c] = (w == 0 ? 0.f : red[c]) + dg[i][e];
+            red[2048 + c] = (w == 0 ? 0.f : red[2048 + c]) + db[i][e];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < C; c += TF_THREADS) {
+    atomicAdd(dgamma + c, red[c]);
+    atomicAdd(dbeta + c, red[2048 + c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ bias / GELU
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float gelu_grad(float v) {
+  return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
+}
+
+template <int ACT>
+__global__ __launch_bounds__(TF_THREADS) void bias_act_fwd(const uint16_t* __restrict__ x, const float* __restrict__ bias,
+                                                           const uint16_t* __restrict__ res, long long rows, int C,
+                                                           uint16_t* __restrict__ y) {
+  const int nch = C >> 3;
+  const long long total = rows * nch;
+  for (long long t = (long long)blockIdx.x * TF_THREADS + threadIdx.x; t < total;
+       t += (long long)gridDim.x * TF_THREADS) {
+    const int ch = (int)(t % nch);
+    float f[8], b[8];
+    unpack8(*reinterpret_cast<const uint4*>(x + t * 8), f);
+    if (bias != nullptr) {
+      load8f(bias + ch * 8, b);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += b[e];
+    }
+    if (ACT == WM_ACT_GELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = gelu_f(f[e]);
+    }
+    if (res != nullptr) {
+      float r[8];
+      unpack8(*reinterpret_cast<const uint4*>(res + t * 8), r);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] += r[e];
+    }
+    *reinterpret_cast<uint4*>(y + t * 8) = pack8(f);
+  }
+}
+
+// Column slabs of CB chunks (8 channels each) x RL row lanes per block: a thread keeps its chunk and
+// walks rows, so the per-channel sums stay in registers until the end of the block.
+// MODE 0: colsum of src only.  MODE 1: dx = dy (identity act) is not written, colsum of dy.
+// MODE 2: GELU: dx = dy * gelu'(x + bias), colsum of dx.
+template <int MODE>
+__global__ __launch_bounds__(TF_THREADS) void colsum_kernel(const uint16_t* __restrict__ x, const float* __restrict__ bias,
+                                                            const uint16_t* __restrict__ dy, long long rows, int C,
+                                                            int CB, int rows_per_block, uint16_t* __restrict__ dx,
+                                                            float* __restrict__ out) {
+  __shared__ float red[TF_THREADS * 8];
+  const int nch = C >> 3;
+  const int RL = TF_THREADS / CB;
+  const int cl = threadIdx.x % CB, rl = threadIdx.x / CB;
+  const int ch = blockIdx.y * CB + cl;
+  const bool on = rl < RL && ch < nch;
+  float acc[8], b[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) acc[e] = b[e] = 0.f;
+  if (on) {
+    if (MODE == 2 && bias != nullptr) load8f(bias + ch * 8, b);
+    const long long r0 = (long long)blockIdx.x * rows_per_block;
+    long long r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    for (long long r = r0 + rl; r < r1; r += RL) {
+      const size_t off = (size_t)r * C + ch * 8;
+      float fd[8];
+      unpack8(*reinterpret_cast<const uint4*>(dy + off), fd);
+      if (MODE == 2) {
+        float fx[8];
+        unpack8(*reinterpret_cast<const uint4*>(x + off), fx);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fd[e] *= gelu_grad(fx[e] + b[e]);
+        const uint4 pk = pack8(fd);
+        *reinterpret_cast<uint4*>(dx + off) = pk;
+        unpack8(pk, fd);  // the sums see the rounded gradient, like a separate reduction would
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) acc[e] += fd[e];
+    }
+  }
+  if (out == nullptr) return;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = on ? acc[e] : 0.f;
+  __syncthreads();
+  if (rl == 0 && ch < nch) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      float s = 0.f;
+      for (int j = 0; j < RL; ++j) s += red[(j * CB + cl) * 8 + e];
+      atomicAdd(out + ch * 8 + e, s);
+    }
+  }
+}
+
+__global__ __launch_bounds__(TF_THREADS) void zero_f32(float* p, long long n) {
+  for (long long i = (long long)blockIdx.x * TF_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * TF_THREADS)
+    p[i] = 0.f;
+}
+
+template <int MODE>
+int launch_colsum(const void* x, const float* bias, const void* dy, long long rows, int C, void* dx, float* out,
+                  hipStream_t st) {
+  const int nch = C >> 3;
+  const int CB = nch <= 64 ? nch : 64;
+  const int slabs = wm_cdiv(nch, CB);
+  // ~2048 blocks in total, at least 64 rows each
+  int rb = wm_cdiv(2048, slabs);
+  long long rpb = (rows + rb - 1) / rb;
+  if (rpb < 64) rpb = 64;
+  rb = wm_cdiv(rows, rpb);
+  dim3 grid(rb, slabs);
+  colsum_kernel<MODE><<<grid, TF_THREADS, 0, st>>>(static_cast<const uint16_t*>(x), bias,
+                                                    static_cast<const uint16_t*>(dy), rows, C, CB, (int)rpb,
+                                                    static_cast<uint16_t*>(dx), out);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+// ------------------------------------------------------------------------------------ tokens
+__global__ __launch_bounds__(TF_THREADS) void tokens_assemble(const uint16_t* __restrict__ patches,
+                                                              const float* __restrict__ cls, const float* __restrict__ pos,
+                                                              int N, int np, int D, uint16_t* __restrict__ tokens) {
+  const int nch = D >> 3;
+  const long long total = (long long)N * (np + 1) * nch;
+  for (long long t = (long long)blockIdx.x * TF_THREADS + threadIdx.x; t < total;
+       t += (long long)gridDim.x * TF_THREADS) {
+    const int ch = (int)(t % nch);
+    const long long tok = t / nch;
+    const int s = (int)(tok % (np + 1));
+    const long long n = tok / (np + 1);
+    float f[8], p[8];
+    load8f(pos + (size_t)s * D + ch * 8, p);
+    if (s == 0) {
+      load8f(cls + ch * 8, f);
+    } else {
+      unpack8(*reinterpret_cast<const uint4*>(patches + ((size_t)(n * np + s - 1) * D + ch * 8)), f);
+    }
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] += p[e];
+    *reinterpret_cast<uint4*>(tokens + (size_t)tok * D + ch * 8) = pack8(f);
+  }
+}
+
+// [N][S][S][3] -> [N * (S/p)^2][p][p][3]: a patch row is p pixels x 3 channels = 6p contiguous bytes
+// (p = 16: 96 B = 6 chunks of 16 B; p = 32: 12 chunks), copied 16 bytes per lane.
+__global__ __launch_bounds__(TF_THREADS) void patchify_kernel(const uint16_t* __restrict__ img, int N, int S, int p,
+                                                              uint16_t* __restrict__ rows) {
+  const int g = S / p;
+  const int cpr = (p * 3) >> 3;  // 16-byte chunks per patch row
+  const long long total = (long long)N * g * g * p * cpr;
+  for (long long t = (long long)blockIdx.x * TF_THREADS + threadIdx.x; t < total;
+       t += (long long)gridDim.x * TF_THREADS) {
+    const int c = (int)(t % cpr);
+    long long u = t / cpr;
+    const int ph = (int)(u % p);
+    u /= p;
+    const int gx = (int)(u % g);
+    u /= g;
+    const int gy = (int)(u % g);
+    const long long n = u / g;
+    const size_t src = (((size_t)n * S + gy * p + ph) * S + gx * p) * 3 + c * 8;
+    *reinterpret_cast<uint4*>(rows + (size_t)t * 8) = *reinterpret_cast<const uint4*>(img + src);
+  }
+}
+
+template <bool SCATTER>
+__global__ __launch_bounds__(TF_THREADS) void rows_by_index(const uint16_t* __restrict__ src,
+                                                            const long long* __restrict__ idx, int B, int S, int K,
+                                                            int C, uint16_t* __restrict__ dst) {
+  const int nch = C >> 3;
+  const long long total = (long long)B * K * nch;
+  for (long long t = (long long)blockIdx.x * TF_THREADS + threadIdx.x; t < total;
+       t += (long long)gridDim.x * TF_THREADS) {
+    const int ch = (int)(t % nch);
+    const long long bk = t / nch;
+    const long long b = bk / K;
+    const long long s = idx[bk];
+    if (s < 0 || s >= S) continue;
+    const size_t big = ((size_t)b * S + s) * C + ch * 8, small = (size_t)bk * C + ch * 8;
+    if (SCATTER) *reinterpret_cast<uint4*>(dst + big) = *reinterpret_cast<const uint4*>(src + small);
+    else *reinterpret_cast<uint4*>(dst + small) = *reinterpret_cast<const uint4*>(src + big);
+  }
+}
+
+__global__ __launch_bounds__(TF_THREADS) void mse_kernel(const uint16_t* __restrict__ pred,
+                                                         const uint16_t* __restrict__ target, long long n,
+                                                         float* __restrict__ loss, uint16_t* __restrict__ dpred) {
+  __shared__ float red[4];
+  const float inv = 1.f / (float)n;
+  float s = 0.f;
+  const long long nch = n >> 3;
+  for (long long t = (long long)blockIdx.x * TF_THREADS + threadIdx.x; t < nch; t += (long long)gridDim.x * TF_THREADS) {
+    float a[8], b[8], d[8];
+    unpack8(*reinterpret_cast<const uint4*>(pred + t * 8), a);
+    unpack8(*reinterpret_cast<const uint4*>(target + t * 8), b);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const float df = a[e] - b[e];
+      s = fmaf(df, df, s);
+      d[e] = 2.f * df * inv;
+    }
+    *reinterpret_cast<uint4*>(dpred + t * 8) = pack8(d);
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+
+// ------------------------------------------------------------------------------------ DINO loss
+// One block per row of D logits (D <= 256 * 8 * DL_MAXV); the row stays in registers.
+constexpr int DL_MAXV = 4;  // D <= 8192 (bf16 rows) / f32 prob rows are streamed
+
+__device__ __forceinline__ float block_reduce(float v, float* red, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(TF_THREADS) void dino_teacher_probs(const uint16_t* __restrict__ t,
+                                                                 const float* __restrict__ center, float inv_temp,
+                                                                 int D, float* __restrict__ probs) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const int nch = D >> 3;
+  float v[DL_MAXV][8];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i) {
+    const int ch = threadIdx.x + TF_THREADS * i;
+    if (ch < nch) {
+      float c[8];
+      unpack8(*reinterpret_cast<const uint4*>(t + row * D + ch * 8), v[i]);
+      load8f(center + ch * 8, c);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = (v[i][e] - c[e]) * inv_temp;
+        m = fmaxf(m, v[i][e]);
+      }
+    }
+  }
+  m = block_reduce(m, red, true);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i) {
+    if (threadIdx.x + TF_THREADS * i < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = expf(v[i][e] - m);
+        s += v[i][e];
+      }
+    }
+  }
+  s = 1.f / block_reduce(s, red, false);
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i) {
+    const int ch = threadIdx.x + TF_THREADS * i;
+    if (ch < nch) {
+      float* o = probs + row * D + ch * 8;
+      *reinterpret_cast<float4*>(o) = make_float4(v[i][0] * s, v[i][1] * s, v[i][2] * s, v[i][3] * s);
+      *reinterpret_cast<float4*>(o + 4) = make_float4(v[i][4] * s, v[i][5] * s, v[i][6] * s, v[i][7] * s);
+    }
+  }
+}
+
+// block = (student view s, sample b).  lsm = x/T - lse;  for every teacher view t != s:
+//   loss -= <p_t, lsm> * w;   dx += w/T * (softmax(x/T) - p_t),   w = 1 / (n_terms * B)
+__global__ __launch_bounds__(TF_THREADS) void dino_loss_kernel(const uint16_t* __restrict__ student,
+                                                               const float* __restrict__ probs, int Vs, int Vt, int B,
+                                                               int D, float inv_temp, float w, float* __restrict__ loss,
+                                                               uint16_t* __restrict__ dstudent) {
+  __shared__ float red[4];
+  const int s = blockIdx.x / B, b = blockIdx.x % B;
+  const long long row = (long long)s * B + b;
+  const int nch = D >> 3;
+  float v[DL_MAXV][8];
+  float m = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i) {
+    const int ch = threadIdx.x + TF_THREADS * i;
+    if (ch < nch) {
+      unpack8(*reinterpret_cast<const uint4*>(student + row * D + ch * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] *= inv_temp;
+        m = fmaxf(m, v[i][e]);
+      }
+    }
+  }
+  m = block_reduce(m, red, true);
+  float sum = 0.f;
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i) {
+    if (threadIdx.x + TF_THREADS * i < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sum += expf(v[i][e] - m);
+    }
+  }
+  sum = block_reduce(sum, red, false);
+  const float lse = m + logf(sum);
+  float dot = 0.f;
+  int nt = 0;
+  float g[DL_MAXV][8];
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i)
+#pragma unroll
+    for (int e = 0; e < 8; ++e) g[i][e] = 0.f;
+  for (int t = 0; t < Vt; ++t) {
+    if (t == s) continue;
+    ++nt;
+    const float* p = probs + ((size_t)t * B + b) * D;
+#pragma unroll
+    for (int i = 0; i < DL_MAXV; ++i) {
+      const int ch = threadIdx.x + TF_THREADS * i;
+      if (ch < nch) {
+        float pv[8];
+        load8f(p + ch * 8, pv);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          dot = fmaf(pv[e], v[i][e] - lse, dot);
+          g[i][e] -= pv[e];
+        }
+      }
+    }
+  }
+  dot = block_reduce(dot, red, false);
+  if (threadIdx.x == 0) atomicAdd(loss, -dot * w);
+  const float k = w * inv_temp;
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i) {
+    const int ch = threadIdx.x + TF_THREADS * i;
+    if (ch < nch) {
+      float o[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = k * ((float)nt * expf(v[i][e] - lse) + g[i][e]);
+      *reinterpret_cast<uint4*>(dstudent + row * D + ch * 8) = pack8(o);
+    }
+  }
+}
+
+// center[d] = m * center[d] + (1 - m) * mean_rows teacher[r][d].  One block per 32 columns.
+__global__ __launch_bounds__(TF_THREADS) void dino_center_kernel(const uint16_t* __restrict__ t, long long rows, int D,
+                                                                 float momentum, float* __restrict__ center) {
+  __shared__ float red[8][33];
+  const int c = blockIdx.x * 32 + (threadIdx.x & 31), rl = threadIdx.x >> 5;
+  float s = 0.f;
+  if (c < D)
+    for (long long r = rl; r < rows; r += 8) s += bf2f(t[r * D + c]);
+  red[rl][threadIdx.x & 31] = s;
+  __syncthreads();
+  if (rl == 0 && c < D) {
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tot += red[j][threadIdx.x & 31];
+    center[c] = momentum * center[c] + (1.f - momentum) * tot / (float)rows;
+  }
+}
+
+// ------------------------------------------------------------------------------------ optimiser
+__global__ __launch_bounds__(TF_THREADS) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                           float* __restrict__ m, float* __restrict__ v, long long n,
+                                                           const float* __restrict__ hyper) {
+  const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5],
+              bc2s = sqrtf(hyper[6]), gs = hyper[7];
+  const float step = lr / bc1;
+  for (long long i = (long long)blockIdx.x * TF_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * TF_THREADS) {
+    const float gi = g[i] * gs;
+    float pi = p[i] * (1.f - lr * wd);
+    const float mi = b1 * m[i] + (1.f - b1) * gi;
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    pi -= step * mi / (sqrtf(vi) / bc2s + eps);
+    p[i] = pi;
+    m[i] = mi;
+    v[i] = vi;
+  }
+}
+
+__global__ __launch_bounds__(TF_THREADS) void ema_kernel(float* __restrict__ ema, const float* __restrict__ p, long long n,
+                                                         float m) {
+  for (long long i = (long long)blockIdx.x * TF_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * TF_THREADS)
+    ema[i] = ema[i] * m + p[i] * (1.f - m);
+}
+
+inline int ew_blocks(long long work) {
+  long long b = (work + TF_THREADS - 1) / TF_THREADS;
+  if (b > 8192) b = 8192;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace
+
+extern "C" int wm_layernorm_fwd(const void* x, const float* gamma, const float* beta, float eps, long long rows, int C,
+                                void* y, float* mean, float* rstd, void* stream) {
+  WM_REQUIRE(x && gamma && beta && y && mean && rstd, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(C <= 64 * 8 * LN_MAXV, WM_EUNSUPPORTED);
+  WM_REQUIRE(al16(x) && al16(y) && al16(gamma) && al16(beta), WM_EALIGN);
+  long long blocks = (rows + 3) / 4;
+  if (blocks > 4096) blocks = 4096;
+  ln_fwd<<<(int)blocks, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(x), gamma, beta, eps, rows, C, static_cast<uint16_t*>(y), mean, rstd);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean,
+                                const float* rstd, long long rows, int C, void* dx, float* dgamma, float* dbeta,
+                                void* stream) {
+  WM_REQUIRE(x && dy && gamma && mean && rstd && dx && dgamma && dbeta, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(C <= 64 * 8 * LN_MAXV, WM_EUNSUPPORTED);
+  WM_REQUIRE(al16(x) && al16(dy) && al16(dx) && al16(gamma), WM_EALIGN);
+  long long blocks = (rows + 3) / 4;
+  if (blocks > 1024) blocks = 1024;
+  ln_bwd<<<(int)blocks, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), gamma, mean, rstd, rows, C,
+      static_cast<uint16_t*>(dx), dgamma, dbeta);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_bias_act_fwd(const void* x, const float* bias, const void* residual, int act, long long rows, int C,
+                               void* y, void* stream) {
+  WM_REQUIRE(x && y, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(act == WM_ACT_NONE || act == WM_ACT_GELU, WM_EUNSUPPORTED);
+  WM_REQUIRE(al16(x) && al16(y) && al16(bias) && al16(residual), WM_EALIGN);
+  const int blocks = ew_blocks(rows * (C >> 3));
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (act == WM_ACT_GELU)
+    bias_act_fwd<WM_ACT_GELU><<<blocks, TF_THREADS, 0, st>>>(static_cast<const uint16_t*>(x), bias,
+                                                             static_cast<const uint16_t*>(residual), rows, C,
+                                                             static_cast<uint16_t*>(y));
+  else
+    bias_act_fwd<WM_ACT_NONE><<<blocks, TF_THREADS, 0, st>>>(static_cast<const uint16_t*>(x), bias,
+                                                             static_cast<const uint16_t*>(residual), rows, C,
+                                                             static_cast<uint16_t*>(y));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_bias_act_bwd(const void* x, const float* bias, const void* dy, int act, long long rows, int C,
+                               void* dx, float* dbias, void* stream) {
+  WM_REQUIRE(dy, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(al16(x) && al16(dy) && al16(dx) && al16(bias), WM_EALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (act == WM_ACT_NONE) {
+    if (dbias == nullptr) return WM_OK;
+    return launch_colsum<1>(nullptr, nullptr, dy, rows, C, nullptr, dbias, st);
+  }
+  WM_REQUIRE(act == WM_ACT_GELU, WM_EUNSUPPORTED);
+  WM_REQUIRE(x && dx, WM_EINVAL);
+  return launch_colsum<2>(x, bias, dy, rows, C, dx, dbias, st);
+}
+
+extern "C" int wm_colsum_bf16(const void* x, long long rows, int C, float* out, int accumulate, void* stream) {
+  WM_REQUIRE(x && out, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(al16(x), WM_EALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (!accumulate) {
+    zero_f32<<<ew_blocks(C), TF_THREADS, 0, st>>>(out, C);
+    WM_LAUNCH_CHECK();
+  }
+  return launch_colsum<1>(nullptr, nullptr, x, rows, C, nullptr, out, st);
+}
+
+extern "C" int wm_tokens_assemble(const void* patches, const float* cls, const float* pos, int N, int np, int D,
+                                  void* tokens, void* stream) {
+  WM_REQUIRE(patches && cls && pos && tokens, WM_EINVAL);
+  WM_REQUIRE(N > 0 && np > 0 && D > 0 && D % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(al16(patches) && al16(cls) && al16(pos) && al16(tokens), WM_EALIGN);
+  tokens_assemble<<<ew_blocks((long long)N * (np + 1) * (D >> 3)), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(patches), cls, pos, N, np, D, static_cast<uint16_t*>(tokens));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_patchify(const void* images, int N, int S, int p, void* rows, void* stream) {
+  WM_REQUIRE(images && rows, WM_EINVAL);
+  WM_REQUIRE(N > 0 && S > 0 && p > 0 && S % p == 0 && (p * 3) % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(al16(images) && al16(rows), WM_EALIGN);
+  const int g = S / p;
+  patchify_kernel<<<ew_blocks((long long)N * g * g * p * ((p * 3) >> 3)), TF_THREADS, 0,
+                    static_cast<hipStream_t>(stream)>>>(static_cast<const uint16_t*>(images), N, S, p,
+                                                        static_cast<uint16_t*>(rows));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_gather_rows(const void* x, const long long* idx, int B, int S, int K, int C, void* out,
+                              void* stream) {
+  WM_REQUIRE(x && idx && out, WM_EINVAL);
+  WM_REQUIRE(B > 0 && S > 0 && K > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(al16(x) && al16(out), WM_EALIGN);
+  rows_by_index<false><<<ew_blocks((long long)B * K * (C >> 3)), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(x), idx, B, S, K, C, static_cast<uint16_t*>(out));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_scatter_rows(const void* src, const long long* idx, int B, int S, int K, int C, void* dst,
+                               void* stream) {
+  WM_REQUIRE(src && idx && dst, WM_EINVAL);
+  WM_REQUIRE(B > 0 && S > 0 && K > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(al16(src) && al16(dst), WM_EALIGN);
+  rows_by_index<true><<<ew_blocks((long long)B * K * (C >> 3)), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(src), idx, B, S, K, C, static_cast<uint16_t*>(dst));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_mse_fwd_bwd(const void* pred, const void* target, long long n, float* loss, void* dpred,
+                              void* stream) {
+  WM_REQUIRE(pred && target && loss && dpred, WM_EINVAL);
+  WM_REQUIRE(n > 0 && n % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(al16(pred) && al16(target) && al16(dpred), WM_EALIGN);
+  mse_kernel<<<ew_blocks(n >> 3) > 1024 ? 1024 : ew_blocks(n >> 3), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(pred), static_cast<const uint16_t*>(target), n, loss,
+      static_cast<uint16_t*>(dpred));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_dino_teacher_probs(const void* teacher, const float* center, float temp_t, long long rows, int D,
+                                     float* probs, void* stream) {
+  WM_REQUIRE(teacher && center && probs, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && rows < (1ll << 31) && D > 0 && D % 8 == 0 && temp_t > 0.f, WM_EINVAL);
+  WM_REQUIRE(D <= TF_THREADS * 8 * DL_MAXV, WM_EUNSUPPORTED);
+  WM_REQUIRE(al16(teacher) && al16(center) && al16(probs), WM_EALIGN);
+  dino_teacher_probs<<<(int)rows, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(teacher), center, 1.f / temp_t, D, probs);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_dino_loss_fwd_bwd(const void* student, const float* probs, int Vs, int Vt, int B, int D,
+                                    float temp_s, float* loss, void* dstudent, void* stream) {
+  WM_REQUIRE(student && probs && loss && dstudent, WM_EINVAL);
+  WM_REQUIRE(Vs > 0 && Vt > 0 && B > 0 && D > 0 && D % 8 == 0 && temp_s > 0.f, WM_EINVAL);
+  WM_REQUIRE(D <= TF_THREADS * 8 * DL_MAXV, WM_EUNSUPPORTED);
+  WM_REQUIRE(al16(student) && al16(probs) && al16(dstudent), WM_EALIGN);
+  const int ndiag = Vs < Vt ? Vs : Vt;
+  const int n_terms = Vs * Vt - ndiag;
+  WM_REQUIRE(n_terms > 0, WM_EINVAL);
+  const float w = 1.f / ((float)n_terms * (float)B);
+  dino_loss_kernel<<<Vs * B, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(student), probs, Vs, Vt, B, D, 1.f / temp_s, w, loss,
+      static_cast<uint16_t*>(dstudent));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_dino_center_update(const void* teacher, long long rows, int D, float momentum, float* center,
+                                     void* stream) {
+  WM_REQUIRE(teacher && center, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && D > 0, WM_EINVAL);
+  dino_center_kernel<<<wm_cdiv(D, 32), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(teacher), rows, D, momentum, center);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
+                             const float* hyper, void* stream) {
+  WM_REQUIRE(params && grads && exp_avg && exp_avg_sq && hyper, WM_EINVAL);
+  WM_REQUIRE(n > 0, WM_EINVAL);
+  adamw_kernel<<<ew_blocks(n), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(params, grads, exp_avg, exp_avg_sq, n,
+                                                                                  hyper);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_ema_update(float* ema, const float* params, long long n, float m, void* stream) {
+  WM_REQUIRE(ema && params, WM_EINVAL);
+  WM_REQUIRE(n > 0, WM_EINVAL);
+  ema_kernel<<<ew_blocks(n), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(ema, params, n, m);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

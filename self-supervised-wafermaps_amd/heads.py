@@ -4,9 +4,12 @@ from __future__ import annotations
 
 from typing import List, Optional, Tuple
 
+import torch
 import torch.nn as nn
 
+from . import functional as F_hip
 from . import nn as hnn
+from . import ops, vit_ops
 
 
 class ProjectionHead(nn.Module):
@@ -27,15 +30,24 @@ class ProjectionHead(nn.Module):
                 i_bn = len(layers) - 1
             if act:
                 layers.append(act)
-            self._plan.append((i_lin, i_bn, act is not None))
+            self._plan.append((i_lin, i_bn, act))
         self.layers = nn.Sequential(*layers)
 
     def forward(self, x):
-        for i_lin, i_bn, relu in self._plan:
-            x = self.layers[i_lin](x)
-            if i_bn is None:
-                raise NotImplementedError("heads without batch norm need a bias/activation kernel (not built yet)")
-            x = self.layers[i_bn](x, relu=relu)
+        for i_lin, i_bn, act in self._plan:
+            lin = self.layers[i_lin]
+            if i_bn is not None:
+                x = lin(x)
+                if isinstance(act, hnn.GELU):
+                    x = act(self.layers[i_bn](x, relu=False))
+                else:
+                    x = self.layers[i_bn](x, relu=act is not None)
+            elif isinstance(act, hnn.GELU):
+                x = lin(x, act=vit_ops.ACT_GELU)
+            elif act is not None:
+                raise NotImplementedError("bias + ReLU epilogue is not built (no reference head on this path uses it)")
+            else:
+                x = lin(x)
         return x
 
 
@@ -52,3 +64,52 @@ class SimCLRProjectionHead(ProjectionHead):
             blocks.append((hidden_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.ReLU()))
         blocks.append((hidden_dim, output_dim, hnn.BatchNorm1d(output_dim), None))
         super().__init__(blocks)
+
+
+class DINOProjectionHead(ProjectionHead):
+    """lightly.models.modules.heads.DINOProjectionHead (reference: scripts/WM811k_benchmark.py:553-559,
+    MixedWM38_pretrain.py:146-152): Linear-[BN]-GELU x2, Linear -> bottleneck, L2-normalise,
+    weight-normalised bias-free Linear with the gain frozen at 1.  As in lightly, ONE BatchNorm1d
+    instance serves both hidden blocks (state_dict keys layers.1.* and layers.4.* alias)."""
+
+    def __init__(self, input_dim: int = 2048, hidden_dim: int = 2048, bottleneck_dim: int = 256, output_dim: int = 65536,
+                 batch_norm: bool = False, freeze_last_layer: int = -1, norm_last_layer: bool = True):
+        bn = hnn.BatchNorm1d(hidden_dim) if batch_norm else None
+        super().__init__([(input_dim, hidden_dim, bn, hnn.GELU()), (hidden_dim, hidden_dim, bn, hnn.GELU()),
+                          (hidden_dim, bottleneck_dim, None, None)])
+        for m in self.modules():
+            if isinstance(m, hnn.Linear):
+                nn.init.trunc_normal_(m.weight, std=0.02)
+                if m.bias is not None:
+                    nn.init.constant_(m.bias, 0)
+        self.freeze_last_layer = freeze_last_layer
+        self.last_layer = _WeightNormLinear(bottleneck_dim, output_dim, train_gain=not norm_last_layer)
+
+    def cancel_last_layer_gradients(self, current_epoch: int) -> None:
+        if current_epoch >= self.freeze_last_layer:
+            return
+        for p in self.last_layer.parameters():
+            p.grad = None
+
+    def forward(self, x):
+        x = super().forward(x)
+        x = F_hip.l2_normalize(x)
+        return self.last_layer(x)
+
+
+class _WeightNormLinear(nn.Module):
+    """torch.nn.utils.weight_norm(nn.Linear(in, out, bias=False)) with parameters weight_g [out, 1]
+    (filled with 1) and weight_v [out, in]: W = g * v / ||v||_row."""
+
+    def __init__(self, in_features: int, out_features: int, train_gain: bool = False):
+        super().__init__()
+        v = torch.empty(out_features, in_features)
+        nn.init.kaiming_uniform_(v, a=5 ** 0.5)
+        self.weight_g = nn.Parameter(torch.ones(out_features, 1), requires_grad=train_gain)
+        self.weight_v = nn.Parameter(v)
+        if train_gain:
+            raise NotImplementedError("DINOProjectionHead(norm_last_layer=False): trainable gain has no HIP path yet")
+
+    def forward(self, x):
+        w = F_hip.l2_normalize(self.weight_v, eps=0.0)  # gain frozen at 1
+        return ops.linear(x, w)

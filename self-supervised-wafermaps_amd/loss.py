@@ -73,3 +73,56 @@ class NTXentLoss(nn.Module):
         z = torch.cat([out0, out1], dim=0).float().contiguous()
         zn = F_hip.l2_normalize(z)
         return _NTXentCore.apply(zn, b, self.temperature, self.gather_distributed)
+
+
+class DINOLoss(nn.Module):
+    """lightly.loss.DINOLoss as the reference calls it (scripts/WM811k_benchmark.py:564,586:
+    `DINOLoss(output_dim=2048)`, `criterion(teacher_out, student_out, epoch=...)`).
+
+    teacher_out / student_out: lists of [B, D] tensors (the reference's form) or already stacked
+    view-major [V*B, D] tensors with `batch=B`.  Views with the same list index are the same crop
+    and are skipped (lightly zeroes the diagonal of the [teacher view, student view] loss matrix).
+    The centre is updated after the loss, from this step's teacher outputs; under
+    torch.distributed the batch mean is all-reduced first, as lightly does."""
+
+    def __init__(self, output_dim: int = 65536, warmup_teacher_temp: float = 0.04, teacher_temp: float = 0.04,
+                 warmup_teacher_temp_epochs: int = 30, student_temp: float = 0.1, center_momentum: float = 0.9):
+        super().__init__()
+        self.warmup_teacher_temp_epochs = warmup_teacher_temp_epochs
+        self.teacher_temp = teacher_temp
+        self.student_temp = student_temp
+        self.center_momentum = center_momentum
+        self.register_buffer("center", torch.zeros(1, 1, output_dim))
+        self.teacher_temp_schedule = torch.linspace(warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs)
+
+    def forward(self, teacher_out, student_out, epoch: int, batch: int = None):
+        from . import vit_ops
+
+        if isinstance(teacher_out, (list, tuple)):
+            vt, batch = len(teacher_out), teacher_out[0].shape[0]
+            teacher = torch.cat([t.detach() for t in teacher_out], dim=0)
+        else:
+            teacher, vt = teacher_out.detach(), teacher_out.shape[0] // batch
+        if isinstance(student_out, (list, tuple)):
+            vs = len(student_out)
+            student = torch.cat(list(student_out), dim=0)
+        else:
+            student, vs = student_out, student_out.shape[0] // batch
+        temp = float(self.teacher_temp_schedule[epoch]) if epoch < self.warmup_teacher_temp_epochs else self.teacher_temp
+        probs = vit_ops.dino_teacher_probs(teacher, self.center, temp)
+        loss = vit_ops.dino_loss(student, probs, vs, vt, batch, self.student_temp)
+        self.update_center(teacher)
+        return loss
+
+    @torch.no_grad()
+    def update_center(self, teacher: torch.Tensor) -> None:
+        from . import vit_ops
+
+        if _world() > 1:
+            # lightly: batch_center = mean over (views, batch), all-reduced and divided by world size
+            mean = teacher.float().mean(dim=0, keepdim=True)
+            dist.all_reduce(mean)
+            mean /= _world()
+            self.center.mul_(self.center_momentum).add_(mean.view_as(self.center), alpha=1 - self.center_momentum)
+        else:
+            vit_ops.dino_center_update(self.center, teacher, self.center_momentum)

@@ -1,3 +1,5 @@
 from .knn import KNNBenchmarkModule, macro_metrics  # noqa: F401
 from .resnet import ResNet18, create_model  # noqa: F401
 from .simclr import SimCLR  # noqa: F401
+from .vit import VisionTransformer, vit_base, vit_small  # noqa: F401
+from .dino import DINOViT  # noqa: F401

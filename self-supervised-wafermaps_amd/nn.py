@@ -6,7 +6,7 @@ import math
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import ops, vit_ops
 
 
 class Conv2d(nn.Module):
@@ -76,19 +76,43 @@ class BatchNorm1d(_BatchNorm):
 
 
 class Linear(nn.Module):
-    """Bias-free linear layer (the heads the reference uses pair every Linear with a BatchNorm,
-    lightly: `bias = not batch_norm`)."""
+    """nn.Linear: weight float32 [out, in], optional bias; x bf16 [rows, in].  The bias, an optional
+    GELU and an optional residual add run as one epilogue pass after the GEMM kernel."""
 
     def __init__(self, in_features, out_features, bias=False):
         super().__init__()
-        if bias:
-            raise NotImplementedError("Linear with bias has no HIP path yet (heads with batch_norm=False)")
         self.in_features, self.out_features = in_features, out_features
         self.weight = nn.Parameter(torch.empty(out_features, in_features))
         nn.init.kaiming_uniform_(self.weight, a=math.sqrt(5))  # nn.Linear default
+        if bias:
+            bound = 1 / math.sqrt(in_features)
+            self.bias = nn.Parameter(torch.empty(out_features).uniform_(-bound, bound))
+        else:
+            self.register_parameter("bias", None)
+
+    def forward(self, x, act: int = vit_ops.ACT_NONE, residual=None):
+        if self.bias is None and act == vit_ops.ACT_NONE and residual is None:
+            return ops.linear(x, self.weight)
+        return vit_ops.linear(x, self.weight, self.bias, act, residual)
+
+
+class LayerNorm(nn.Module):
+    def __init__(self, normalized_shape, eps=1e-5):
+        super().__init__()
+        self.normalized_shape, self.eps = int(normalized_shape), eps
+        self.weight = nn.Parameter(torch.ones(normalized_shape))
+        self.bias = nn.Parameter(torch.zeros(normalized_shape))
 
     def forward(self, x):
-        return ops.linear(x, self.weight)
+        return vit_ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+
+class GELU(nn.Module):
+    """Marker module: exact (erf) GELU, fused into the preceding Linear's epilogue pass or applied
+    by ProjectionHead after a BatchNorm."""
+
+    def forward(self, x):
+        return vit_ops.bias_act(x, None, vit_ops.ACT_GELU)
 
 
 class ReLU(nn.Module):

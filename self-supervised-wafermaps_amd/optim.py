@@ -19,7 +19,7 @@ _ALIGN = 64  # elements: every parameter starts on a 256-byte boundary
 
 
 class _Arena:
-    def __init__(self, params: List[torch.nn.Parameter]):
+    def __init__(self, params: List[torch.nn.Parameter], second_moment: bool = False):
         dev = params[0].device
         if dev.type != "cuda":
             raise _lib.WaferHipError("fused SGD needs parameters on the GPU")
@@ -33,6 +33,7 @@ class _Arena:
         self.params = torch.zeros(total, dtype=torch.float32, device=dev)
         self.grads = torch.zeros(total, dtype=torch.float32, device=dev)
         self.momentum = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.second = torch.zeros(total, dtype=torch.float32, device=dev) if second_moment else None
         with torch.no_grad():
             for p, o in zip(params, offs):
                 n = p.numel()
@@ -78,5 +79,50 @@ class SGD(torch.optim.Optimizer):
                 self._hyper_host[i] = h
             check(lib.wm_sgd_step(ptr(arena.params), ptr(arena.grads), ptr(arena.momentum), arena.numel, ptr(hyper),
                                   stream_ptr()), "wm_sgd_step")
+        ops.bump_weight_epoch()
+        return loss
+
+
+class AdamW(torch.optim.Optimizer):
+    """torch.optim.AdamW's update (decoupled weight decay, bias-corrected moments, no amsgrad — what
+    the reference's DINOViT and MAE use, scripts/WM811k_benchmark.py:591-598, :956-963) in one launch
+    per parameter group over flat float32 arenas."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
+                 grad_scale: float = 1.0):
+        if lr < 0 or eps < 0 or weight_decay < 0 or not 0 <= betas[0] < 1 or not 0 <= betas[1] < 1:
+            raise ValueError("invalid AdamW hyper-parameter")
+        super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
+        self.grad_scale = float(grad_scale)
+        self._arenas, self._hyper, self._steps = [], [], []
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            arena = _Arena(ps, second_moment=True)
+            self._arenas.append(arena)
+            self._hyper.append(torch.zeros(8, dtype=torch.float32, device=arena.params.device))
+            self._steps.append(0)
+        ops.bump_weight_epoch()
+
+    @property
+    def grad_arenas(self) -> List[torch.Tensor]:
+        return [a.grads for a in self._arenas]
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        for a in self._arenas:
+            a.grads.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        lib = _lib.load()
+        for i, (group, arena, hyper) in enumerate(zip(self.param_groups, self._arenas, self._hyper)):
+            self._steps[i] += 1
+            t = self._steps[i]
+            b1, b2 = group["betas"]
+            h = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
+                 1.0 - b1 ** t, 1.0 - b2 ** t, self.grad_scale)
+            hyper.copy_(torch.tensor(h, dtype=torch.float32), non_blocking=False)
+            check(lib.wm_adamw_step(ptr(arena.params), ptr(arena.grads), ptr(arena.momentum), ptr(arena.second),
+                                    arena.numel, ptr(hyper), stream_ptr()), "wm_adamw_step")
         ops.bump_weight_epoch()
         return loss

@@ -1,0 +1,370 @@
+"""Autograd pairing of the vision-transformer kernels (include/wafer_hip.h, "Vision-transformer path").
+
+Token activations are bf16 [rows, C] (rows = images x tokens, token-major); parameters float32.
+The Linear layers themselves run on the implicit-GEMM kernel (`ops.linear`, a 1x1 convolution on a
+1x1 image); this module adds what surrounds them in a ViT block: LayerNorm, bias / GELU / residual
+epilogues, attention, patch embedding, token assembly, row gather / scatter, the DINO loss and MSE.
+No CPU fallback: every function raises when the HIP library is missing.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import _lib, ops
+from ._lib import check, ptr, stream_ptr
+from .ops import _arena_grad, _need_cuda
+
+ACT_NONE, ACT_GELU = 0, 1
+
+
+def _bf16_rows(x: torch.Tensor) -> torch.Tensor:
+    if x.dtype != torch.bfloat16:
+        x = x.to(torch.bfloat16)
+    return x.contiguous()
+
+
+def _grad_target(p: torch.Tensor):
+    """(buffer the kernels accumulate into, value to hand to autograd)."""
+    slot = _arena_grad(p)
+    if slot is not None:
+        return slot, None
+    g = torch.zeros_like(p, dtype=torch.float32)
+    return g, g
+
+
+class _LayerNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _need_cuda(x, "layer_norm")
+        x = _bf16_rows(x)
+        rows, c = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(_lib.load().wm_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), eps, rows, c, ptr(y), ptr(mean), ptr(rstd),
+                                           stream_ptr()), "wm_layernorm_fwd")
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.params = (gamma, beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
+        rows, c = x.shape
+        dy = _bf16_rows(dy)
+        dx = torch.empty_like(x)
+        dg, dg_ret = _grad_target(gamma)
+        db, db_ret = _grad_target(beta)
+        check(_lib.load().wm_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), rows, c, ptr(dx), ptr(dg),
+                                           ptr(db), stream_ptr()), "wm_layernorm_bwd")
+        return dx, dg_ret, db_ret, None
+
+
+def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
+    """nn.LayerNorm over the last dim of bf16 [rows, C]."""
+    return _LayerNorm.apply(x, gamma, beta, float(eps))
+
+
+class _BiasAct(torch.autograd.Function):
+    """out = act(x + bias) (+ residual)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, residual, act):
+        _need_cuda(x, "bias_act")
+        x = _bf16_rows(x)
+        rows, c = x.shape
+        if residual is not None:
+            residual = _bf16_rows(residual)
+        y = torch.empty_like(x)
+        check(_lib.load().wm_bias_act_fwd(ptr(x), ptr(bias), ptr(residual), act, rows, c, ptr(y), stream_ptr()),
+              "wm_bias_act_fwd")
+        ctx.act = act
+        ctx.bias = bias
+        ctx.has_res = residual is not None
+        ctx.save_for_backward(x if act != ACT_NONE else None)
+        ctx.shape = (rows, c)
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        rows, c = ctx.shape
+        dout = _bf16_rows(dout)
+        bias = ctx.bias
+        db = db_ret = None
+        if bias is not None and bias.requires_grad:
+            db, db_ret = _grad_target(bias)
+        lib = _lib.load()
+        if ctx.act == ACT_NONE:
+            if db is not None:
+                check(lib.wm_bias_act_bwd(0, 0, ptr(dout), ACT_NONE, rows, c, 0, ptr(db), stream_ptr()), "wm_bias_act_bwd")
+            dx = dout
+        else:
+            dx = torch.empty_like(dout)
+            check(lib.wm_bias_act_bwd(ptr(x), ptr(bias), ptr(dout), ctx.act, rows, c, ptr(dx), ptr(db), stream_ptr()),
+                  "wm_bias_act_bwd")
+        return dx, db_ret, (dout if ctx.has_res else None), None
+
+
+def bias_act(x: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
+             residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    return _BiasAct.apply(x, bias, residual, int(act))
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
+           residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """act(x @ W^T + bias) (+ residual) on bf16 [rows, C]: the GEMM kernel, then one epilogue pass."""
+    y = ops.linear(x, weight)
+    if bias is None and act == ACT_NONE and residual is None:
+        return y
+    return bias_act(y, bias, act, residual)
+
+
+class _Attention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv, b, s, h, scale):
+        _need_cuda(qkv, "attention")
+        qkv = _bf16_rows(qkv)
+        if qkv.shape != (b * s, 3 * h * 64):
+            raise ValueError(f"attention: qkv {tuple(qkv.shape)} vs B={b} S={s} H={h} (head dim 64)")
+        out = torch.empty((b * s, h * 64), dtype=torch.bfloat16, device=qkv.device)
+        lse = torch.empty((b, h, s), dtype=torch.float32, device=qkv.device)
+        check(_lib.load().wm_attention_fwd(ptr(qkv), b, s, h, scale, ptr(out), ptr(lse), stream_ptr()), "wm_attention_fwd")
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.geom = (b, s, h, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, lse = ctx.saved_tensors
+        b, s, h, scale = ctx.geom
+        dout = _bf16_rows(dout)
+        dqkv = torch.empty_like(qkv)
+        check(_lib.load().wm_attention_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), b, s, h, scale, ptr(dqkv),
+                                           stream_ptr()), "wm_attention_bwd")
+        return dqkv, None, None, None, None
+
+
+def attention(qkv: torch.Tensor, batch: int, seq: int, heads: int, scale: Optional[float] = None) -> torch.Tensor:
+    """softmax(scale q k^T) v per head; qkv bf16 [B*S, 3*H*64] as the qkv Linear emits it -> [B*S, H*64]."""
+    return _Attention.apply(qkv, int(batch), int(seq), int(heads), float(64 ** -0.5 if scale is None else scale))
+
+
+class _PatchEmbed(torch.autograd.Function):
+    """Conv2d(3, D, kernel = stride = p) as patchify + GEMM; images need no gradient."""
+
+    @staticmethod
+    def forward(ctx, images, weight):
+        _need_cuda(images, "patch_embed")
+        x = ops._as_nhwc(images)
+        n, c, s, s2 = x.shape
+        d, c2, p, p2 = weight.shape
+        if c != 3 or c2 != 3 or s != s2 or p != p2 or s % p:
+            raise ValueError(f"patch_embed: images {tuple(images.shape)} vs weight {tuple(weight.shape)}")
+        g = s // p
+        lib = _lib.load()
+        rows = torch.empty((n * g * g, p * p * 3), dtype=torch.bfloat16, device=x.device)
+        check(lib.wm_patchify(ptr(x), n, s, p, ptr(rows), stream_ptr()), "wm_patchify")
+        krsc, _ = ops._WCACHE.get(weight, kind="conv")  # [D][p][p][3] == the patch row order
+        y = torch.empty((n * g * g, d), dtype=torch.bfloat16, device=x.device)
+        k = p * p * 3
+        check(lib.wm_conv2d_fwd(ptr(rows), ptr(krsc), ptr(y), n * g * g, 1, 1, k, d, 1, 1, 1, 1, 1, 0, stream_ptr()),
+              "wm_conv2d_fwd(patch_embed)")
+        ctx.save_for_backward(rows)
+        ctx.weight = weight
+        ctx.geom = (n * g * g, k, d, p)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (rows,) = ctx.saved_tensors
+        weight = ctx.weight
+        m, k, d, p = ctx.geom
+        dw = None
+        if ctx.needs_input_grad[1]:
+            dy = _bf16_rows(dy)
+            lib = _lib.load()
+            ws = ops._wgrad_accumulator(weight, (d, p, p, 3))
+            check(lib.wm_conv2d_wgrad(ptr(dy), ptr(rows), ptr(ws), m, 1, 1, k, d, 1, 1, 1, 1, 1, 0, stream_ptr()),
+                  "wm_conv2d_wgrad(patch_embed)")
+            slot = _arena_grad(weight)
+            if slot is not None:
+                check(lib.wm_wgrad_finalize(ptr(ws), d, 3, p, p, ptr(slot), 1, stream_ptr()), "wm_wgrad_finalize")
+            else:
+                dw = torch.empty((d, 3, p, p), dtype=torch.float32, device=dy.device)
+                check(lib.wm_wgrad_finalize(ptr(ws), d, 3, p, p, ptr(dw), 0, stream_ptr()), "wm_wgrad_finalize")
+        return None, dw
+
+
+def patch_embed(images: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+    """images [N,3,S,S] (bf16 channels_last) x weight [D,3,p,p] -> bf16 [N*(S/p)^2, D] (no bias)."""
+    return _PatchEmbed.apply(images, weight)
+
+
+class _TokensAssemble(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, patches, cls, pos, n, np_):
+        _need_cuda(patches, "tokens_assemble")
+        patches = _bf16_rows(patches)
+        d = patches.shape[1]
+        cls_c, pos_c = cls.detach().reshape(-1).contiguous(), pos.detach().reshape(-1, d).contiguous()
+        if pos_c.shape[0] != np_ + 1 or patches.shape[0] != n * np_:
+            raise ValueError(f"tokens_assemble: {tuple(patches.shape)} patches, pos {tuple(pos.shape)}, N={n}, np={np_}")
+        out = torch.empty((n * (np_ + 1), d), dtype=torch.bfloat16, device=patches.device)
+        check(_lib.load().wm_tokens_assemble(ptr(patches), ptr(cls_c), ptr(pos_c), n, np_, d, ptr(out), stream_ptr()),
+              "wm_tokens_assemble")
+        ctx.geom = (n, np_, d)
+        ctx.shapes = (cls.shape, pos.shape)
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
+        n, np_, d = ctx.geom
+        dx = _bf16_rows(dx)
+        s = np_ + 1
+        dpos = torch.empty(s * d, dtype=torch.float32, device=dx.device)
+        check(_lib.load().wm_colsum_bf16(ptr(dx), n, s * d, ptr(dpos), 0, stream_ptr()), "wm_colsum_bf16")
+        dpatch = dx.view(n, s, d)[:, 1:].reshape(n * np_, d)
+        cls_shape, pos_shape = ctx.shapes
+        return dpatch, dpos[:d].reshape(cls_shape), dpos.reshape(pos_shape), None, None
+
+
+def tokens_assemble(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, n: int, np_: int) -> torch.Tensor:
+    """[cls + pos[0]; patches + pos[1:]] per image: bf16 [N*np, D] -> [N*(np+1), D]."""
+    return _TokensAssemble.apply(patches, cls, pos, int(n), int(np_))
+
+
+class _GatherRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, idx, b, s):
+        _need_cuda(x, "gather_rows")
+        x = _bf16_rows(x)
+        c = x.shape[1]
+        idx = idx.to(torch.int64).contiguous()
+        k = idx.shape[1]
+        out = torch.empty((b * k, c), dtype=torch.bfloat16, device=x.device)
+        check(_lib.load().wm_gather_rows(ptr(x), ptr(idx), b, s, k, c, ptr(out), stream_ptr()), "wm_gather_rows")
+        ctx.save_for_backward(idx)
+        ctx.geom = (b, s, k, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        b, s, k, c = ctx.geom
+        dy = _bf16_rows(dy)
+        dx = torch.zeros((b * s, c), dtype=torch.bfloat16, device=dy.device)
+        check(_lib.load().wm_scatter_rows(ptr(dy), ptr(idx), b, s, k, c, ptr(dx), stream_ptr()), "wm_scatter_rows")
+        return dx, None, None, None
+
+
+def gather_rows(x: torch.Tensor, idx: torch.Tensor, batch: int, seq: int) -> torch.Tensor:
+    """lightly get_at_index: x bf16 [B*S, C], idx int64 [B, K] (distinct per row) -> [B*K, C]."""
+    return _GatherRows.apply(x, idx, int(batch), int(seq))
+
+
+class _ScatterRows(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, base, src, idx, b, s):
+        _need_cuda(base, "scatter_rows")
+        base, src = _bf16_rows(base), _bf16_rows(src)
+        c = base.shape[1]
+        idx = idx.to(torch.int64).contiguous()
+        k = idx.shape[1]
+        out = base.clone()
+        check(_lib.load().wm_scatter_rows(ptr(src), ptr(idx), b, s, k, c, ptr(out), stream_ptr()), "wm_scatter_rows")
+        ctx.save_for_backward(idx)
+        ctx.geom = (b, s, k, c)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        b, s, k, c = ctx.geom
+        dout = _bf16_rows(dout)
+        lib = _lib.load()
+        dsrc = torch.empty((b * k, c), dtype=torch.bfloat16, device=dout.device)
+        check(lib.wm_gather_rows(ptr(dout), ptr(idx), b, s, k, c, ptr(dsrc), stream_ptr()), "wm_gather_rows")
+        dbase = dout.clone()
+        zeros = torch.zeros_like(dsrc)
+        check(lib.wm_scatter_rows(ptr(zeros), ptr(idx), b, s, k, c, ptr(dbase), stream_ptr()), "wm_scatter_rows")
+        return dbase, dsrc, None, None, None
+
+
+def scatter_rows(base: torch.Tensor, src: torch.Tensor, idx: torch.Tensor, batch: int, seq: int) -> torch.Tensor:
+    """lightly set_at_index: copy of base [B*S, C] with rows idx [B, K] replaced by src [B*K, C]."""
+    return _ScatterRows.apply(base, src, idx, int(batch), int(seq))
+
+
+class _MSE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        _need_cuda(pred, "mse_loss")
+        pred, target = _bf16_rows(pred), _bf16_rows(target)
+        if pred.shape != target.shape or pred.numel() % 8:
+            raise ValueError(f"mse_loss: {tuple(pred.shape)} vs {tuple(target.shape)}")
+        loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
+        dpred = torch.empty_like(pred)
+        check(_lib.load().wm_mse_fwd_bwd(ptr(pred), ptr(target), pred.numel(), ptr(loss), ptr(dpred), stream_ptr()),
+              "wm_mse_fwd_bwd")
+        ctx.save_for_backward(dpred)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dpred,) = ctx.saved_tensors
+        return (dpred.float() * g).to(torch.bfloat16), None
+
+
+def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """nn.MSELoss() (mean) on bf16 tensors; the gradient is produced in the same pass."""
+    return _MSE.apply(pred, target)
+
+
+class _DinoLoss(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, student, probs, vs, vt, b, temp_s):
+        _need_cuda(student, "dino_loss")
+        student = _bf16_rows(student)
+        d = student.shape[1]
+        if student.shape[0] != vs * b or tuple(probs.shape) != (vt * b, d) or probs.dtype != torch.float32:
+            raise ValueError(f"dino_loss: student {tuple(student.shape)}, probs {tuple(probs.shape)} {probs.dtype}")
+        loss = torch.zeros(1, dtype=torch.float32, device=student.device)
+        dstudent = torch.empty_like(student)
+        check(_lib.load().wm_dino_loss_fwd_bwd(ptr(student), ptr(probs.contiguous()), vs, vt, b, d, temp_s, ptr(loss),
+                                               ptr(dstudent), stream_ptr()), "wm_dino_loss_fwd_bwd")
+        ctx.save_for_backward(dstudent)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dstudent,) = ctx.saved_tensors
+        return (dstudent.float() * g).to(torch.bfloat16), None, None, None, None, None
+
+
+def dino_teacher_probs(teacher: torch.Tensor, center: torch.Tensor, temp: float) -> torch.Tensor:
+    """softmax((teacher - center) / temp) per row: bf16 [rows, D] -> float32 [rows, D] (no gradient)."""
+    _need_cuda(teacher, "dino_teacher_probs")
+    teacher = _bf16_rows(teacher.detach())
+    rows, d = teacher.shape
+    probs = torch.empty((rows, d), dtype=torch.float32, device=teacher.device)
+    check(_lib.load().wm_dino_teacher_probs(ptr(teacher), ptr(center.reshape(-1).contiguous()), float(temp), rows, d,
+                                            ptr(probs), stream_ptr()), "wm_dino_teacher_probs")
+    return probs
+
+
+def dino_loss(student: torch.Tensor, probs: torch.Tensor, n_student_views: int, n_teacher_views: int, batch: int,
+              student_temp: float = 0.1) -> torch.Tensor:
+    """Mean over (teacher view t, student view s != t) and batch of -<p_t, log_softmax(student_s / T)>."""
+    return _DinoLoss.apply(student, probs, int(n_student_views), int(n_teacher_views), int(batch), float(student_temp))
+
+
+def dino_center_update(center: torch.Tensor, teacher: torch.Tensor, momentum: float) -> None:
+    """center <- m center + (1 - m) mean_rows(teacher), in place (float32 [D] / [1, D])."""
+    teacher = _bf16_rows(teacher.detach())
+    rows, d = teacher.shape
+    check(_lib.load().wm_dino_center_update(ptr(teacher), rows, d, float(momentum), ptr(center), stream_ptr()),
+          "wm_dino_center_update")

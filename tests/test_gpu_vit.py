@@ -1,0 +1,359 @@
+"""GPU parity of the vision-transformer path: each kernel against plain torch
+float32 on the same bf16-rounded inputs, then ViT features, the DINO head / loss, AdamW / EMA and a
+whole DINO training step against oracle/vit.py on identical weights.
+Tolerances: bf16 storage of activations (2^-9 relative per stage); stated at each check."""
+import copy
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _bf(x):
+    return x.bfloat16().float()
+
+
+def _close(got, ref, rel=1e-2, what=""):
+    got, ref = got.float().cpu(), ref.float().cpu()
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+
+
+def _cos(a, b):
+    a, b = a.float().flatten().cpu().double(), b.float().flatten().cpu().double()
+    return float((a @ b) / (a.norm() * b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("rows,c", [(37, 384), (1000, 384), (130, 768), (9, 2048), (64, 8)])
+def test_layer_norm(rows, c):
+    from ssl_wafermap_amd import vit_ops
+
+    g = torch.Generator().manual_seed(rows + c)
+    x = _bf(torch.randn(rows, c, generator=g) * 2 + 0.5)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    dy = _bf(torch.randn(rows, c, generator=g))
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (c,), gr, br, 1e-6)
+    ref.backward(dy)
+    xd = x.to(DEV).bfloat16().requires_grad_(True)
+    gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    y = vit_ops.layer_norm(xd, gd, bd, 1e-6)
+    y.backward(dy.to(DEV).bfloat16())
+    _close(y, ref.detach(), what="y")
+    _close(xd.grad, xr.grad, what="dx")
+    _close(gd.grad, gr.grad, rel=2e-2, what="dgamma")  # sums of bf16-rounded... products over rows
+    _close(bd.grad, br.grad, what="dbeta")
+
+
+@pytest.mark.parametrize("rows,c,act,res", [(197, 384, 0, True), (300, 1536, 1, False), (64, 1152, 0, False),
+                                            (50, 3072, 1, False), (33, 8, 1, True)])
+def test_bias_act(rows, c, act, res):
+    from ssl_wafermap_amd import vit_ops
+
+    g = torch.Generator().manual_seed(rows)
+    x = _bf(torch.randn(rows, c, generator=g) * 1.5)
+    b = torch.randn(c, generator=g) * 0.3
+    r = _bf(torch.randn(rows, c, generator=g)) if res else None
+    dy = _bf(torch.randn(rows, c, generator=g))
+    xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = xr + br
+    if act:
+        ref = F.gelu(ref)
+    if res:
+        rr = r.clone().requires_grad_(True)
+        ref = ref + rr
+    ref.backward(dy)
+    xd, bd = x.to(DEV).bfloat16().requires_grad_(True), b.to(DEV).requires_grad_(True)
+    rd = r.to(DEV).bfloat16().requires_grad_(True) if res else None
+    y = vit_ops.bias_act(xd, bd, act, rd)
+    y.backward(dy.to(DEV).bfloat16())
+    _close(y, ref.detach(), what="y")
+    _close(xd.grad, xr.grad, what="dx")
+    _close(bd.grad, br.grad, rel=2e-2, what="dbias")
+    if res:
+        _close(rd.grad, rr.grad, what="dres")
+
+
+@pytest.mark.parametrize("b,s,h", [(3, 197, 6), (4, 37, 6), (2, 50, 12), (5, 13, 12), (1, 256, 2), (2, 128, 1),
+                                   (2, 1, 3), (2, 224, 2)])
+def test_attention_matches_torch(b, s, h):
+    from ssl_wafermap_amd import vit_ops
+
+    g = torch.Generator().manual_seed(b * 1000 + s)
+    qkv = _bf(torch.randn(b, s, 3, h, 64, generator=g))
+    do = _bf(torch.randn(b, s, h, 64, generator=g))
+    qr = qkv.clone().requires_grad_(True)
+    q, k, v = qr[:, :, 0].transpose(1, 2), qr[:, :, 1].transpose(1, 2), qr[:, :, 2].transpose(1, 2)  # [b,h,s,64]
+    p = ((q @ k.transpose(-2, -1)) * 0.125).softmax(-1)
+    ref = (p @ v).transpose(1, 2)  # [b,s,h,64]
+    ref.backward(do)
+    qd = qkv.to(DEV).bfloat16().reshape(b * s, 3 * h * 64).requires_grad_(True)
+    out = vit_ops.attention(qd, b, s, h)
+    out.backward(do.to(DEV).bfloat16().reshape(b * s, h * 64))
+    # P is rounded to bf16 before the PV product: 2^-9 relative on each probability
+    _close(out, ref.detach().reshape(b * s, h * 64), rel=1.5e-2, what="out")
+    _close(qd.grad, qr.grad.reshape(b * s, 3 * h * 64), rel=2.5e-2, what="dqkv")
+    assert _cos(qd.grad, qr.grad) > 0.999
+
+
+def test_attention_rejects_bad_shapes():
+    from ssl_wafermap_amd import _lib, vit_ops
+
+    x = torch.zeros(2 * 300, 3 * 64, dtype=torch.bfloat16, device=DEV)
+    with pytest.raises(_lib.WaferHipError):
+        vit_ops.attention(x, 2, 300, 1)  # S > 256
+    with pytest.raises(ValueError):
+        vit_ops.attention(x, 2, 100, 1)
+
+
+def test_patch_embed_and_tokens():
+    from ssl_wafermap_amd import ops, vit_ops
+
+    g = torch.Generator().manual_seed(5)
+    n, s, p, d = 3, 96, 16, 384
+    img = _bf(torch.randn(n, 3, s, s, generator=g))
+    w = torch.randn(d, 3, p, p, generator=g) * 0.05
+    cls, pos = torch.randn(1, 1, d, generator=g), torch.randn(1, 37, d, generator=g)
+    wr, cr, pr = w.clone().requires_grad_(True), cls.clone().requires_grad_(True), pos.clone().requires_grad_(True)
+    t = F.conv2d(img, _bf(wr), None, stride=p).flatten(2).transpose(1, 2)
+    ref = torch.cat([cr.expand(n, -1, -1), _bf(t)], 1) + pr
+    dy = _bf(torch.randn(n, 37, d, generator=g))
+    ref.backward(dy)
+    wd, cd, pd = w.to(DEV).requires_grad_(True), cls.to(DEV).requires_grad_(True), pos.to(DEV).requires_grad_(True)
+    patches = vit_ops.patch_embed(ops.to_nhwc_bf16(img.to(DEV)), wd)
+    tok = vit_ops.tokens_assemble(patches, cd, pd, n, 36)
+    tok.backward(dy.to(DEV).bfloat16().reshape(n * 37, d))
+    _close(tok, ref.detach().reshape(n * 37, d), what="tokens")
+    _close(wd.grad, wr.grad, rel=2e-2, what="dW")
+    _close(pd.grad, pr.grad, what="dpos")
+    _close(cd.grad, cr.grad, what="dcls")
+
+
+def test_gather_scatter_mse():
+    from ssl_wafermap_amd import vit_ops
+    from ssl_wafermap_amd.utils import get_at_index, random_token_mask, set_at_index
+
+    g = torch.Generator().manual_seed(9)
+    b, s, c = 4, 50, 64
+    x = _bf(torch.randn(b, s, c, generator=g))
+    keep, mask = random_token_mask((b, s), 0.75, generator=g)
+    assert keep.shape == (b, 12) and (keep[:, 0] == 0).all()  # class token always kept
+    xr = x.clone().requires_grad_(True)
+    ref = torch.gather(xr, 1, keep.unsqueeze(-1).expand(-1, -1, c))
+    dy = _bf(torch.randn(b, 12, c, generator=g))
+    ref.backward(dy)
+    xd = x.to(DEV).bfloat16().requires_grad_(True)
+    got = get_at_index(xd, keep.to(DEV))
+    got.backward(dy.to(DEV).bfloat16())
+    assert torch.equal(got.float().cpu(), ref.detach())
+    assert torch.equal(xd.grad.float().cpu(), xr.grad)
+    val = _bf(torch.randn(b, mask.shape[1], c, generator=g))
+    ref2 = x.clone().scatter(1, mask.unsqueeze(-1).expand(-1, -1, c), val)
+    got2 = set_at_index(x.to(DEV).bfloat16(), mask.to(DEV), val.to(DEV).bfloat16())
+    assert torch.equal(got2.float().cpu(), ref2)
+    a, t = _bf(torch.randn(64, 96, generator=g)), _bf(torch.randn(64, 96, generator=g))
+    ar = a.clone().requires_grad_(True)
+    lr = F.mse_loss(ar, t)
+    lr.backward()
+    ad = a.to(DEV).bfloat16().requires_grad_(True)
+    ld = vit_ops.mse_loss(ad, t.to(DEV).bfloat16())
+    ld.backward()
+    assert abs(float(ld) - float(lr)) <= 1e-5 * abs(float(lr))
+    _close(ad.grad, ar.grad, what="dpred")
+
+
+@pytest.mark.parametrize("vs,vt,b,d", [(8, 2, 16, 2048), (2, 2, 5, 256), (4, 2, 3, 65536 // 8)])
+def test_dino_loss_matches_oracle(vs, vt, b, d):
+    from oracle import vit as ov
+    from ssl_wafermap_amd.loss import DINOLoss
+
+    g = torch.Generator().manual_seed(vs * 10 + b)
+    teacher = [_bf(torch.randn(b, d, generator=g)) for _ in range(vt)]
+    student = [_bf(torch.randn(b, d, generator=g) * 0.5) for _ in range(vs)]
+    center = torch.randn(1, 1, d, generator=g) * 0.1
+    sr = [t.clone().requires_grad_(True) for t in student]
+    ref, batch_center = ov.dino_loss(teacher, sr, center, 0.04, 0.1)
+    ref.backward()
+    crit = DINOLoss(output_dim=d).to(DEV)
+    crit.center.copy_(center.to(DEV))
+    sd = [t.to(DEV).bfloat16().requires_grad_(True) for t in student]
+    loss = crit([t.to(DEV).bfloat16() for t in teacher], sd, epoch=40)
+    loss.backward()
+    assert abs(float(loss) - float(ref)) <= 2e-4 * abs(float(ref)), (float(loss), float(ref))
+    for a, r in zip(sd, sr):
+        _close(a.grad, r.grad, rel=1e-2, what="dstudent")
+    _close(crit.center, 0.9 * center + 0.1 * batch_center, rel=1e-4, what="center")
+    # warm-up temperature schedule (lightly: linspace(0.04, teacher_temp, 30)) is indexed by epoch
+    crit2 = DINOLoss(output_dim=d, warmup_teacher_temp=0.02, teacher_temp=0.06, warmup_teacher_temp_epochs=5).to(DEV)
+    ref2, _ = ov.dino_loss(teacher, student, torch.zeros(1, 1, d), 0.04, 0.1)
+    got2 = crit2([t.to(DEV).bfloat16() for t in teacher], [t.to(DEV).bfloat16() for t in student], epoch=2)
+    assert abs(float(got2) - float(ref2)) <= 2e-4 * abs(float(ref2))
+
+
+def test_adamw_and_ema_match_torch():
+    from oracle import vit as ov
+    from ssl_wafermap_amd import optim
+    from ssl_wafermap_amd.utils import update_momentum
+
+    torch.manual_seed(3)
+    shapes = [(384, 384), (384,), (7, 5, 3), (1,)]
+    ps = [torch.nn.Parameter(torch.randn(*s, device=DEV)) for s in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    topt = torch.optim.AdamW(ref, lr=3e-3, weight_decay=0.05, betas=(0.9, 0.95))
+    opt = optim.AdamW(ps, lr=3e-3, weight_decay=0.05, betas=(0.9, 0.95))
+    for step in range(4):
+        for p, r in zip(ps, ref):
+            gval = torch.randn_like(r)
+            r.grad = gval.clone()
+            p.grad.copy_(gval)
+        opt.step()
+        topt.step()
+    for p, r in zip(ps, ref):
+        torch.testing.assert_close(p.detach(), r.detach(), rtol=2e-5, atol=2e-6)
+    # EMA: student parameters live in the optimiser arena, the teacher gets flattened on first use
+    student = torch.nn.ParameterList(ps)
+    teacher = torch.nn.ParameterList([torch.nn.Parameter(torch.randn_like(p), requires_grad=False) for p in ps])
+    want = [0.99 * t.detach() + 0.01 * p.detach() for t, p in zip(teacher, student)]
+    update_momentum(student, teacher, 0.99)
+    for t, w in zip(teacher, want):
+        torch.testing.assert_close(t.detach(), w, rtol=1e-6, atol=1e-7)
+    assert getattr(teacher, "_hip_flat", None) is not None  # single-launch path was taken
+
+
+def _tiny_vit(depth=2):
+    from ssl_wafermap_amd.models.vit import VisionTransformer
+
+    torch.manual_seed(0)
+    m = VisionTransformer(patch_size=16, embed_dim=384, depth=depth, num_heads=6)
+    with torch.no_grad():  # break the symmetry of the zero biases / unit LayerNorms
+        for p_ in m.parameters():
+            if p_.dim() == 1:
+                p_.add_(torch.randn_like(p_) * 0.05)
+    return m
+
+
+@pytest.mark.parametrize("size", [224, 96])
+def test_vit_features_and_gradients_match_oracle(size):
+    from oracle import vit as ov
+    from ssl_wafermap_amd import ops
+
+    m = _tiny_vit(depth=3).to(DEV)
+    sd = {k: v.detach().float().cpu().clone().requires_grad_(v.requires_grad) for k, v in m.state_dict(keep_vars=True).items()}
+    g = torch.Generator().manual_seed(size)
+    x = _bf(torch.randn(4, 3, size, size, generator=g))
+    dy = _bf(torch.randn(4, 384, generator=g))
+    ref = ov.vit_features(x, sd, heads=6)
+    ref.backward(dy)
+    y = m(ops.to_nhwc_bf16(x.to(DEV)))
+    y.backward(dy.to(DEV).bfloat16())
+    # tolerance: bf16 residual stream through 3 blocks; SURVEY 8d asks 1e-3 cosine on embeddings
+    for i in range(4):
+        assert _cos(y[i], ref[i]) > 1 - 1e-3
+    _close(y, ref.detach(), rel=3e-2, what="features")
+    worst = 1.0
+    for k, p_ in m.named_parameters():
+        c = _cos(p_.grad, sd[k].grad)
+        worst = min(worst, c)
+        assert c > 0.98, (k, c)
+    assert worst > 0.98
+
+
+def test_dino_head_matches_oracle_with_per_view_batchnorm():
+    from oracle import vit as ov
+    from ssl_wafermap_amd import heads, ops
+
+    torch.manual_seed(1)
+    for bn in (True, False):
+        head = heads.DINOProjectionHead(384, 2048, 256, 2048, batch_norm=bn).to(DEV).train()
+        sd = {k: v.detach().float().cpu().clone() for k, v in head.state_dict().items()}
+        y = _bf(torch.randn(3 * 32, 384))
+        ref = ov.dino_head(y, sd, training=True, groups=3)
+        with ops.bn_groups(3):
+            got = head(y.to(DEV).bfloat16())
+        for i in range(0, 96, 17):
+            assert _cos(got[i], ref[i]) > 1 - 2e-3, (bn, i)
+        _close(got, ref, rel=4e-2, what=f"dino head bn={bn}")
+
+
+def test_dino_training_step_matches_oracle_and_learns():
+    """Whole step on identical weights: teacher EMA -> teacher fwd -> student fwd on 2 global + 2 local
+    crops -> DINO loss -> backward -> AdamW.  A 2-block ViT keeps the CPU-free oracle quick."""
+    from oracle import vit as ov
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models import DINOViT
+    from ssl_wafermap_amd.models.vit import VisionTransformer
+
+    torch.manual_seed(0)
+    model = DINOViT(None, 9, batch_size=8, max_epochs=10, log_rep_std=False)
+    model.backbone = VisionTransformer(patch_size=16, embed_dim=384, depth=2, num_heads=6)
+    model.teacher_backbone = copy.deepcopy(model.backbone)
+    for p_ in model.teacher_backbone.parameters():
+        p_.requires_grad = False
+    model = model.to(DEV).train()
+    (opt,), _ = model.configure_optimizers()
+    b = 8
+    g = torch.Generator().manual_seed(11)
+    views = [_bf(torch.randn(b, 3, 224, 224, generator=g)) for _ in range(2)] + \
+            [_bf(torch.randn(b, 3, 96, 96, generator=g)) for _ in range(2)]
+
+    # ---- oracle on the same weights (float32, on the GPU for speed)
+    sd = {k: v.detach().clone().float() for k, v in model.state_dict().items()}
+    s_bb = {k[len("backbone."):]: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith("backbone.")}
+    s_hd = {k[len("head."):]: (v.clone().requires_grad_(v.is_floating_point() and "running" not in k and "weight_g" not in k))
+            for k, v in sd.items() if k.startswith("head.")}
+    t_bb = {k[len("teacher_backbone."):]: v.clone() for k, v in sd.items() if k.startswith("teacher_backbone.")}
+    t_hd = {k[len("teacher_head."):]: v.clone() for k, v in sd.items() if k.startswith("teacher_head.")}
+    ov.update_momentum({k: v.detach() for k, v in s_bb.items()}, t_bb, 0.99)
+    ov.update_momentum({k: v.detach() for k, v in s_hd.items() if v.is_floating_point() and "running" not in k},
+                       {k: v for k, v in t_hd.items() if v.is_floating_point() and "running" not in k and "num_batches" not in k}, 0.99)
+    vd = [v.to(DEV) for v in views]
+    with torch.no_grad():
+        t_out = [ov.dino_head(ov.vit_features(v, t_bb, 6), t_hd, training=True) for v in vd[:2]]
+    s_out = [ov.dino_head(ov.vit_features(v, s_bb, 6), s_hd, training=True) for v in vd]
+    ref_loss, _ = ov.dino_loss(t_out, s_out, torch.zeros(1, 1, 2048, device=DEV), 0.04, 0.1)
+    ref_loss.backward()
+
+    # ---- HIP path
+    batch = ([ops.to_nhwc_bf16(v) for v in vd], None)
+    opt.zero_grad()
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    assert abs(float(loss) - float(ref_loss)) <= 5e-3 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    pairs = [("backbone." + k, p_.grad, s_bb[k].grad) for k, p_ in model.backbone.named_parameters()]
+    for k, p_ in model.head.named_parameters():
+        if p_.requires_grad:
+            ref_g = s_hd[k].grad
+            if k.startswith("layers.1."):  # one BatchNorm1d serves both hidden blocks (layers.1 == layers.4)
+                ref_g = ref_g + s_hd[k.replace("layers.1.", "layers.4.")].grad
+            pairs.append(("head." + k, p_.grad, ref_g))
+    # a per-view BatchNorm right after the first head Linear cancels any constant added to every row
+    # of the features: the gradient of backbone.norm.bias is exactly zero (pure rounding noise on both
+    # sides), so directions are compared only where the reference gradient is not negligible
+    top = max(float(r.norm() / math.sqrt(r.numel())) for _, _, r in pairs)
+    cos = [(_cos(a, r), k) for k, a, r in pairs if float(r.norm() / math.sqrt(r.numel())) > 1e-3 * top]
+    assert len(cos) >= len(pairs) - 4
+    worst = min(cos)
+    med = float(np.median([c for c, _ in cos]))
+    # bf16 activations + bf16 probabilities in attention against a float32 oracle
+    assert worst[0] > 0.9 and med > 0.98, (worst, med)
+    # teacher moved by the EMA
+    got_t = dict(model.teacher_backbone.state_dict())
+    for k in ("blocks.0.attn.qkv.weight", "pos_embed", "norm.bias"):
+        torch.testing.assert_close(got_t[k].float(), t_bb[k], rtol=1e-5, atol=1e-6)
+    # ---- and it trains: a few steps on the same batch reduce the loss
+    first = float(loss)
+    for grp in opt.param_groups:  # the scheduled rate at epoch 0 of a batch-8 run is 2e-7: use a real one
+        grp["lr"] = 5e-4
+    for i in range(8):
+        opt.step()
+        opt.zero_grad()
+        loss = model.training_step(batch, i + 1)
+        loss.backward()
+    assert math.isfinite(float(loss)) and float(loss) < first, (first, float(loss))

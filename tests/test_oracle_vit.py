@@ -1,0 +1,111 @@
+"""CPU checks of the vision-transformer oracle (oracle/vit.py) against independent closed forms,
+and of the host logic of the ViT path (pos-embed resize matrix, lightly utils)."""
+import math
+
+import torch
+import torch.nn.functional as F
+
+from oracle import vit as ov
+
+
+def test_dino_loss_closed_form():
+    g = torch.Generator().manual_seed(0)
+    vt, vs, b, d = 2, 5, 3, 16
+    t = [torch.randn(b, d, generator=g, dtype=torch.float64) for _ in range(vt)]
+    s = [torch.randn(b, d, generator=g, dtype=torch.float64) for _ in range(vs)]
+    c = torch.randn(1, 1, d, generator=g, dtype=torch.float64)
+    got, centre = ov.dino_loss(t, s, c, 0.04, 0.1)
+    want, n = 0.0, 0
+    for i in range(vt):
+        p = torch.softmax((t[i] - c[0]) / 0.04, -1)
+        for j in range(vs):
+            if i == j:
+                continue
+            want += -(p * torch.log_softmax(s[j] / 0.1, -1)).sum(-1).mean()
+            n += 1
+    assert n == vt * vs - min(vt, vs)
+    assert abs(float(got) - float(want / n)) < 1e-12
+    assert torch.allclose(centre, torch.stack(t).mean((0, 1), keepdim=True))
+
+
+def test_adamw_matches_torch():
+    torch.manual_seed(1)
+    ps = {"a": torch.randn(7, 5), "b": torch.randn(3)}
+    ref = [torch.nn.Parameter(v.clone()) for v in ps.values()]
+    opt = torch.optim.AdamW(ref, lr=1e-2, betas=(0.9, 0.95), weight_decay=0.05)
+    state = {}
+    for step in range(1, 5):
+        grads = {k: torch.randn_like(v) for k, v in ps.items()}
+        for r, g in zip(ref, grads.values()):
+            r.grad = g.clone()
+        opt.step()
+        ov.adamw_step(ps, grads, state, step, 1e-2, (0.9, 0.95), 1e-8, 0.05)
+    for r, v in zip(ref, ps.values()):
+        torch.testing.assert_close(r.detach(), v, rtol=1e-6, atol=1e-7)
+
+
+def test_vit_oracle_matches_nn_modules():
+    """The functional restatement against torch.nn building blocks wired the way dino's block is."""
+    torch.manual_seed(2)
+    d, heads, s = 128, 2, 10
+    sd = {"norm1.weight": torch.rand(d) + 0.5, "norm1.bias": torch.randn(d) * 0.1, "norm2.weight": torch.rand(d) + 0.5,
+          "norm2.bias": torch.randn(d) * 0.1, "attn.qkv.weight": torch.randn(3 * d, d) * 0.05,
+          "attn.qkv.bias": torch.randn(3 * d) * 0.05, "attn.proj.weight": torch.randn(d, d) * 0.05,
+          "attn.proj.bias": torch.randn(d) * 0.05, "mlp.fc1.weight": torch.randn(4 * d, d) * 0.05,
+          "mlp.fc1.bias": torch.randn(4 * d) * 0.05, "mlp.fc2.weight": torch.randn(d, 4 * d) * 0.05,
+          "mlp.fc2.bias": torch.randn(d) * 0.05}
+    x = torch.randn(3, s, d)
+    got = ov.block(x, {"b." + k: v for k, v in sd.items()}, "b", heads)
+    mha = torch.nn.MultiheadAttention(d, heads, batch_first=True)
+    with torch.no_grad():
+        mha.in_proj_weight.copy_(sd["attn.qkv.weight"]); mha.in_proj_bias.copy_(sd["attn.qkv.bias"])
+        mha.out_proj.weight.copy_(sd["attn.proj.weight"]); mha.out_proj.bias.copy_(sd["attn.proj.bias"])
+    h = F.layer_norm(x, (d,), sd["norm1.weight"], sd["norm1.bias"], 1e-6)
+    y = x + mha(h, h, h, need_weights=False)[0]
+    h = F.layer_norm(y, (d,), sd["norm2.weight"], sd["norm2.bias"], 1e-6)
+    want = y + F.linear(F.gelu(F.linear(h, sd["mlp.fc1.weight"], sd["mlp.fc1.bias"])), sd["mlp.fc2.weight"], sd["mlp.fc2.bias"])
+    torch.testing.assert_close(got, want, rtol=1e-4, atol=1e-5)
+
+
+def test_pos_embed_resize_matrix_equals_interpolation():
+    from ssl_wafermap_amd.models.vit import VisionTransformer
+
+    torch.manual_seed(3)
+    m = VisionTransformer(patch_size=16, embed_dim=64, depth=0, num_heads=1)
+    with torch.no_grad():
+        m.pos_embed.normal_()
+    for g_new in (6, 7, 14):
+        got = m.pos_for(g_new)
+        want = ov.pos_embed_for(m.pos_embed.detach(), g_new)
+        assert got.shape == (1, g_new * g_new + 1, 64)
+        torch.testing.assert_close(got.detach(), want, rtol=1e-5, atol=1e-6)
+
+
+def test_random_token_mask_and_scheduler():
+    from ssl_wafermap_amd.utils import random_token_mask
+    from ssl_wafermap_amd.utils.scheduler import cosine_warmup_factor
+
+    g = torch.Generator().manual_seed(0)
+    keep, mask = random_token_mask((5, 50), 0.75, generator=g)
+    assert keep.shape == (5, 12) and mask.shape == (5, 38)
+    assert (keep[:, 0] == 0).all()
+    both = torch.cat([keep, mask], 1).sort(1).values
+    assert (both == torch.arange(50)).all()
+    assert cosine_warmup_factor(0, 20, 150) == 1 / 20 and cosine_warmup_factor(19, 20, 150) == 1.0
+    assert abs(cosine_warmup_factor(150, 20, 150)) < 1e-12
+    assert math.isclose(cosine_warmup_factor(85, 20, 150), 0.5)
+
+
+def test_dino_head_state_dict_keys_follow_lightly():
+    from ssl_wafermap_amd import heads
+
+    h = heads.DINOProjectionHead(384, 2048, 256, 2048, batch_norm=True)
+    keys = set(h.state_dict().keys())
+    for k in ("layers.0.weight", "layers.1.weight", "layers.1.running_mean", "layers.3.weight", "layers.4.weight",
+              "layers.6.weight", "layers.6.bias", "last_layer.weight_g", "last_layer.weight_v"):
+        assert k in keys, k
+    assert "layers.0.bias" not in keys  # Linear before a BatchNorm has no bias
+    assert h.layers[1] is h.layers[4]    # lightly passes one BatchNorm1d instance to both blocks
+    assert not h.last_layer.weight_g.requires_grad and float(h.last_layer.weight_g.min()) == 1.0
+    h2 = heads.DINOProjectionHead(384, 2048, 256, 2048, batch_norm=False)
+    assert {"layers.0.bias", "layers.2.bias", "layers.4.bias"} <= set(h2.state_dict().keys())
