@@ -301,12 +301,13 @@ int wm_tokens_assemble(const void* patches, const float* cls, const float* pos, 
  * convolution (kernel = stride = p) becomes a GEMM against the [D][p][p][3] weight layout. */
 int wm_patchify(const void* images, int N, int S, int p, void* rows, void* stream);
 
-/* Multi-head self-attention, head dim 64, S <= 256, softmax(scale * q k^T) v.
- * qkv [B][S][3][H][64] (the qkv Linear's output as is), out / dout [B][S][H][64], lse [B][H][S] f32.
- * bwd writes dqkv in the layout of qkv. */
-int wm_attention_fwd(const void* qkv, int B, int S, int H, float scale, void* out, float* lse, void* stream);
+/* Multi-head self-attention, head_dim 64 or 32, S <= 256, softmax(scale * q k^T) v.
+ * qkv [B][S][3][H][head_dim] (the qkv / in_proj Linear's output as is), out / dout [B][S][H][head_dim],
+ * lse [B][H][S] f32.  bwd writes dqkv in the layout of qkv. */
+int wm_attention_fwd(const void* qkv, int B, int S, int H, int head_dim, float scale, void* out, float* lse,
+                     void* stream);
 int wm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int S, int H,
-                     float scale, void* dqkv, void* stream);
+                     int head_dim, float scale, void* dqkv, void* stream);
 
 /* Row gather / scatter on [B][S][C] bf16 by per-batch token indices idx [B][K] (int64, as
  * torch.argsort returns): lightly's get_at_index / set_at_index.  scatter writes only the indexed

@@ -120,3 +120,68 @@ def adamw_step(params, grads, state, step, lr, betas=(0.9, 0.999), eps=1e-8, wei
 def update_momentum(params, params_ema, m):
     for k in params_ema:
         params_ema[k].mul_(m).add_(params[k], alpha=1 - m)
+
+
+# ---------------------------------------------------------------------------------------- MAE
+# torchvision.models.vit_b_32 + lightly masked_autoencoder.MAEBackbone / MAEDecoder as the reference's
+# MAE drives them (scripts/WM811k_benchmark.py:876-957).  PARITY UNPINNED upstream.
+
+def tv_block(x, sd, p, heads, eps=1e-6):
+    """torchvision EncoderBlock (dropout 0): nn.MultiheadAttention(batch_first) + MLP, pre-norm."""
+    c = x.shape[-1]
+    h = F.layer_norm(x, (c,), sd[p + ".ln_1.weight"], sd[p + ".ln_1.bias"], eps)
+    b, s, _ = h.shape
+    qkv = F.linear(h, sd[p + ".self_attention.in_proj_weight"], sd[p + ".self_attention.in_proj_bias"])
+    q, k, v = qkv.reshape(b, s, 3, heads, c // heads).permute(2, 0, 3, 1, 4)
+    a = ((q @ k.transpose(-2, -1)) * ((c // heads) ** -0.5)).softmax(-1) @ v
+    a = a.transpose(1, 2).reshape(b, s, c)
+    x = x + F.linear(a, sd[p + ".self_attention.out_proj.weight"], sd[p + ".self_attention.out_proj.bias"])
+    h = F.layer_norm(x, (c,), sd[p + ".ln_2.weight"], sd[p + ".ln_2.bias"], eps)
+    h = F.gelu(F.linear(h, sd[p + ".mlp.0.weight"], sd[p + ".mlp.0.bias"]))
+    return x + F.linear(h, sd[p + ".mlp.3.weight"], sd[p + ".mlp.3.bias"])
+
+
+def _tv_layers(x, sd, prefix, heads):
+    n = 1 + max(int(k[len(prefix):].split(".")[0].rsplit("_", 1)[1]) for k in sd if k.startswith(prefix + "encoder_layer_"))
+    for i in range(n):
+        x = tv_block(x, sd, f"{prefix}encoder_layer_{i}", heads)
+    return x
+
+
+def lightly_patchify(images, p):
+    n, c, h, w = images.shape
+    g = h // p
+    x = images.reshape(n, c, g, p, g, p)
+    return torch.einsum("nchpwq->nhwpqc", x).reshape(n, g * g, p * p * c)
+
+
+def mae_encode(images, sd, idx_keep, heads=12, prefix="backbone."):
+    g = {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+    p = g["conv_proj.weight"].shape[-1]
+    t = F.conv2d(images, g["conv_proj.weight"], g["conv_proj.bias"], stride=p).flatten(2).transpose(1, 2)
+    n = t.shape[0]
+    t = torch.cat([g["class_token"].expand(n, -1, -1), t], dim=1) + g["encoder.pos_embedding"]
+    if idx_keep is not None:
+        t = torch.gather(t, 1, idx_keep.unsqueeze(-1).expand(-1, -1, t.shape[-1]))
+    t = _tv_layers(t, g, "encoder.layers.", heads)
+    c = t.shape[-1]
+    return F.layer_norm(t, (c,), g["encoder.ln.weight"], g["encoder.ln.bias"], 1e-6)
+
+
+def mae_loss(images, sd, idx_keep, idx_mask, enc_heads=12, dec_heads=16):
+    """The reference's MAE.training_step for given token indices (:925-954)."""
+    x_enc = mae_encode(images, sd, idx_keep, enc_heads)
+    d = {k[len("decoder."):]: v for k, v in sd.items() if k.startswith("decoder.")}
+    x_dec = F.linear(x_enc, d["decoder_embed.weight"], d["decoder_embed.bias"])
+    b, seq = images.shape[0], d["pos_embedding"].shape[1]
+    c = x_dec.shape[-1]
+    x_masked = sd["mask_token"].repeat(b, seq, 1)
+    x_masked = x_masked.scatter(1, idx_keep.unsqueeze(-1).expand(-1, -1, c), x_dec)
+    t = _tv_layers(x_masked + d["pos_embedding"], d, "layers.", dec_heads)
+    t = F.layer_norm(t, (c,), d["ln.weight"], d["ln.bias"], 1e-6)
+    pred = torch.gather(t, 1, idx_mask.unsqueeze(-1).expand(-1, -1, c))
+    pred = F.linear(pred, d["decoder_pred.weight"], d["decoder_pred.bias"])
+    p = sd["backbone.conv_proj.weight"].shape[-1]
+    patches = lightly_patchify(images, p)
+    target = torch.gather(patches, 1, (idx_mask - 1).unsqueeze(-1).expand(-1, -1, patches.shape[-1]))
+    return F.mse_loss(pred, target)

@@ -137,8 +137,8 @@ SIGNATURES = {
     "wm_colsum_bf16": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_void_p]),
     "wm_tokens_assemble": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_patchify": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
-    "wm_attention_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
-    "wm_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p,
+    "wm_attention_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "wm_attention_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p,
                                  c_void_p]),
     "wm_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_scatter_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

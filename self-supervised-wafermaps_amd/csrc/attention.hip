@@ -30,14 +30,18 @@
 namespace {
 
 constexpr int AT_THREADS = 256;
-constexpr int AT_ROWB = 144;  // LDS bytes per token row: 64 bf16 + 16 B pad
+// LDS bytes per token row: HD bf16 + 16 B pad (144 for head dim 64, 80 for 32: in both, 16
+// consecutive rows start on 16 distinct 4-bank groups)
+#define AT_ROWB (HD * 2 + 16)
 
+template <int HD>
 __device__ __forceinline__ bf16x8_t frag_rows(const uint8_t* base, int row, int ks, int fg) {
   return *reinterpret_cast<const bf16x8_t*>(base + row * AT_ROWB + ks * 64 + fg * 16);
 }
 
 // Operand with k running along the ROWS of the LDS image: 32 rows from row0, the 16 columns of
 // block blk.  k-slot (fg, e) <-> row0 + 4 fg + e (e < 4) / row0 + 16 + 4 fg + (e - 4).
+template <int HD>
 __device__ __forceinline__ bf16x8_t frag_cols(const uint8_t* base, int row0, int blk, int lane) {
   const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
   const uint8_t* p = base + (row0 + 4 * tg + tq) * AT_ROWB + blk * 32 + 8 * tp;
@@ -55,16 +59,18 @@ __device__ __forceinline__ bf16x8_t pack_slots(const f32x4_t a, const f32x4_t b)
 }
 
 // rows [0, S) of one [token][64] operand of (image b, head h) -> LDS; rows [S, SP) zero
+template <int HD>
 __device__ __forceinline__ void stage_rows(const uint16_t* src, size_t row_stride, int S, int SP, uint8_t* dst) {
-  for (int i = threadIdx.x; i < SP * 8; i += AT_THREADS) {
-    const int r = i >> 3, c = i & 7;
+  constexpr int CPR = HD / 8;  // 16-byte chunks per row
+  for (int i = threadIdx.x; i < SP * CPR; i += AT_THREADS) {
+    const int r = i / CPR, c = i % CPR;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (r < S) v = *reinterpret_cast<const uint4*>(src + (size_t)r * row_stride + c * 8);
     *reinterpret_cast<uint4*>(dst + r * AT_ROWB + c * 16) = v;
   }
 }
 
-template <int NT>
+template <int NT, int HD>
 __global__ __launch_bounds__(AT_THREADS) void attn_fwd(const uint16_t* __restrict__ qkv, int S, int H, float scale,
                                                        uint16_t* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) uint8_t at_smem[];
@@ -75,23 +81,27 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd(const uint16_t* __restric
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const size_t rs = (size_t)3 * H * 64;
-  const uint16_t* base = qkv + (size_t)b * S * rs + h * 64;
-  stage_rows(base, rs, S, SP, sq);
-  stage_rows(base + (size_t)H * 64, rs, S, SP, sk);
-  stage_rows(base + (size_t)2 * H * 64, rs, S, SP, sv);
+  constexpr int KS = HD / 32, DJ = HD / 16;
+  const size_t rs = (size_t)3 * H * HD;
+  const uint16_t* base = qkv + (size_t)b * S * rs + h * HD;
+  stage_rows<HD>(base, rs, S, SP, sq);
+  stage_rows<HD>(base + (size_t)H * HD, rs, S, SP, sk);
+  stage_rows<HD>(base + (size_t)2 * H * HD, rs, S, SP, sv);
   __syncthreads();
 
   for (int qs = wave; qs < NT; qs += 4) {
     const int q = qs * 16 + fr;
-    const bf16x8_t qf0 = frag_rows(sq, q, 0, fg), qf1 = frag_rows(sq, q, 1, fg);
+    bf16x8_t qf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_rows<HD>(sq, q, ks, fg);
     f32x4_t sc[NT];
     float m = -INFINITY;
 #pragma unroll
     for (int t = 0; t < NT; ++t) {
       f32x4_t a = {0.f, 0.f, 0.f, 0.f};
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sk, t * 16 + fr, 0, fg), qf0, a, 0, 0, 0);
-      a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sk, t * 16 + fr, 1, fg), qf1, a, 0, 0, 0);
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(sk, t * 16 + fr, ks, fg), qf[ks], a, 0, 0, 0);
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         const int key = t * 16 + 4 * fg + e;
@@ -112,21 +122,21 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd(const uint16_t* __restric
       }
     l += __shfl_xor(l, 16, 64);
     l += __shfl_xor(l, 32, 64);
-    f32x4_t o[4];
+    f32x4_t o[DJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) o[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < DJ; ++j) o[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < NT / 2; ++kk) {
       const bf16x8_t pf = pack_slots(sc[2 * kk], sc[2 * kk + 1]);
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(sv, kk * 32, j, lane), pf, o[j], 0, 0, 0);
+      for (int j = 0; j < DJ; ++j)
+        o[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(sv, kk * 32, j, lane), pf, o[j], 0, 0, 0);
     }
     if (q < S) {
       const float inv = 1.f / l;
-      uint16_t* dst = out + ((size_t)(b * S + q) * H + h) * 64 + 4 * fg;
+      uint16_t* dst = out + ((size_t)(b * S + q) * H + h) * HD + 4 * fg;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < DJ; ++j)
         *reinterpret_cast<uint2*>(dst + j * 16) =
             make_uint2(pack_bf2(o[j][0] * inv, o[j][1] * inv), pack_bf2(o[j][2] * inv, o[j][3] * inv));
       if (fg == 0) lse[((size_t)b * H + h) * S + q] = m + logf(l);
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd(const uint16_t* __restric
   }
 }
 
-template <int NT>
+template <int NT, int HD>
 __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                        const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                        int S, int H, float scale, uint16_t* __restrict__ dqkv) {
@@ -149,16 +159,17 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restric
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int fr = lane & 15, fg = lane >> 4;
-  const size_t rs = (size_t)3 * H * 64, os = (size_t)H * 64;
-  const uint16_t* base = qkv + (size_t)b * S * rs + h * 64;
-  const uint16_t* obase = out + (size_t)b * S * os + h * 64;
-  const uint16_t* dobase = dout + (size_t)b * S * os + h * 64;
-  stage_rows(base, rs, S, SP, sq);
-  stage_rows(base + (size_t)H * 64, rs, S, SP, sk);
-  stage_rows(base + (size_t)2 * H * 64, rs, S, SP, sv);
-  // dO -> LDS and delta[q] = sum_d dO[q][d] O[q][d] (8 lanes per row)
-  for (int i = threadIdx.x; i < SP * 8; i += AT_THREADS) {
-    const int r = i >> 3, c = i & 7;
+  constexpr int KS = HD / 32, DJ = HD / 16, CPR = HD / 8;
+  const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
+  const uint16_t* base = qkv + (size_t)b * S * rs + h * HD;
+  const uint16_t* obase = out + (size_t)b * S * os + h * HD;
+  const uint16_t* dobase = dout + (size_t)b * S * os + h * HD;
+  stage_rows<HD>(base, rs, S, SP, sq);
+  stage_rows<HD>(base + (size_t)H * HD, rs, S, SP, sk);
+  stage_rows<HD>(base + (size_t)2 * H * HD, rs, S, SP, sv);
+  // dO -> LDS and delta[q] = sum_d dO[q][d] O[q][d] (CPR adjacent lanes per row)
+  for (int i = threadIdx.x; i < SP * CPR; i += AT_THREADS) {
+    const int r = i / CPR, c = i % CPR;
     uint4 dv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
     if (r < S) {
       dv = *reinterpret_cast<const uint4*>(dobase + (size_t)r * os + c * 8);
@@ -174,7 +185,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restric
     }
     d += __shfl_xor(d, 1, 64);
     d += __shfl_xor(d, 2, 64);
-    d += __shfl_xor(d, 4, 64);
+    if (CPR == 8) d += __shfl_xor(d, 4, 64);
     if (c == 0) {
       s_delta[r] = d;
       s_lse[r] = r < S ? lse[((size_t)b * H + h) * S + r] : 0.f;
@@ -182,12 +193,16 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restric
   }
   __syncthreads();
 
-  uint16_t* dq_base = dqkv + (size_t)b * S * rs + h * 64;
+  uint16_t* dq_base = dqkv + (size_t)b * S * rs + h * HD;
   // ---- pass A: dQ, by query strips
   for (int qs = wave; qs < NT; qs += 4) {
     const int q = qs * 16 + fr;
-    const bf16x8_t qf0 = frag_rows(sq, q, 0, fg), qf1 = frag_rows(sq, q, 1, fg);
-    const bf16x8_t df0 = frag_rows(sdo, q, 0, fg), df1 = frag_rows(sdo, q, 1, fg);
+    bf16x8_t qf[KS], df[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      qf[ks] = frag_rows<HD>(sq, q, ks, fg);
+      df[ks] = frag_rows<HD>(sdo, q, ks, fg);
+    }
     const float lq = s_lse[q], dl = s_delta[q];
     bf16x8_t dsf[NT / 2];
 #pragma unroll
@@ -197,10 +212,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restric
       for (int u = 0; u < 2; ++u) {
         const int t = 2 * kk + u;
         f32x4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sk, t * 16 + fr, 0, fg), qf0, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sk, t * 16 + fr, 1, fg), qf1, a, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sv, t * 16 + fr, 0, fg), df0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sv, t * 16 + fr, 1, fg), df1, dp, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(sk, t * 16 + fr, ks, fg), qf[ks], a, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(sv, t * 16 + fr, ks, fg), df[ks], dp, 0, 0, 0);
+        }
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           const int key = t * 16 + 4 * fg + e;
@@ -210,18 +226,18 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restric
       }
       dsf[kk] = pack_slots(ds2[0], ds2[1]);
     }
-    f32x4_t dq[4];
+    f32x4_t dq[DJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dq[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < DJ; ++j) dq[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < NT / 2; ++kk)
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        dq[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(sk, kk * 32, j, lane), dsf[kk], dq[j], 0, 0, 0);
+      for (int j = 0; j < DJ; ++j)
+        dq[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(sk, kk * 32, j, lane), dsf[kk], dq[j], 0, 0, 0);
     if (q < S) {
       uint16_t* dst = dq_base + (size_t)q * rs + 4 * fg;
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
+      for (int j = 0; j < DJ; ++j)
         *reinterpret_cast<uint2*>(dst + j * 16) =
             make_uint2(pack_bf2(dq[j][0], dq[j][1]), pack_bf2(dq[j][2], dq[j][3]));
     }
@@ -230,8 +246,12 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restric
   for (int ksn = wave; ksn < NT; ksn += 4) {
     const int key = ksn * 16 + fr;
     const bool keyok = key < S;
-    const bf16x8_t kf0 = frag_rows(sk, key, 0, fg), kf1 = frag_rows(sk, key, 1, fg);
-    const bf16x8_t vf0 = frag_rows(sv, key, 0, fg), vf1 = frag_rows(sv, key, 1, fg);
+    bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[ks] = frag_rows<HD>(sk, key, ks, fg);
+      vf[ks] = frag_rows<HD>(sv, key, ks, fg);
+    }
     bf16x8_t pf[NT / 2], dsf[NT / 2];
 #pragma unroll
     for (int kk = 0; kk < NT / 2; ++kk) {
@@ -240,10 +260,11 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restric
       for (int u = 0; u < 2; ++u) {
         const int t = 2 * kk + u;
         f32x4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sq, t * 16 + fr, 0, fg), kf0, a, 0, 0, 0);
-        a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sq, t * 16 + fr, 1, fg), kf1, a, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sdo, t * 16 + fr, 0, fg), vf0, dp, 0, 0, 0);
-        dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows(sdo, t * 16 + fr, 1, fg), vf1, dp, 0, 0, 0);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(sq, t * 16 + fr, ks, fg), kf[ks], a, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(sdo, t * 16 + fr, ks, fg), vf[ks], dp, 0, 0, 0);
+        }
         const int q0 = t * 16 + 4 * fg;
         const f32x4_t lq = *reinterpret_cast<const f32x4_t*>(s_lse + q0);
         const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(s_delta + q0);
@@ -257,21 +278,21 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restric
       pf[kk] = pack_slots(p2[0], p2[1]);
       dsf[kk] = pack_slots(ds2[0], ds2[1]);
     }
-    f32x4_t dv[4], dk[4];
+    f32x4_t dv[DJ], dk[DJ];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) dv[j] = dk[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < DJ; ++j) dv[j] = dk[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int kk = 0; kk < NT / 2; ++kk)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        dv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(sdo, kk * 32, j, lane), pf[kk], dv[j], 0, 0, 0);
-        dk[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols(sq, kk * 32, j, lane), dsf[kk], dk[j], 0, 0, 0);
+      for (int j = 0; j < DJ; ++j) {
+        dv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(sdo, kk * 32, j, lane), pf[kk], dv[j], 0, 0, 0);
+        dk[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(sq, kk * 32, j, lane), dsf[kk], dk[j], 0, 0, 0);
       }
     if (keyok) {
-      uint16_t* dkp = dq_base + (size_t)key * rs + (size_t)H * 64 + 4 * fg;
-      uint16_t* dvp = dkp + (size_t)H * 64;
+      uint16_t* dkp = dq_base + (size_t)key * rs + (size_t)H * HD + 4 * fg;
+      uint16_t* dvp = dkp + (size_t)H * HD;
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
+      for (int j = 0; j < DJ; ++j) {
         *reinterpret_cast<uint2*>(dkp + j * 16) = make_uint2(pack_bf2(dk[j][0], dk[j][1]), pack_bf2(dk[j][2], dk[j][3]));
         *reinterpret_cast<uint2*>(dvp + j * 16) = make_uint2(pack_bf2(dv[j][0], dv[j][1]), pack_bf2(dv[j][2], dv[j][3]));
       }
@@ -286,32 +307,32 @@ int at_set_lds(K kernel, int bytes) {
   return e == hipSuccess ? WM_OK : (int)e;
 }
 
-template <int NT>
+template <int NT, int HD>
 int launch_fwd(const void* qkv, int B, int S, int H, float scale, void* out, float* lse, hipStream_t st) {
   constexpr int lds = 3 * NT * 16 * AT_ROWB;
   static bool attr = false;
   if (!attr) {
-    const int rc = at_set_lds(&attn_fwd<NT>, lds);
+    const int rc = at_set_lds(&attn_fwd<NT, HD>, lds);
     if (rc != WM_OK) return rc;
     attr = true;
   }
-  attn_fwd<NT><<<B * H, AT_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), S, H, scale,
+  attn_fwd<NT, HD><<<B * H, AT_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), S, H, scale,
                                                static_cast<uint16_t*>(out), lse);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
 
-template <int NT>
+template <int NT, int HD>
 int launch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int S, int H, float scale,
                void* dqkv, hipStream_t st) {
   constexpr int lds = 4 * NT * 16 * AT_ROWB + 2 * NT * 16 * 4;
   static bool attr = false;
   if (!attr) {
-    const int rc = at_set_lds(&attn_bwd<NT>, lds);
+    const int rc = at_set_lds(&attn_bwd<NT, HD>, lds);
     if (rc != WM_OK) return rc;
     attr = true;
   }
-  attn_bwd<NT><<<B * H, AT_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), static_cast<const uint16_t*>(out),
+  attn_bwd<NT, HD><<<B * H, AT_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), static_cast<const uint16_t*>(out),
                                                static_cast<const uint16_t*>(dout), lse, S, H, scale,
                                                static_cast<uint16_t*>(dqkv));
   WM_LAUNCH_CHECK();
@@ -320,32 +341,45 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
 
 inline bool at_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+template <int HD>
+int dispatch_fwd(const void* qkv, int B, int S, int H, float scale, void* out, float* lse, hipStream_t st) {
+  if (S <= 32) return launch_fwd<2, HD>(qkv, B, S, H, scale, out, lse, st);
+  if (S <= 64) return launch_fwd<4, HD>(qkv, B, S, H, scale, out, lse, st);
+  if (S <= 128) return launch_fwd<8, HD>(qkv, B, S, H, scale, out, lse, st);
+  if (S <= 224) return launch_fwd<14, HD>(qkv, B, S, H, scale, out, lse, st);
+  return launch_fwd<16, HD>(qkv, B, S, H, scale, out, lse, st);
+}
+
+template <int HD>
+int dispatch_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int S, int H, float scale,
+                 void* dqkv, hipStream_t st) {
+  if (S <= 32) return launch_bwd<2, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  if (S <= 64) return launch_bwd<4, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  if (S <= 128) return launch_bwd<8, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  if (S <= 224) return launch_bwd<14, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  return launch_bwd<16, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+}
+
 }  // namespace
 
-extern "C" int wm_attention_fwd(const void* qkv, int B, int S, int H, float scale, void* out, float* lse,
-                                void* stream) {
+extern "C" int wm_attention_fwd(const void* qkv, int B, int S, int H, int head_dim, float scale, void* out,
+                                float* lse, void* stream) {
   WM_REQUIRE(qkv && out && lse, WM_EINVAL);
   WM_REQUIRE(B > 0 && S > 0 && H > 0 && (long long)B * H < (1ll << 31), WM_EINVAL);
-  WM_REQUIRE(S <= 256, WM_EUNSUPPORTED);
+  WM_REQUIRE(S <= 256 && (head_dim == 64 || head_dim == 32), WM_EUNSUPPORTED);
   WM_REQUIRE(at_al16(qkv) && at_al16(out), WM_EALIGN);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (S <= 32) return launch_fwd<2>(qkv, B, S, H, scale, out, lse, st);
-  if (S <= 64) return launch_fwd<4>(qkv, B, S, H, scale, out, lse, st);
-  if (S <= 128) return launch_fwd<8>(qkv, B, S, H, scale, out, lse, st);
-  if (S <= 224) return launch_fwd<14>(qkv, B, S, H, scale, out, lse, st);
-  return launch_fwd<16>(qkv, B, S, H, scale, out, lse, st);
+  if (head_dim == 64) return dispatch_fwd<64>(qkv, B, S, H, scale, out, lse, st);
+  return dispatch_fwd<32>(qkv, B, S, H, scale, out, lse, st);
 }
 
 extern "C" int wm_attention_bwd(const void* qkv, const void* out, const void* dout, const float* lse, int B, int S,
-                                int H, float scale, void* dqkv, void* stream) {
+                                int H, int head_dim, float scale, void* dqkv, void* stream) {
   WM_REQUIRE(qkv && out && dout && lse && dqkv, WM_EINVAL);
   WM_REQUIRE(B > 0 && S > 0 && H > 0 && (long long)B * H < (1ll << 31), WM_EINVAL);
-  WM_REQUIRE(S <= 256, WM_EUNSUPPORTED);
+  WM_REQUIRE(S <= 256 && (head_dim == 64 || head_dim == 32), WM_EUNSUPPORTED);
   WM_REQUIRE(at_al16(qkv) && at_al16(out) && at_al16(dout) && at_al16(dqkv), WM_EALIGN);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (S <= 32) return launch_bwd<2>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
-  if (S <= 64) return launch_bwd<4>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
-  if (S <= 128) return launch_bwd<8>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
-  if (S <= 224) return launch_bwd<14>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
-  return launch_bwd<16>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  if (head_dim == 64) return dispatch_bwd<64>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  return dispatch_bwd<32>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
 }

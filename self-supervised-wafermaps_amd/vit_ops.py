@@ -125,32 +125,36 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 class _Attention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv, b, s, h, scale):
+    def forward(ctx, qkv, b, s, h, hd, scale):
         _need_cuda(qkv, "attention")
         qkv = _bf16_rows(qkv)
-        if qkv.shape != (b * s, 3 * h * 64):
-            raise ValueError(f"attention: qkv {tuple(qkv.shape)} vs B={b} S={s} H={h} (head dim 64)")
-        out = torch.empty((b * s, h * 64), dtype=torch.bfloat16, device=qkv.device)
+        if qkv.shape != (b * s, 3 * h * hd):
+            raise ValueError(f"attention: qkv {tuple(qkv.shape)} vs B={b} S={s} H={h} head_dim={hd}")
+        out = torch.empty((b * s, h * hd), dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty((b, h, s), dtype=torch.float32, device=qkv.device)
-        check(_lib.load().wm_attention_fwd(ptr(qkv), b, s, h, scale, ptr(out), ptr(lse), stream_ptr()), "wm_attention_fwd")
+        check(_lib.load().wm_attention_fwd(ptr(qkv), b, s, h, hd, scale, ptr(out), ptr(lse), stream_ptr()),
+              "wm_attention_fwd")
         ctx.save_for_backward(qkv, out, lse)
-        ctx.geom = (b, s, h, scale)
+        ctx.geom = (b, s, h, hd, scale)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         qkv, out, lse = ctx.saved_tensors
-        b, s, h, scale = ctx.geom
+        b, s, h, hd, scale = ctx.geom
         dout = _bf16_rows(dout)
         dqkv = torch.empty_like(qkv)
-        check(_lib.load().wm_attention_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), b, s, h, scale, ptr(dqkv),
+        check(_lib.load().wm_attention_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), b, s, h, hd, scale, ptr(dqkv),
                                            stream_ptr()), "wm_attention_bwd")
-        return dqkv, None, None, None, None
+        return dqkv, None, None, None, None, None
 
 
-def attention(qkv: torch.Tensor, batch: int, seq: int, heads: int, scale: Optional[float] = None) -> torch.Tensor:
-    """softmax(scale q k^T) v per head; qkv bf16 [B*S, 3*H*64] as the qkv Linear emits it -> [B*S, H*64]."""
-    return _Attention.apply(qkv, int(batch), int(seq), int(heads), float(64 ** -0.5 if scale is None else scale))
+def attention(qkv: torch.Tensor, batch: int, seq: int, heads: int, scale: Optional[float] = None,
+              head_dim: int = 64) -> torch.Tensor:
+    """softmax(scale q k^T) v per head; qkv bf16 [B*S, 3*H*hd] as the qkv Linear emits it -> [B*S, H*hd]
+    (head_dim 64: ViT-S/16, ViT-B/32; 32: the MAE decoder's 512 / 16)."""
+    return _Attention.apply(qkv, int(batch), int(seq), int(heads), int(head_dim),
+                            float(head_dim ** -0.5 if scale is None else scale))
 
 
 class _PatchEmbed(torch.autograd.Function):

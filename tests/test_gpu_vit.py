@@ -81,25 +81,26 @@ def test_bias_act(rows, c, act, res):
         _close(rd.grad, rr.grad, what="dres")
 
 
-@pytest.mark.parametrize("b,s,h", [(3, 197, 6), (4, 37, 6), (2, 50, 12), (5, 13, 12), (1, 256, 2), (2, 128, 1),
-                                   (2, 1, 3), (2, 224, 2)])
-def test_attention_matches_torch(b, s, h):
+@pytest.mark.parametrize("b,s,h,hd", [(3, 197, 6, 64), (4, 37, 6, 64), (2, 50, 12, 64), (5, 13, 12, 64), (1, 256, 2, 64),
+                                      (2, 128, 1, 64), (2, 1, 3, 64), (2, 224, 2, 64), (3, 50, 16, 32), (2, 12, 16, 32),
+                                      (1, 250, 2, 32), (2, 100, 3, 32)])
+def test_attention_matches_torch(b, s, h, hd):
     from ssl_wafermap_amd import vit_ops
 
     g = torch.Generator().manual_seed(b * 1000 + s)
-    qkv = _bf(torch.randn(b, s, 3, h, 64, generator=g))
-    do = _bf(torch.randn(b, s, h, 64, generator=g))
+    qkv = _bf(torch.randn(b, s, 3, h, hd, generator=g))
+    do = _bf(torch.randn(b, s, h, hd, generator=g))
     qr = qkv.clone().requires_grad_(True)
     q, k, v = qr[:, :, 0].transpose(1, 2), qr[:, :, 1].transpose(1, 2), qr[:, :, 2].transpose(1, 2)  # [b,h,s,64]
-    p = ((q @ k.transpose(-2, -1)) * 0.125).softmax(-1)
-    ref = (p @ v).transpose(1, 2)  # [b,s,h,64]
+    p = ((q @ k.transpose(-2, -1)) * hd ** -0.5).softmax(-1)
+    ref = (p @ v).transpose(1, 2)  # [b,s,h,hd]
     ref.backward(do)
-    qd = qkv.to(DEV).bfloat16().reshape(b * s, 3 * h * 64).requires_grad_(True)
-    out = vit_ops.attention(qd, b, s, h)
-    out.backward(do.to(DEV).bfloat16().reshape(b * s, h * 64))
+    qd = qkv.to(DEV).bfloat16().reshape(b * s, 3 * h * hd).requires_grad_(True)
+    out = vit_ops.attention(qd, b, s, h, head_dim=hd)
+    out.backward(do.to(DEV).bfloat16().reshape(b * s, h * hd))
     # P is rounded to bf16 before the PV product: 2^-9 relative on each probability
-    _close(out, ref.detach().reshape(b * s, h * 64), rel=1.5e-2, what="out")
-    _close(qd.grad, qr.grad.reshape(b * s, 3 * h * 64), rel=2.5e-2, what="dqkv")
+    _close(out, ref.detach().reshape(b * s, h * hd), rel=1.5e-2, what="out")
+    _close(qd.grad, qr.grad.reshape(b * s, 3 * h * hd), rel=2.5e-2, what="dqkv")
     assert _cos(qd.grad, qr.grad) > 0.999
 
 
@@ -357,3 +358,61 @@ def test_dino_training_step_matches_oracle_and_learns():
         loss = model.training_step(batch, i + 1)
         loss.backward()
     assert math.isfinite(float(loss)) and float(loss) < first, (first, float(loss))
+
+
+def test_mae_training_step_matches_oracle_and_learns():
+    """MAE step (2-block ViT-B/32 encoder to keep it quick, the reference's 1-block 512/16 decoder) on
+    identical weights and token masks: loss, gradients, and a falling loss under AdamW."""
+    from oracle import vit as ov
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models import MAE
+    from ssl_wafermap_amd.models.mae import MAEBackbone
+    from ssl_wafermap_amd.utils import random_token_mask
+
+    torch.manual_seed(0)
+    model = MAE(None, 9, batch_size=8, log_rep_std=False)
+    model.backbone = MAEBackbone(224, 32, 2, 12, 768, 3072)
+    with torch.no_grad():
+        model.mask_token.normal_(std=0.02)
+        for p_ in model.parameters():
+            if p_.dim() == 1:
+                p_.add_(torch.randn_like(p_) * 0.02)
+    model = model.to(DEV).train()
+    b = 8
+    g = torch.Generator().manual_seed(4)
+    images = _bf(torch.randn(b, 3, 224, 224, generator=g)).to(DEV)
+    keep, mask = random_token_mask((b, 50), 0.75, generator=g)
+    keep, mask = keep.to(DEV), mask.to(DEV)
+    sd = {k: v.detach().clone().float().requires_grad_(True) for k, v in model.state_dict().items()}
+    ref = ov.mae_loss(images, sd, keep, mask)
+    ref.backward()
+
+    x_enc = model.forward_encoder(ops.to_nhwc_bf16(images), keep)
+    pred = model.forward_decoder(x_enc, keep, mask)
+    from ssl_wafermap_amd.utils import get_at_index, patchify
+
+    target = get_at_index(patchify(ops.to_nhwc_bf16(images), 32), mask - 1)
+    torch.testing.assert_close(target.float(), torch.gather(ov.lightly_patchify(images, 32), 1,
+                                                             (mask - 1).unsqueeze(-1).expand(-1, -1, 3072)))
+    loss = model.criterion(pred, target)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 5e-3 * abs(float(ref.detach())), (float(loss), float(ref))
+    pairs = [(k, p_.grad, sd[k].grad) for k, p_ in model.named_parameters()]
+    top = max(float(r.norm() / math.sqrt(r.numel())) for _, _, r in pairs)
+    cos = [(_cos(a, r), k) for k, a, r in pairs if float(r.norm() / math.sqrt(r.numel())) > 1e-3 * top]
+    worst, med = min(cos), float(np.median([c for c, _ in cos]))
+    assert worst[0] > 0.9 and med > 0.98, (worst, med, len(cos), len(pairs))
+
+    (opt,), _ = model.configure_optimizers()
+    for grp in opt.param_groups:
+        grp["lr"] = 3e-4
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    batch = ([ops.to_nhwc_bf16(images)], None)
+    losses = []
+    for i in range(8):
+        opt.zero_grad()
+        l_ = model.training_step(batch, i, generator=gen)
+        l_.backward()
+        opt.step()
+        losses.append(float(l_.detach()))
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
