@@ -426,12 +426,16 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
         glds16(src, lds_addr(stage + A_BYTES + t * X_BYTES + ((i * 4 + wave) * 8) * RB));
       }
       // advance this row by one chunk (64 pixels)
-      pq[i] += WG_PIX;
-      while (pq[i] >= a.Q) {
-        pq[i] -= a.Q;
-        if (++pp[i] == a.P) {
-          pp[i] = 0;
-          ++pn[i];
+      if (pqn == 1) {
+        pn[i] += WG_PIX;  // Linear layers (1x1 image): a row is an image
+      } else {
+        pq[i] += WG_PIX;
+        while (pq[i] >= a.Q) {
+          pq[i] -= a.Q;
+          if (++pp[i] == a.P) {
+            pp[i] = 0;
+            ++pn[i];
+          }
         }
       }
     }

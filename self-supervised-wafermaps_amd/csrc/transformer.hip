@@ -218,7 +218,34 @@ __global__ __launch_bounds__(TF_THREADS) void colsum_kernel(const uint16_t* __re
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
-    for (long long r = r0 + rl; r < r1; r += RL) {
+    // four rows per trip: the loads of a trip are independent and issued together
+    long long r = r0 + rl;
+    for (; r + 3 * RL < r1; r += 4 * RL) {
+      uint4 vd[4], vx[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const size_t off = (size_t)(r + u * RL) * C + ch * 8;
+        vd[u] = *reinterpret_cast<const uint4*>(dy + off);
+        if (MODE == 2) vx[u] = *reinterpret_cast<const uint4*>(x + off);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        float fd[8];
+        unpack8(vd[u], fd);
+        if (MODE == 2) {
+          float fx[8];
+          unpack8(vx[u], fx);
+#pragma unroll
+          for (int e = 0; e < 8; ++e) fd[e] *= gelu_grad(fx[e] + b[e]);
+          const uint4 pk = pack8(fd);
+          *reinterpret_cast<uint4*>(dx + (size_t)(r + u * RL) * C + ch * 8) = pk;
+          unpack8(pk, fd);  // the sums see the rounded gradient, like a separate reduction would
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] += fd[e];
+      }
+    }
+    for (; r < r1; r += RL) {
       const size_t off = (size_t)r * C + ch * 8;
       float fd[8];
       unpack8(*reinterpret_cast<const uint4*>(dy + off), fd);
@@ -229,7 +256,7 @@ __global__ __launch_bounds__(TF_THREADS) void colsum_kernel(const uint16_t* __re
         for (int e = 0; e < 8; ++e) fd[e] *= gelu_grad(fx[e] + b[e]);
         const uint4 pk = pack8(fd);
         *reinterpret_cast<uint4*>(dx + off) = pk;
-        unpack8(pk, fd);  // the sums see the rounded gradient, like a separate reduction would
+        unpack8(pk, fd);
       }
 #pragma unroll
       for (int e = 0; e < 8; ++e) acc[e] += fd[e];

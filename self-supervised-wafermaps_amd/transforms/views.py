@@ -22,6 +22,10 @@ class Views(list):
 
     stacked = None
 
+    def __init__(self, *a):
+        super().__init__(*a)
+        self.stacked_groups = {}  # (first view, one past last) -> the launch buffer those views slice
+
 
 class MultiViewTransform:
     def __init__(self, transforms: Sequence[ViewSpec]):
@@ -61,6 +65,7 @@ class MultiViewTransform:
                                   params_dev=None if params_dev is None else params_dev[gi])
             for v in range(j - i):
                 out.append(batch[v * n:(v + 1) * n])
+            out.stacked_groups[(i, j)] = batch  # views i..j-1 are slices of this one buffer
             if len(groups) == 1:
                 out.stacked = batch
         return out
