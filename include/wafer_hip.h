@@ -188,6 +188,11 @@ int wm_conv2d_dgrad_add(const void* dy, const void* w_crsk, const void* residual
  * f32 atomics, so the caller zeroes dw_krsc first and the low bits depend on arrival order. */
 int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_krsc, int N, int H, int W, int C, int K,
                     int R, int S, int P, int Q, int stride, int pad, void* stream);
+/* Same, and dbias[K] += sum over pixels of dy (dbias may be NULL): a Linear layer's bias gradient comes
+ * out of the weight-gradient launch (one extra MFMA per dY fragment in the first column group's
+ * blocks) instead of a separate reduction pass over dy. */
+int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_krsc, float* dbias, int N, int H, int W, int C,
+                         int K, int R, int S, int P, int Q, int stride, int pad, void* stream);
 
 /* f32 OIHW master weights -> bf16 [K][R][S][C] and/or [C][R][S][K] (either may be NULL). */
 int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int S, void* w_krsc, void* w_crsk,

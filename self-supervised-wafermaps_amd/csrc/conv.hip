@@ -320,6 +320,10 @@ struct WgradArgs {
   const uint16_t* x;   // [N][H][W][C]
   float* dw;           // [K][R][S][C] f32, accumulated with atomics
   int N, H, W, C, K, R, S, P, Q, stride, pad, M, chunks_per_split, total_chunks;
+  // optional bias gradient dbias[K] += sum over pixels of dy: the blocks of the first column group
+  // multiply their dY fragments with an all-ones B operand (one extra MFMA per fragment and k-step),
+  // so a Linear layer's bias gradient costs no extra pass over dY
+  float* dbias;
 };
 
 constexpr int WG_PIX = 64;  // pixels per staged chunk (two MFMA k-steps)
@@ -446,6 +450,13 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   for (int i = 0; i < MJ; ++i)
 #pragma unroll
     for (int j = 0; j < WT * NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  // bias gradient: only column group 0, and only one of the waves that share a channel range
+  const bool bias_wave = a.dbias != nullptr && blockIdx.x == 0 && (SQ ? (wave & 1) == 0 : (BMO == 128 || (wave & 1) == 0));
+  f32x4_t bacc[MJ];
+#pragma unroll
+  for (int i = 0; i < MJ; ++i) bacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+  const s16x8_t ones_s = {0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80};
+  const bf16x8_t ones = __builtin_bit_cast(bf16x8_t, ones_s);
 
   // transposed-read geometry: 16-lane group g, lane (q, p) inside it; MFMA k-slot (g, e) holds
   // pixel 4g + e (e < 4) or 16 + 4g + (e - 4) of the 32-pixel k-step — same map for both operands.
@@ -465,6 +476,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
         const s16x4_t hi = tr_read(buf + r1 * RA + wg_swz<RA>(r1, blk) * 32 + 8 * tp);
         const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         af[i] = __builtin_bit_cast(bf16x8_t, v);
+      }
+      if (bias_wave) {
+#pragma unroll
+        for (int i = 0; i < MJ; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, bacc[i], 0, 0, 0);
       }
 #pragma unroll
       for (int t = 0; t < WT; ++t) {
@@ -509,6 +524,12 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
           const int col = (ct0 + tile_w + t) * 64 + col_w + j * 16 + fr;
           atomicAdd(a.dw + (size_t)kk * rsc + col, acc[i][t * NJ + j][e]);
         }
+  if (bias_wave && fr == 0) {  // every column of bacc holds the same sums: lane column 0 reports
+#pragma unroll
+    for (int i = 0; i < MJ; ++i)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) atomicAdd(a.dbias + k0 + cout_w + i * 16 + fg * 4 + e, bacc[i][e]);
+  }
 }
 
 template <typename K>
@@ -669,6 +690,12 @@ static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const v
 extern "C" int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_krsc, int N, int H, int W,
                                int C, int K, int R, int S, int P, int Q, int stride, int pad,
                                void* stream) {
+  return wm_conv2d_wgrad_bias(dy, x, dw_krsc, nullptr, N, H, W, C, K, R, S, P, Q, stride, pad, stream);
+}
+
+extern "C" int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_krsc, float* dbias, int N, int H,
+                                    int W, int C, int K, int R, int S, int P, int Q, int stride, int pad,
+                                    void* stream) {
   WM_REQUIRE(dy && x && dw_krsc, WM_EINVAL);
   const int rc = conv_check(N, H, W, C, K, R, S, P, Q, stride, pad);
   if (rc != WM_OK) return rc;
@@ -677,6 +704,7 @@ extern "C" int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_krsc, in
   a.dy = static_cast<const uint16_t*>(dy);
   a.x = static_cast<const uint16_t*>(x);
   a.dw = dw_krsc;
+  a.dbias = dbias;
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.P = P; a.Q = Q;
   a.stride = stride; a.pad = pad; a.M = N * P * Q;
   a.chunks_per_split = 0; a.total_chunks = 0;

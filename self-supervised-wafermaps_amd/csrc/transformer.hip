@@ -287,8 +287,9 @@ int launch_colsum(const void* x, const float* bias, const void* dy, long long ro
   const int nch = C >> 3;
   const int CB = nch <= 64 ? nch : 64;
   const int slabs = wm_cdiv(nch, CB);
-  // ~2048 blocks in total, at least 64 rows each
-  int rb = wm_cdiv(2048, slabs);
+  // ~768 blocks in total (3 per CU), at least 64 rows each: every block ends with one f32 atomic per
+  // channel on the SAME addresses, and a chain of N same-address atomics costs ~0.1 us x N
+  int rb = wm_cdiv(768, slabs);
   long long rpb = (rows + rb - 1) / rb;
   if (rpb < 64) rpb = 64;
   rb = wm_cdiv(rows, rpb);
@@ -599,7 +600,7 @@ extern "C" int wm_layernorm_bwd(const void* x, const void* dy, const float* gamm
   WM_REQUIRE(C <= 64 * 8 * LN_MAXV, WM_EUNSUPPORTED);
   WM_REQUIRE(al16(x) && al16(dy) && al16(dx) && al16(gamma), WM_EALIGN);
   long long blocks = (rows + 3) / 4;
-  if (blocks > 1024) blocks = 1024;
+  if (blocks > 512) blocks = 512;  // same-address atomic chains at the end: keep them short
   ln_bwd<<<(int)blocks, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
       static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), gamma, mean, rstd, rows, C,
       static_cast<uint16_t*>(dx), dgamma, dbeta);

@@ -114,9 +114,66 @@ def bias_act(x: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
     return _BiasAct.apply(x, bias, residual, int(act))
 
 
+class _LinearBias(torch.autograd.Function):
+    """out = x @ W^T + bias (+ residual).  Backward: the bias gradient rides in the weight-gradient
+    launch (wm_conv2d_wgrad_bias), so dout is read by exactly two kernels (dgrad, wgrad)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual):
+        _need_cuda(x, "linear")
+        x = _bf16_rows(x)
+        rows, c = x.shape
+        k = weight.shape[0]
+        if weight.shape[1] != c:
+            raise ValueError(f"linear: x {tuple(x.shape)} vs weight {tuple(weight.shape)}")
+        train = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
+        krsc, _ = ops._WCACHE.get(weight, kind="linear", need_crsk=train and x.requires_grad)
+        lib = _lib.load()
+        y = torch.empty((rows, k), dtype=torch.bfloat16, device=x.device)
+        check(lib.wm_conv2d_fwd(ptr(x), ptr(krsc), ptr(y), rows, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
+              "wm_conv2d_fwd(linear)")
+        if residual is not None:
+            residual = _bf16_rows(residual)
+        # epilogue in place: element t is read and written by the same lane
+        check(lib.wm_bias_act_fwd(ptr(y), ptr(bias), ptr(residual), ACT_NONE, rows, k, ptr(y), stream_ptr()),
+              "wm_bias_act_fwd")
+        ctx.save_for_backward(x)
+        ctx.params = (weight, bias)
+        ctx.geom = (rows, c, k)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dout):
+        (x,) = ctx.saved_tensors
+        weight, bias = ctx.params
+        rows, c, k = ctx.geom
+        dout = _bf16_rows(dout)
+        lib = _lib.load()
+        dx = dw = db_ret = None
+        if ctx.needs_input_grad[0]:
+            _, crsk = ops._WCACHE.get(weight, kind="linear", need_crsk=True)
+            dx = torch.empty((rows, c), dtype=torch.bfloat16, device=dout.device)
+            check(lib.wm_conv2d_dgrad(ptr(dout), ptr(crsk), ptr(dx), rows, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
+                  "wm_conv2d_dgrad(linear)")
+        want_b = bias is not None and bias.requires_grad
+        if ctx.needs_input_grad[1] or want_b:
+            db = None
+            if want_b:
+                db, db_ret = _grad_target(bias)
+            slot = _arena_grad(weight)
+            tgt = slot if slot is not None else torch.zeros((k, c), dtype=torch.float32, device=dout.device)
+            check(lib.wm_conv2d_wgrad_bias(ptr(dout), ptr(x), ptr(tgt), ptr(db), rows, 1, 1, c, k, 1, 1, 1, 1, 1, 0,
+                                           stream_ptr()), "wm_conv2d_wgrad_bias(linear)")
+            dw = None if slot is not None else tgt
+        return dx, dw, db_ret, (dout if ctx.has_res else None)
+
+
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(x @ W^T + bias) (+ residual) on bf16 [rows, C]: the GEMM kernel, then one epilogue pass."""
+    if act == ACT_NONE and (bias is not None or residual is not None):
+        return _LinearBias.apply(x, weight, bias, residual)
     y = ops.linear(x, weight)
     if bias is None and act == ACT_NONE and residual is None:
         return y

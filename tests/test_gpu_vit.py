@@ -81,6 +81,35 @@ def test_bias_act(rows, c, act, res):
         _close(rd.grad, rr.grad, what="dres")
 
 
+@pytest.mark.parametrize("rows,c,k,res", [(591, 384, 1152, False), (100, 768, 3072, False), (1000, 1536, 384, True),
+                                           (37, 512, 512, True), (5000, 384, 384, False), (64, 256, 2048, False)])
+def test_linear_bias_gradient_rides_in_wgrad(rows, c, k, res):
+    from ssl_wafermap_amd import vit_ops
+
+    g = torch.Generator().manual_seed(rows + k)
+    x = _bf(torch.randn(rows, c, generator=g))
+    w = _bf(torch.randn(k, c, generator=g) * 0.05)
+    b = torch.randn(k, generator=g) * 0.2
+    r = _bf(torch.randn(rows, k, generator=g)) if res else None
+    dy = _bf(torch.randn(rows, k, generator=g))
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = _bf(F.linear(xr, wr)) + br
+    if res:
+        rr = r.clone().requires_grad_(True)
+        ref = ref + rr
+    ref.backward(dy)
+    xd, wd, bd = x.to(DEV).bfloat16().requires_grad_(True), w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    rd = r.to(DEV).bfloat16().requires_grad_(True) if res else None
+    y = vit_ops.linear(xd, wd, bd, residual=rd)
+    y.backward(dy.to(DEV).bfloat16())
+    _close(y, ref.detach(), what="y")
+    _close(xd.grad, xr.grad, what="dx")
+    _close(wd.grad, wr.grad, what="dW")
+    _close(bd.grad, br.grad, rel=5e-3, what="dbias")
+    if res:
+        _close(rd.grad, rr.grad, what="dres")
+
+
 @pytest.mark.parametrize("b,s,h,hd", [(3, 197, 6, 64), (4, 37, 6, 64), (2, 50, 12, 64), (5, 13, 12, 64), (1, 256, 2, 64),
                                       (2, 128, 1, 64), (2, 1, 3, 64), (2, 224, 2, 64), (3, 50, 16, 32), (2, 12, 16, 32),
                                       (1, 250, 2, 32), (2, 100, 3, 32)])
