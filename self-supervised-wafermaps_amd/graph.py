@@ -71,7 +71,9 @@ class GraphedTrainStep:
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        # thread_local: other threads of the process (the RCCL watchdog of torch.distributed polls its
+        # events while we record) must not invalidate the capture
+        with torch.cuda.graph(g, capture_error_mode="thread_local"):
             self.loss = self._body()
         self.graph = g
         return self
