@@ -125,7 +125,42 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restri
       }
     }
     if (rr < rpp) {
-      for (int r = r_begin + rr; r < r_end; r += rpp) {
+      int r = r_begin + rr;
+      if (MODE == 1 && ps.dy == nullptr) {
+        // four rows per trip: their 8-12 loads are independent and issued together (one row per trip
+        // leaves a single 16-byte load per lane in flight and the pass latency-bound at ~3 TB/s)
+        for (; r + 3 * rpp < r_end; r += 4 * rpp) {
+          uint4 vy[4], vd[4], vo[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const size_t off = (gbase + r + u * rpp) * C + cidx * 8;
+            vy[u] = *reinterpret_cast<const uint4*>(y + off);
+            vd[u] = *reinterpret_cast<const uint4*>(dout + off);
+            if (out) vo[u] = *reinterpret_cast<const uint4*>(out + off);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            float fy[8], fd[8];
+            unpack8(vy[u], fy);
+            unpack8(vd[u], fd);
+            if (out) {
+              float fo[8];
+              unpack8(vo[u], fo);
+#pragma unroll
+              for (int e = 0; e < 8; ++e) fd[e] = fo[e] > 0.f ? fd[e] : 0.f;
+            } else if (remask) {
+#pragma unroll
+              for (int e = 0; e < 8; ++e) fd[e] = bf2f(f2bf(fmaf(fy[e], msc[e], msh[e]))) > 0.f ? fd[e] : 0.f;
+            }
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              s1[e] += fd[e];
+              s2[e] = fmaf(fd[e], (fy[e] - mu[e]) * is[e], s2[e]);
+            }
+          }
+        }
+      }
+      for (; r < r_end; r += rpp) {
         const size_t off = (gbase + r) * C + cidx * 8;
         float fy[8];
         unpack8(*reinterpret_cast<const uint4*>(y + off), fy);
@@ -264,27 +299,45 @@ __global__ void bn_eval_params(const float* __restrict__ gamma, const float* __r
   }
 }
 
+// POW2: C/8 is a power of two dividing the block size, so a thread keeps its channel chunk for the whole
+// grid-stride loop: no divisions, and the per-channel coefficients are loaded once per statistics
+// group instead of once per 16-byte item.
+template <bool POW2>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply(const uint16_t* __restrict__ y,
                                                        const uint16_t* __restrict__ residual,
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        long long rows, int C, int rows_per_group,
-                                                       int relu, uint16_t* __restrict__ out) {
+                                                       int relu, int cshift, uint16_t* __restrict__ out) {
   const int cpr = C >> 3;
   const long long total = rows * cpr;
+  int cur_g = -1;
+  float sc[8], sh[8];
   for (long long p = (long long)blockIdx.x * BN_THREADS + threadIdx.x; p < total;
        p += (long long)gridDim.x * BN_THREADS) {
-    const long long row = p / cpr;
-    const int c0 = (int)(p - row * cpr) * 8;
-    const int g = (int)(row / rows_per_group);
+    long long row;
+    int c0, g;
+    if (POW2) {
+      row = p >> cshift;
+      c0 = (int)(p & (cpr - 1)) * 8;
+      g = 0;
+      for (long long lim = rows_per_group; row >= lim; lim += rows_per_group) ++g;
+    } else {
+      row = p / cpr;
+      c0 = (int)(p - row * cpr) * 8;
+      g = (int)(row / rows_per_group);
+    }
+    if (!POW2 || g != cur_g) {
+      const float4 sa = *reinterpret_cast<const float4*>(scale + (size_t)g * C + c0);
+      const float4 sb = *reinterpret_cast<const float4*>(scale + (size_t)g * C + c0 + 4);
+      const float4 ha = *reinterpret_cast<const float4*>(shift + (size_t)g * C + c0);
+      const float4 hb = *reinterpret_cast<const float4*>(shift + (size_t)g * C + c0 + 4);
+      sc[0] = sa.x; sc[1] = sa.y; sc[2] = sa.z; sc[3] = sa.w; sc[4] = sb.x; sc[5] = sb.y; sc[6] = sb.z; sc[7] = sb.w;
+      sh[0] = ha.x; sh[1] = ha.y; sh[2] = ha.z; sh[3] = ha.w; sh[4] = hb.x; sh[5] = hb.y; sh[6] = hb.z; sh[7] = hb.w;
+      cur_g = g;
+    }
     float f[8];
     unpack8(*reinterpret_cast<const uint4*>(y + row * C + c0), f);
-    const float4 sa = *reinterpret_cast<const float4*>(scale + (size_t)g * C + c0);
-    const float4 sb = *reinterpret_cast<const float4*>(scale + (size_t)g * C + c0 + 4);
-    const float4 ha = *reinterpret_cast<const float4*>(shift + (size_t)g * C + c0);
-    const float4 hb = *reinterpret_cast<const float4*>(shift + (size_t)g * C + c0 + 4);
-    const float sc[8] = {sa.x, sa.y, sa.z, sa.w, sb.x, sb.y, sb.z, sb.w};
-    const float sh[8] = {ha.x, ha.y, ha.z, ha.w, hb.x, hb.y, hb.z, hb.w};
 #pragma unroll
     for (int e = 0; e < 8; ++e) f[e] = fmaf(f[e], sc[e], sh[e]);
     if (residual) {
@@ -338,20 +391,43 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize(
   }
 }
 
+template <bool POW2>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __restrict__ y,
                                                            const uint16_t* __restrict__ dout,
                                                            const uint16_t* __restrict__ out,
                                                            const float* __restrict__ coef,
                                                            long long rows, int C, int rows_per_group,
-                                                           int remask, uint16_t* __restrict__ dy,
+                                                           int remask, int cshift, uint16_t* __restrict__ dy,
                                                            uint16_t* __restrict__ dz, const PoolSrc ps) {
   const int cpr = C >> 3;
   const long long total = rows * cpr;
+  int cur_g = -1;
+  float k[7][8];  // mean, invstd, gamma*invstd, s1/M, s2/M, forward scale, forward shift
   for (long long p = (long long)blockIdx.x * BN_THREADS + threadIdx.x; p < total;
        p += (long long)gridDim.x * BN_THREADS) {
-    const long long row = p / cpr;
-    const int c0 = (int)(p - row * cpr) * 8;
-    const int g = (int)(row / rows_per_group);
+    long long row;
+    int c0, g;
+    if (POW2) {
+      row = p >> cshift;
+      c0 = (int)(p & (cpr - 1)) * 8;
+      g = 0;
+      for (long long lim = rows_per_group; row >= lim; lim += rows_per_group) ++g;
+    } else {
+      row = p / cpr;
+      c0 = (int)(p - row * cpr) * 8;
+      g = (int)(row / rows_per_group);
+    }
+    if (!POW2 || g != cur_g) {
+      const float* cf = coef + (size_t)g * 7 * C + c0;
+#pragma unroll
+      for (int t = 0; t < 7; ++t) {
+        const float4 a = *reinterpret_cast<const float4*>(cf + (size_t)t * C);
+        const float4 b = *reinterpret_cast<const float4*>(cf + (size_t)t * C + 4);
+        k[t][0] = a.x; k[t][1] = a.y; k[t][2] = a.z; k[t][3] = a.w;
+        k[t][4] = b.x; k[t][5] = b.y; k[t][6] = b.z; k[t][7] = b.w;
+      }
+      cur_g = g;
+    }
     const size_t off = row * C + c0;
     float fy[8], fd[8];
     unpack8(*reinterpret_cast<const uint4*>(y + off), fy);
@@ -363,20 +439,28 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __res
 #pragma unroll
       for (int e = 0; e < 8; ++e) fd[e] = fo[e] > 0.f ? fd[e] : 0.f;
     }
-    const float* cf = coef + (size_t)g * 7 * C + c0;
     if (!out && remask) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) fd[e] = bf2f(f2bf(fmaf(fy[e], cf[5 * C + e], cf[6 * C + e]))) > 0.f ? fd[e] : 0.f;
+      for (int e = 0; e < 8; ++e) fd[e] = bf2f(f2bf(fmaf(fy[e], k[5][e], k[6][e]))) > 0.f ? fd[e] : 0.f;
     }
     if (dz) *reinterpret_cast<uint4*>(dz + off) = pack8(fd);
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
-      const float xh = (fy[e] - cf[e]) * cf[C + e];
-      r[e] = cf[2 * C + e] * (fd[e] - cf[3 * C + e] - xh * cf[4 * C + e]);
+      const float xh = (fy[e] - k[0][e]) * k[1][e];
+      r[e] = k[2][e] * (fd[e] - k[3][e] - xh * k[4][e]);
     }
     *reinterpret_cast<uint4*>(dy + off) = pack8(r);
   }
+}
+
+inline bool chunk_pow2(int C, int* shift) {
+  const int cpr = C >> 3;
+  if (cpr <= 0 || (cpr & (cpr - 1)) || BN_THREADS % cpr) return false;
+  int sft = 0;
+  while ((1 << sft) < cpr) ++sft;
+  *shift = sft;
+  return true;
 }
 
 __global__ __launch_bounds__(BN_THREADS) void add_bf16_kernel(const uint16_t* __restrict__ a,
@@ -407,6 +491,19 @@ inline int stream_grid(long long items) {
   if (b > 256 * 16) b = 256 * 16;
   if (b < 1) b = 1;
   return (int)b;
+}
+
+inline void launch_bn_apply(const void* y, const void* residual, const float* scale, const float* shift, long long rows,
+                            int C, int rpg, int relu, void* out, hipStream_t st) {
+  int csh = 0;
+  if (chunk_pow2(C, &csh))
+    bn_apply<true><<<stream_grid(rows * (C >> 3)), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(residual), scale, shift, rows, C, rpg, relu, csh,
+        static_cast<uint16_t*>(out));
+  else
+    bn_apply<false><<<stream_grid(rows * (C >> 3)), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(residual), scale, shift, rows, C, rpg, relu, csh,
+        static_cast<uint16_t*>(out));
 }
 
 int bn_shape_check(long long rows, int C, int G) {
@@ -448,9 +545,7 @@ extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float*
   bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, 0, gamma, beta, eps, momentum, running_mean,
                                                    running_var, save_mean, save_invstd, scale, shift);
   WM_LAUNCH_CHECK();
-  bn_apply<<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(static_cast<const uint16_t*>(y),
-                                                           static_cast<const uint16_t*>(residual), scale, shift,
-                                                           rows, C, rpg, relu, static_cast<uint16_t*>(out));
+  launch_bn_apply(y, residual, scale, shift, rows, C, rpg, relu, out, st);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -475,9 +570,7 @@ extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, c
   bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(stat_part, stat_buckets, G, C, rpg, 1, gamma, beta, eps, momentum,
                                                    running_mean, running_var, save_mean, save_invstd, scale, shift);
   WM_LAUNCH_CHECK();
-  bn_apply<<<stream_grid(rows * (C >> 3)), BN_THREADS, 0, st>>>(static_cast<const uint16_t*>(y),
-                                                                static_cast<const uint16_t*>(residual), scale, shift,
-                                                                rows, C, rpg, relu, static_cast<uint16_t*>(out));
+  launch_bn_apply(y, residual, scale, shift, rows, C, rpg, relu, out, st);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -539,9 +632,8 @@ extern "C" int wm_bn_eval_fwd(const void* y, const void* residual, const float* 
   bn_eval_params<<<1, C < 1024 ? ((C + 63) / 64) * 64 : 1024, 0, st>>>(gamma, beta, running_mean, running_var, eps,
                                                                      C, scale, shift);
   WM_LAUNCH_CHECK();
-  bn_apply<<<stream_grid(rows * (C >> 3)), BN_THREADS, 0, st>>>(
-      static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(residual), scale, shift, rows, C,
-      (int)(rows < (1ll << 31) - 1 ? rows : (1ll << 31) - 1), relu, static_cast<uint16_t*>(out));
+  launch_bn_apply(y, residual, scale, shift, rows, C, (int)(rows < (1ll << 31) - 1 ? rows : (1ll << 31) - 1), relu, out,
+                  st);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -601,9 +693,15 @@ static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, in
   bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, beta, save_mean, save_invstd, dgamma,
                                                    dbeta, accumulate, coef);
   WM_LAUNCH_CHECK();
-  bn_bwd_apply<<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
-      static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
-      coef, rows, C, rpg, remask ? 1 : 0, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz), ps);
+  int csh = 0;
+  if (chunk_pow2(C, &csh))
+    bn_bwd_apply<true><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
+        coef, rows, C, rpg, remask ? 1 : 0, csh, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz), ps);
+  else
+    bn_bwd_apply<false><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
+        coef, rows, C, rpg, remask ? 1 : 0, csh, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz), ps);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

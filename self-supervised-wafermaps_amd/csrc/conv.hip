@@ -341,7 +341,7 @@ __device__ __forceinline__ int wg_swz(int row, int blk) {
 // A block owns BMO output channels x NT consecutive 64-column tiles of the (r,s,c) axis: the dY
 // tile is fetched once per 64-pixel chunk and multiplied against NT gathered X tiles, so the MFMA
 // work per barrier is NT x that of a single tile (layer1 and the stem have only 64 channels).
-template <int BMO, int CPT, int NT>
+template <int BMO, int CPT, int NT, bool BIAS>
 __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   extern __shared__ __attribute__((aligned(16))) uint8_t wg_smem[];
   constexpr int RA = BMO * 2;  // dY tile row bytes
@@ -451,7 +451,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
 #pragma unroll
     for (int j = 0; j < WT * NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
   // bias gradient: only column group 0, and only one of the waves that share a channel range
-  const bool bias_wave = a.dbias != nullptr && blockIdx.x == 0 && (SQ ? (wave & 1) == 0 : (BMO == 128 || (wave & 1) == 0));
+  // (BIAS is a template flag: carrying the extra accumulators in the convolution instantiations
+  // cost them ~12 %)
+  const bool bias_wave = BIAS && blockIdx.x == 0 && (SQ ? (wave & 1) == 0 : (BMO == 128 || (wave & 1) == 0));
   f32x4_t bacc[MJ];
 #pragma unroll
   for (int i = 0; i < MJ; ++i) bacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -477,7 +479,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
         const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         af[i] = __builtin_bit_cast(bf16x8_t, v);
       }
-      if (bias_wave) {
+      if (BIAS && bias_wave) {
 #pragma unroll
         for (int i = 0; i < MJ; ++i) bacc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], ones, bacc[i], 0, 0, 0);
       }
@@ -524,7 +526,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
           const int col = (ct0 + tile_w + t) * 64 + col_w + j * 16 + fr;
           atomicAdd(a.dw + (size_t)kk * rsc + col, acc[i][t * NJ + j][e]);
         }
-  if (bias_wave && fr == 0) {  // every column of bacc holds the same sums: lane column 0 reports
+  if (BIAS && bias_wave && fr == 0) {  // every column of bacc holds the same sums: lane column 0 reports
 #pragma unroll
     for (int i = 0; i < MJ; ++i)
 #pragma unroll
@@ -554,12 +556,12 @@ int launch_igemm(const ConvArgs& a, hipStream_t st) {
   return WM_OK;
 }
 
-template <int BMO, int CPT, int NT>
-int launch_wgrad(WgradArgs a, hipStream_t st) {
+template <int BMO, int CPT, int NT, bool BIAS>
+int launch_wgrad_impl(WgradArgs a, hipStream_t st) {
   constexpr int lds = 2 * (WG_PIX * BMO * 2 + NT * WG_PIX * 128);
   static bool attr = false;
   if (!attr) {
-    const int rc = set_lds(&conv_wgrad<BMO, CPT, NT>, lds);
+    const int rc = set_lds(&conv_wgrad<BMO, CPT, NT, BIAS>, lds);
     if (rc != WM_OK) return rc;
     attr = true;
   }
@@ -579,9 +581,16 @@ int launch_wgrad(WgradArgs a, hipStream_t st) {
   a.chunks_per_split = wm_cdiv(a.total_chunks, nsplit);
   nsplit = wm_cdiv(a.total_chunks, a.chunks_per_split);
   dim3 grid(colgroups, ktiles, nsplit);
-  conv_wgrad<BMO, CPT, NT><<<grid, CV_THREADS, lds, st>>>(a);
+  conv_wgrad<BMO, CPT, NT, BIAS><<<grid, CV_THREADS, lds, st>>>(a);
   WM_LAUNCH_CHECK();
   return WM_OK;
+}
+
+template <int BMO, int CPT, int NT>
+int launch_wgrad(const WgradArgs& a, hipStream_t st) {
+  if (a.dbias == nullptr) return launch_wgrad_impl<BMO, CPT, NT, false>(a, st);
+  if constexpr (CPT == 8) return launch_wgrad_impl<BMO, CPT, NT, true>(a, st);
+  return WM_EUNSUPPORTED;  // no bias gradient on the space-to-depth stem form
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
