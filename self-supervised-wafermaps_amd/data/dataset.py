@@ -18,7 +18,7 @@ from .store import WaferStore
 
 class WaferMapDataset:
     def __init__(self, X, y=None, transform=None, device: Optional[str] = None):
-        self.store = WaferStore(list(X), device=device)
+        self.store = WaferStore(X if isinstance(X, WaferStore) else list(X), device=device)
         if y is not None:
             self.y = torch.as_tensor(np.asarray(list(y)))
         else:

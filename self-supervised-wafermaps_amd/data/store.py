@@ -15,6 +15,14 @@ import torch
 
 class WaferStore:
     def __init__(self, wafers: Sequence, device: Optional[torch.device] = None):
+        if isinstance(wafers, WaferStore):  # share the host arrays of an existing store
+            for k in ("heights_np", "widths_np", "offsets_np", "bytes_np", "max_elems", "n"):
+                setattr(self, k, getattr(wafers, k))
+            self.device = None
+            self.bytes = self.offsets = self.heights = self.widths = None
+            if device is not None:
+                self.to(device)
+            return
         arrays = [np.ascontiguousarray(np.asarray(w), dtype=np.uint8) for w in wafers]
         if not arrays:
             raise ValueError("WaferStore: empty collection")
@@ -51,3 +59,33 @@ class WaferStore:
 
     def nbytes(self) -> int:
         return int(self.bytes_np.nbytes)
+
+    # ---- on-disk form: the flat arrays themselves, so loading is four reads and no
+    # per-wafer Python work (the reference unpickles a pandas Series of 2-D arrays: *.pkl.xz)
+    def save(self, path, labels=None) -> None:
+        extra = {} if labels is None else {"labels": np.asarray(labels)}
+        np.savez(path, bytes=self.bytes_np, offsets=self.offsets_np, heights=self.heights_np, widths=self.widths_np,
+                 **extra)
+
+    @classmethod
+    def load(cls, path, device: Optional[torch.device] = None):
+        """-> (store, labels or None) from a file written by save()."""
+        with np.load(path) as z:
+            self = cls.__new__(cls)
+            self.bytes_np = np.ascontiguousarray(z["bytes"], dtype=np.uint8)
+            self.offsets_np = z["offsets"].astype(np.int64)
+            self.heights_np = z["heights"].astype(np.int32)
+            self.widths_np = z["widths"].astype(np.int32)
+            labels = z["labels"] if "labels" in z.files else None
+        sizes = self.heights_np.astype(np.int64) * self.widths_np.astype(np.int64)
+        want = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64) if len(sizes) else np.zeros(0, np.int64)
+        if (len(sizes) == 0 or not np.array_equal(want, self.offsets_np) or int(sizes.sum()) != self.bytes_np.size
+                or sizes.min() < 1 or max(self.heights_np.max(), self.widths_np.max()) > 256):
+            raise ValueError(f"{path}: not a consistent wafer store")
+        self.max_elems = int(sizes.max())
+        self.n = len(sizes)
+        self.device = None
+        self.bytes = self.offsets = self.heights = self.widths = None
+        if device is not None:
+            self.to(device)
+        return self, labels

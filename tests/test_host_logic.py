@@ -189,3 +189,53 @@ def test_collate_functions_have_the_reference_view_structure():
     assert isinstance(denoise[1], T.MedianFilter)  # denoise=True -> RandomOneOf{DieNoise | MedianFilter}
     x = T.rgb_scale(np.array([[0.0, 0.5], [1.0, 0.25]]))
     assert x.dtype == np.uint8 and x.tolist() == [[0, 128], [255, 64]]
+
+
+def test_ingest_of_reference_pickles_and_flat_store_roundtrip(tmp_path):
+    """pandas *.pkl.xz with waferMap / failureCode columns (the reference's processed files) -> flat
+    store -> .npz -> identical store; a dataset built on the loaded store sees the same wafers."""
+    import pandas as pd
+
+    from ssl_wafermap_amd.data import WaferMapDataset, WaferStore, convert_pickle, read_wafer_pickle
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+
+    wafers, labels = synthetic_wafers(37, seed=4)
+    df = pd.DataFrame({"waferMap": pd.Series(list(wafers)), "failureCode": np.asarray(labels).astype(np.int8),
+                       "label": [np.arange(8) % 2 for _ in wafers]})
+    src = tmp_path / "train_1_split.pkl.xz"
+    df.to_pickle(src)
+    store, y = read_wafer_pickle(src)
+    assert len(store) == 37 and np.array_equal(y, np.asarray(labels))
+    for i in (0, 5, 36):
+        assert np.array_equal(store.wafer(i), wafers[i])
+    _, multi = read_wafer_pickle(src, label_col="label")
+    assert multi.shape == (37, 8)
+    with pytest.raises(KeyError):
+        read_wafer_pickle(src, label_col="nope")
+    dst = tmp_path / "train_1_split.npz"
+    convert_pickle(src, dst)
+    loaded, y2 = WaferStore.load(dst)
+    assert np.array_equal(loaded.bytes_np, store.bytes_np) and np.array_equal(loaded.offsets_np, store.offsets_np)
+    assert np.array_equal(y2, y) and loaded.max_elems == store.max_elems
+    ds = WaferMapDataset(loaded, y2)
+    assert len(ds) == 37 and np.array_equal(ds.store.wafer(7), wafers[7])
+    bad = dict(np.load(dst))
+    bad["heights"] = bad["heights"].copy()
+    bad["heights"][3] += 1
+    np.savez(tmp_path / "bad.npz", **bad)
+    with pytest.raises(ValueError):
+        WaferStore.load(tmp_path / "bad.npz")
+
+
+_REF_SPLIT = "/root/reference/data/processed/WM811K/train_1_split.pkl.xz"
+
+
+@pytest.mark.skipif(not __import__("os").path.exists(_REF_SPLIT), reason="reference checkout not present")
+def test_ingest_reads_a_real_reference_split():
+    from ssl_wafermap_amd.data import read_wafer_pickle
+
+    store, y = read_wafer_pickle(_REF_SPLIT)
+    assert len(store) == len(y) > 100
+    vals = np.unique(store.bytes_np)
+    assert set(vals.tolist()) <= {0, 128, 255}
+    assert 1 <= store.heights_np.min() and store.heights_np.max() <= 256
