@@ -110,6 +110,14 @@ int wm_knn_topk(const void* query, const void* bank, int nq, int n, int d, int d
                 int bank_index_base, float* out_sim, int32_t* out_idx, void* workspace,
                 size_t workspace_bytes, void* stream);
 
+/* General-shape variant for the retrieval flow: float32, any d <= 1024 (d % 4 == 0), k <= 16, score =
+ * q.x + bias[row] (bias may be NULL).  With bias = -||x||^2 / 2 the ranking is the Euclidean one
+ * (sklearn NearestNeighbors on the dumped embeddings, notebooks/2.0-Figures-nearest-neighbors cell 2). */
+size_t wm_knn_topk_general_workspace_bytes(int nq, int n, int d, int k);
+int wm_knn_topk_general(const float* query, const float* bank, const float* bias, int nq, int n, int d, int k,
+                        int bank_index_base, float* out_sim, int32_t* out_idx, void* workspace,
+                        size_t workspace_bytes, void* stream);
+
 /* Merge `parts` candidate lists per query ([parts][nq][k], e.g. all-gathered shard results)
  * into the global top-k.  in_* and out_* may not alias. */
 int wm_knn_merge(const float* in_sim, const int32_t* in_idx, int parts, int nq, int k,
@@ -333,6 +341,15 @@ int wm_dino_loss_fwd_bwd(const void* student, const float* probs, int Vs, int Vt
                          float* loss, void* dstudent, void* stream);
 /* center = momentum * center + (1 - momentum) * mean over rows of teacher[rows][D]. */
 int wm_dino_center_update(const void* teacher, long long rows, int D, float momentum, float* center, void* stream);
+
+/* Column statistics and standardisation of a feature matrix x [rows][C] (float32 or bf16: WM_F32 /
+ * WM_BF16), the sklearn StandardScaler the reference applies to dumped embeddings
+ * (notebooks/3.0-Embeddings-inference.ipynb cell 7): mean[c], var[c] = biased variance (two passes:
+ * sums, then squared deviations from the mean).  mean and var must be zeroed by the caller.
+ * wm_standardize: out[r][c] = (x[r][c] - mean[c]) * inv_scale[c], float32. */
+int wm_colstats(const void* x, int dtype, long long rows, int C, float* mean, float* var, void* stream);
+int wm_standardize(const void* x, int dtype, long long rows, int C, const float* mean, const float* inv_scale,
+                   float* out, void* stream);
 
 /* torch.optim.AdamW step over flat f32 arenas; hyper = DEVICE {lr, beta1, beta2, eps, weight_decay,
  * bias_correction1, bias_correction2, grad_scale}. */

@@ -149,6 +149,11 @@ SIGNATURES = {
     "wm_dino_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                      c_void_p]),
     "wm_dino_center_update": (c_int, [c_void_p, c_longlong, c_int, c_float, c_void_p, c_void_p]),
+    "wm_knn_topk_general_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "wm_knn_topk_general": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
+                                    c_void_p, c_size_t, c_void_p]),
+    "wm_colstats": (c_int, [c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
+    "wm_standardize": (c_int, [c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wm_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),
     "wm_ema_update": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p]),
 }

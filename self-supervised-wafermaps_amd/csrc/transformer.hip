@@ -568,6 +568,68 @@ __global__ __launch_bounds__(TF_THREADS) void ema_kernel(float* __restrict__ ema
     ema[i] = ema[i] * m + p[i] * (1.f - m);
 }
 
+// ------------------------------------------------------------------------------------ column stats
+template <typename T>
+__device__ __forceinline__ float ld1(const T* p, size_t i);
+template <>
+__device__ __forceinline__ float ld1<float>(const float* p, size_t i) { return p[i]; }
+template <>
+__device__ __forceinline__ float ld1<uint16_t>(const uint16_t* p, size_t i) { return bf2f(p[i]); }
+
+// PASS 0: acc[c] += sum_r x[r][c] / rows.  PASS 1: acc[c] += sum_r (x[r][c] - mean[c])^2 / rows.
+// Block = 32 columns x 8 row lanes over a slab of rows; one atomic per column and block.
+template <typename T, int PASS>
+__global__ __launch_bounds__(TF_THREADS) void colstats_kernel(const T* __restrict__ x, long long rows, int C,
+                                                              int rows_per_block, const float* __restrict__ mean,
+                                                              float* __restrict__ acc) {
+  __shared__ float red[8][33];
+  const int cl = threadIdx.x & 31, rl = threadIdx.x >> 5;
+  const int c = blockIdx.y * 32 + cl;
+  const long long r0 = (long long)blockIdx.x * rows_per_block;
+  long long r1 = r0 + rows_per_block;
+  if (r1 > rows) r1 = rows;
+  float s = 0.f;
+  if (c < C) {
+    const float mu = PASS == 1 ? mean[c] : 0.f;
+    for (long long r = r0 + rl; r < r1; r += 8) {
+      const float v = ld1<T>(x, (size_t)r * C + c) - mu;
+      s += PASS == 1 ? v * v : v;
+    }
+  }
+  red[rl][cl] = s;
+  __syncthreads();
+  if (rl == 0 && c < C) {
+    float tot = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) tot += red[j][cl];
+    atomicAdd(acc + c, tot / (float)rows);
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(TF_THREADS) void standardize_kernel(const T* __restrict__ x, long long rows, int C,
+                                                                 const float* __restrict__ mean,
+                                                                 const float* __restrict__ inv_scale,
+                                                                 float* __restrict__ out) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * TF_THREADS + threadIdx.x; i < total; i += (long long)gridDim.x * TF_THREADS) {
+    const int c = (int)(i % C);
+    out[i] = (ld1<T>(x, (size_t)i) - mean[c]) * inv_scale[c];
+  }
+}
+
+template <typename T>
+int launch_colstats(const void* x, long long rows, int C, float* mean, float* var, hipStream_t st) {
+  long long rpb = (rows + 255) / 256;
+  if (rpb < 64) rpb = 64;
+  dim3 grid(wm_cdiv(rows, rpb), wm_cdiv(C, 32));
+  colstats_kernel<T, 0><<<grid, TF_THREADS, 0, st>>>(static_cast<const T*>(x), rows, C, (int)rpb, nullptr, mean);
+  WM_LAUNCH_CHECK();
+  colstats_kernel<T, 1><<<grid, TF_THREADS, 0, st>>>(static_cast<const T*>(x), rows, C, (int)rpb, mean, var);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
 inline int ew_blocks(long long work) {
   long long b = (work + TF_THREADS - 1) / TF_THREADS;
   if (b > 8192) b = 8192;
@@ -765,6 +827,31 @@ extern "C" int wm_ema_update(float* ema, const float* params, long long n, float
   WM_REQUIRE(ema && params, WM_EINVAL);
   WM_REQUIRE(n > 0, WM_EINVAL);
   ema_kernel<<<ew_blocks(n), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(ema, params, n, m);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_colstats(const void* x, int dtype, long long rows, int C, float* mean, float* var, void* stream) {
+  WM_REQUIRE(x && mean && var, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && C > 0, WM_EINVAL);
+  WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return dtype == WM_F32 ? launch_colstats<float>(x, rows, C, mean, var, st)
+                         : launch_colstats<uint16_t>(x, rows, C, mean, var, st);
+}
+
+extern "C" int wm_standardize(const void* x, int dtype, long long rows, int C, const float* mean,
+                              const float* inv_scale, float* out, void* stream) {
+  WM_REQUIRE(x && mean && inv_scale && out, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && C > 0, WM_EINVAL);
+  WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int blocks = ew_blocks(rows * C);
+  if (dtype == WM_F32)
+    standardize_kernel<float><<<blocks, TF_THREADS, 0, st>>>(static_cast<const float*>(x), rows, C, mean, inv_scale, out);
+  else
+    standardize_kernel<uint16_t><<<blocks, TF_THREADS, 0, st>>>(static_cast<const uint16_t*>(x), rows, C, mean,
+                                                                inv_scale, out);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

@@ -225,3 +225,53 @@ def test_knn_edge_sizes(nq, n, d, k, dtype):
     assert torch.equal(torch.sort(idx.cpu().long(), 1).values, torch.sort(idx_ref, 1).values) or k < n
     with pytest.raises(Exception):
         F.knn_topk(q.to(_dev()), bank.to(_dev()), n + 1)  # k > n is rejected, not silently clipped
+
+
+def test_standard_scaler_and_retrieval_match_sklearn():
+    """StandardScaler + nearest neighbours (cosine, L2) against sklearn on the same data."""
+    from sklearn.neighbors import NearestNeighbors
+    from sklearn.preprocessing import StandardScaler as SkScaler
+
+    from ssl_wafermap_amd.retrieval import StandardScaler, nearest_neighbors
+
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(3000, 512, generator=g) * (torch.rand(512, generator=g) * 3 + 0.1) + torch.randn(512, generator=g)
+    x[:, 7] = 2.5  # constant feature: sklearn leaves it unscaled
+    x = x.half().float()  # the reference stores float16 embeddings
+    ref = SkScaler().fit(x.numpy().astype("float64"))
+    sc = StandardScaler().fit(x.to("cuda:0"))
+    assert np.allclose(sc.mean_.cpu().numpy(), ref.mean_, rtol=1e-5, atol=1e-5)
+    assert np.allclose(sc.var_.cpu().numpy(), ref.var_, rtol=1e-4, atol=1e-6)
+    z = sc.transform(x.to("cuda:0"))
+    zr = ref.transform(x.numpy().astype("float64"))
+    assert np.allclose(z.cpu().numpy(), zr, rtol=1e-4, atol=1e-4)  # incl. the constant column: 0 (f32 mean error 1e-6)
+    xb = x.bfloat16()  # bf16 features straight from the backbone: same arithmetic on the rounded values
+    zb = sc.transform(xb.to("cuda:0"))
+    assert np.allclose(zb.cpu().numpy(), ref.transform(xb.float().numpy().astype("float64")), rtol=1e-4, atol=1e-4)
+    q = z[:40] + 0.05 * torch.randn(40, 512, generator=g).to(z.device)
+    for metric, sk_metric in (("cosine", "cosine"), ("l2", "euclidean")):
+        dist, idx = nearest_neighbors(q, z, 10, metric=metric)
+        nn_ = NearestNeighbors(n_neighbors=10, metric=sk_metric, algorithm="brute").fit(z.cpu().numpy().astype("float64"))
+        dref, iref = nn_.kneighbors(q.cpu().numpy().astype("float64"))
+        assert (idx[:, 0].cpu().numpy() == iref[:, 0]).all()
+        agree = np.mean([len(set(a.tolist()) & set(b.tolist())) / 10 for a, b in zip(idx.cpu().numpy(), iref)])
+        assert agree > 0.99, (metric, agree)
+        assert np.allclose(dist.cpu().numpy()[:, :3], dref[:, :3], rtol=2e-3, atol=2e-3)
+
+
+def test_embed_dataset_runs_the_eval_backbone():
+    from ssl_wafermap_amd.data import WaferLoader, WaferMapDataset
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.models import SimCLR
+    from ssl_wafermap_amd.retrieval import embed_dataset
+    from ssl_wafermap_amd.transforms import InferenceTransform
+
+    wafers, labels = synthetic_wafers(50, seed=2)
+    ds = WaferMapDataset(wafers, labels, transform=InferenceTransform(), device="cuda:0")
+    torch.manual_seed(0)
+    model = SimCLR(None, 9).to("cuda:0").train()
+    feats = embed_dataset(model, WaferLoader(ds, 16), out_dtype=torch.float16)
+    assert feats.shape == (50, 512) and feats.dtype == torch.float16 and torch.isfinite(feats.float()).all()
+    assert model.training  # mode restored
+    again = embed_dataset(model, WaferLoader(ds, 25), out_dtype=None)
+    assert torch.allclose(again.float(), feats.float(), atol=2e-2, rtol=2e-2)  # batch size does not matter in eval
