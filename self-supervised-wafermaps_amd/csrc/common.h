@@ -79,4 +79,12 @@ __device__ __forceinline__ void glds16_nt(const void* gsrc, uint32_t lds_base) {
       : "memory");
 }
 
+// Same with an LDS byte address the caller already has as an integer, M0 declared clobbered instead
+// of saved and restored (the k-loops issue 6-10 of these per step: the save/restore pair and the
+// generic->LDS pointer cast's null check were a third of the scalar instructions of the issue phase).
+__device__ __forceinline__ void glds16_at(const void* gsrc, uint32_t lds_byte_addr) {
+  const uint32_t base = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(base) : "memory", "m0");
+}
+
 static inline int wm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

@@ -147,14 +147,24 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
 #pragma unroll
   for (int i = 0; i < NB; ++i) pb[i] = a.wt + (size_t)(n0 + rowl + 32 * i) * wrow + chunk * 8;
 
-  auto issue = [&](int kt, uint8_t* stage) {
+  // running decode of the k-tile index (issue() is called for kt = 0, 1, 2, ... in order): channel
+  // offset and tap coordinates advance by carries instead of two integer divisions per k-step
+  int it_c0 = 0, it_r = 0, it_s = 0;
+  const uint32_t smem_base = lds_addr(cv_smem);
+  auto issue = [&](int kt, uint32_t stage) {
     int r, s;
     long long koff;  // uniform element offset of this k-tile relative to p0
+    const int c0 = it_c0;
     if constexpr (MODE == 2) {
-      const int cpk = a.SC >> 6;
-      const int tapj = kt / cpk;
-      const int c0 = (kt - tapj * cpk) * 64;
-      const int jr = tapj / ns, js = tapj - jr * ns;
+      const int jr = it_r, js = it_s;
+      it_c0 += 64;
+      if (it_c0 == a.SC) {
+        it_c0 = 0;
+        if (++it_s == ns) {
+          it_s = 0;
+          ++it_r;
+        }
+      }
       r = jr;  // steps of -1 source pixel per valid tap
       s = js;
       koff = (long long)(-jr * a.SW - js) * a.SC + c0;
@@ -163,20 +173,25 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
         const int sh = bh[i] - jr, sw = bw[i] - js;
         const bool ok = (unsigned)sh < (unsigned)a.SH && (unsigned)sw < (unsigned)a.SW;
         const uint16_t* src = ok ? p0[i] + koff : conv_zero_page + chunk * 8;
-        glds16(src, lds_addr(stage + (wave * 8 + 32 * i) * CV_ROW));
+        glds16_at(src, stage + (wave * 8 + 32 * i) * CV_ROW);
       }
       // weights: tap (r0 + 2 jr, s0 + 2 js)
       const size_t wk = ((size_t)((r0 + 2 * jr) * a.S + (s0 + 2 * js)) * a.SC) + c0;
 #pragma unroll
       for (int i = 0; i < NB; ++i)
-        glds16(pb[i] + wk, lds_addr(stage + A_BYTES + (wave * 8 + 32 * i) * CV_ROW));
+        glds16_at(pb[i] + wk, stage + A_BYTES + (wave * 8 + 32 * i) * CV_ROW);
       return;
     } else if constexpr (CPT == 8) {
-      const int cpk = a.SC >> 6;
-      const int tap = kt / cpk;
-      const int c0 = (kt - tap * cpk) * 64;
-      r = tap / a.S;
-      s = tap - r * a.S;
+      r = it_r;
+      s = it_s;
+      it_c0 += 64;
+      if (it_c0 == a.SC) {
+        it_c0 = 0;
+        if (++it_s == a.S) {
+          it_s = 0;
+          ++it_r;
+        }
+      }
       koff = DGRAD ? ((long long)(-r * a.SW - s) * a.SC + c0) : ((long long)(r * a.SW + s) * a.SC + c0);
     } else {  // 16-channel source: one k-tile = kernel row kt; the lane's chunk picks the tap
       r = kt;
@@ -198,7 +213,6 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
           ok = ok && (((th | tw) & 1) == 0);
           const int sh = th >> 1, sw = tw >> 1;
           ok = ok && sh < a.SH && sw < a.SW;
-          const int c0 = (kt % (a.SC >> 6)) * 64;
           src = a.src + ((long long)(nb[i] + sh * a.SW + sw) * a.SC + c0 + chunk * 8);
         } else {
           ok = ok && th < a.SH && tw < a.SW;
@@ -206,11 +220,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
         }
       }
       if (!ok) src = conv_zero_page + chunk * 8;
-      glds16(src, lds_addr(stage + (wave * 8 + 32 * i) * CV_ROW));
+      glds16_at(src, stage + (wave * 8 + 32 * i) * CV_ROW);
     }
 #pragma unroll
     for (int i = 0; i < NB; ++i)
-      glds16(pb[i] + (size_t)kt * 64, lds_addr(stage + A_BYTES + (wave * 8 + 32 * i) * CV_ROW));
+      glds16_at(pb[i] + (size_t)kt * 64, stage + A_BYTES + (wave * 8 + 32 * i) * CV_ROW);
   };
 
   f32x4_t acc[NJ][4];
@@ -243,11 +257,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
     }
   };
 
-  if (nkt > 0) issue(0, cv_smem);
+  if (nkt > 0) issue(0, smem_base);
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt have landed
     __builtin_amdgcn_s_barrier();                     // ... everyone's; and compute(kt-1) is over
-    if (kt + 1 < nkt && !(WM_CONV_ABLATE & 1)) issue(kt + 1, cv_smem + ((kt + 1) & 1) * STAGE);
+    if (kt + 1 < nkt && !(WM_CONV_ABLATE & 1)) issue(kt + 1, smem_base + ((kt + 1) & 1) * STAGE);
     if (!(WM_CONV_ABLATE & 2)) compute(cv_smem + (kt & 1) * STAGE);
   }
   __syncthreads();
@@ -392,7 +406,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
     pq[i] = rem - pp[i] * a.Q;
   }
 
-  auto issue = [&](int it, uint8_t* stage) {
+  const uint32_t smem_base = lds_addr(wg_smem);
+  auto issue = [&](int it, uint32_t stage) {
     const int pix0 = (chunk_begin + it) * WG_PIX;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
@@ -401,7 +416,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
       const int lc = (wg_swz<RA>(row, a_pc >> 1) << 1) | (a_pc & 1);
       const uint16_t* src = a.dy + (size_t)(pix0 + row) * a.K + k0 + lc * 8;
       if (pix0 + row >= a.M) src = conv_zero_page + lc * 8;
-      glds16(src, lds_addr(stage + row0 * RA));
+      glds16_at(src, stage + row0 * RA);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -427,7 +442,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
         const bool ok = inb && (unsigned)sh < (unsigned)a.H && (unsigned)sw < (unsigned)a.W;
         const uint16_t* src = a.x + (((nbase + sh) * a.W + sw) * a.C + coff);
         if (!ok) src = conv_zero_page + xlc[i] * 8;
-        glds16(src, lds_addr(stage + A_BYTES + t * X_BYTES + ((i * 4 + wave) * 8) * RB));
+        glds16_at(src, stage + A_BYTES + t * X_BYTES + ((i * 4 + wave) * 8) * RB);
       }
       // advance this row by one chunk (64 pixels)
       if (pqn == 1) {
@@ -504,11 +519,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
     }
   };
 
-  issue(0, wg_smem);
+  issue(0, smem_base);
   for (int it = 0; it < iters; ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
-    if (it + 1 < iters && !(WM_CONV_ABLATE & 1)) issue(it + 1, wg_smem + ((it + 1) & 1) * STAGE);
+    if (it + 1 < iters && !(WM_CONV_ABLATE & 1)) issue(it + 1, smem_base + ((it + 1) & 1) * STAGE);
     if (!(WM_CONV_ABLATE & 2)) compute(wg_smem + (it & 1) * STAGE);
   }
 
