@@ -392,9 +392,12 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   const int iters = chunk_end - chunk_begin;
   if (iters <= 0) return;
 
-  // running (n, p, q) of this lane's two X rows (shared by the NT tiles)
+  // running (n, p, q) of this lane's two X rows (shared by the NT tiles).  Every chunk advances a row
+  // by 64 pixels: (dq, dpp, dn) is that step in mixed radix (Q, P), applied with two carries.
   int pn[2], pp[2], pq[2], xrow[2], xlc[2];
   const int pqn = a.P * a.Q;
+  const int step_q = WG_PIX % a.Q, step_rows = WG_PIX / a.Q;
+  const int step_p = step_rows % a.P, step_n = step_rows / a.P;
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     xrow[i] = (i * 4 + wave) * 8 + x_ro;
@@ -405,24 +408,32 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
     pp[i] = rem / a.Q;
     pq[i] = rem - pp[i] * a.Q;
   }
+  // lane-constant part of the dY addresses (element offsets fit 32 bits: host-checked)
+  uint32_t dy_off[NA];
+  int dy_row[NA];
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = (i * 4 + wave) * RPI_A + a_ro;
+    const int lc = (wg_swz<RA>(row, a_pc >> 1) << 1) | (a_pc & 1);
+    dy_row[i] = row;
+    dy_off[i] = (uint32_t)row * (uint32_t)a.K + (uint32_t)(k0 + lc * 8);
+  }
 
   const uint32_t smem_base = lds_addr(wg_smem);
   auto issue = [&](int it, uint32_t stage) {
     const int pix0 = (chunk_begin + it) * WG_PIX;
+    const uint32_t dy_base = (uint32_t)pix0 * (uint32_t)a.K;
 #pragma unroll
     for (int i = 0; i < NA; ++i) {
-      const int row0 = (i * 4 + wave) * RPI_A;
-      const int row = row0 + a_ro;
-      const int lc = (wg_swz<RA>(row, a_pc >> 1) << 1) | (a_pc & 1);
-      const uint16_t* src = a.dy + (size_t)(pix0 + row) * a.K + k0 + lc * 8;
-      if (pix0 + row >= a.M) src = conv_zero_page + lc * 8;
-      glds16_at(src, stage + row0 * RA);
+      const uint16_t* src = a.dy + (dy_base + dy_off[i]);
+      if (pix0 + dy_row[i] >= a.M) src = conv_zero_page + (dy_off[i] & 63);  // any 16-byte aligned zeros
+      glds16_at(src, stage + ((i * 4 + wave) * RPI_A) * RA);
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const bool inb = pix0 + xrow[i] < a.M;
       const int hb = pp[i] * a.stride - a.pad, wb = pq[i] * a.stride - a.pad;
-      const size_t nbase = (size_t)pn[i] * a.H;
+      const int lin = (pn[i] * a.H + hb) * a.W + wb;  // linear input pixel of tap (0, 0); may be "negative"
 #pragma unroll
       for (int t = 0; t < NT; ++t) {
         const int ct = ct0 + t;
@@ -439,24 +450,20 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
           coff = (xlc[i] & 1) * 8;
         }
         const int sh = hb + r, sw = wb + s;
-        const bool ok = inb && (unsigned)sh < (unsigned)a.H && (unsigned)sw < (unsigned)a.W;
-        const uint16_t* src = a.x + (((nbase + sh) * a.W + sw) * a.C + coff);
+        const bool ok = inb & ((unsigned)sh < (unsigned)a.H) & ((unsigned)sw < (unsigned)a.W);
+        const uint32_t off = (uint32_t)(lin + r * a.W + s) * (uint32_t)a.C + (uint32_t)coff;
+        const uint16_t* src = a.x + off;
         if (!ok) src = conv_zero_page + xlc[i] * 8;
         glds16_at(src, stage + A_BYTES + t * X_BYTES + ((i * 4 + wave) * 8) * RB);
       }
       // advance this row by one chunk (64 pixels)
-      if (pqn == 1) {
-        pn[i] += WG_PIX;  // Linear layers (1x1 image): a row is an image
-      } else {
-        pq[i] += WG_PIX;
-        while (pq[i] >= a.Q) {
-          pq[i] -= a.Q;
-          if (++pp[i] == a.P) {
-            pp[i] = 0;
-            ++pn[i];
-          }
-        }
-      }
+      pq[i] += step_q;
+      int carry = pq[i] >= a.Q;
+      pq[i] -= carry ? a.Q : 0;
+      pp[i] += step_p + carry;
+      carry = pp[i] >= a.P;
+      pp[i] -= carry ? a.P : 0;
+      pn[i] += step_n + carry;
     }
   };
 
@@ -724,6 +731,9 @@ extern "C" int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_krs
   const int rc = conv_check(N, H, W, C, K, R, S, P, Q, stride, pad);
   if (rc != WM_OK) return rc;
   WM_REQUIRE(aligned16(dy) && aligned16(x) && aligned16(dw_krsc), WM_EALIGN);
+  // the kernel forms element offsets in 32 bits
+  WM_REQUIRE((long long)N * H * W * C < (1ll << 32) - (1 << 20) && (long long)N * P * Q * K < (1ll << 32) - (1 << 20),
+             WM_EUNSUPPORTED);
   WgradArgs a;
   a.dy = static_cast<const uint16_t*>(dy);
   a.x = static_cast<const uint16_t*>(x);
