@@ -196,6 +196,11 @@ int wm_conv2d_dgrad_add(const void* dy, const void* w_crsk, const void* residual
  * f32 atomics, so the caller zeroes dw_krsc first and the low bits depend on arrival order. */
 int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_krsc, int N, int H, int W, int C, int K,
                     int R, int S, int P, int Q, int stride, int pad, void* stream);
+/* Forward with y = conv(x) + bias[k] (+ residual, same shape as y), both optional, added in the
+ * epilogue: a Linear layer's bias and the residual add of a transformer block cost no extra pass. */
+int wm_conv2d_fwd_bias_res(const void* x, const void* w_krsc, const float* bias, const void* residual, void* y,
+                           int N, int H, int W, int C, int K, int R, int S, int P, int Q, int stride, int pad,
+                           void* stream);
 /* Same, and dbias[K] += sum over pixels of dy (dbias may be NULL): a Linear layer's bias gradient comes
  * out of the weight-gradient launch (one extra MFMA per dY fragment in the first column group's
  * blocks) instead of a separate reduction pass over dy. */

@@ -5,7 +5,7 @@
 // softmax -> @ v, as run by scripts/WM811k_benchmark.py:566-576) and torch.nn.MultiheadAttention
 // inside torchvision's vit_b_32 encoder blocks (MAE, :903-947), and their autograd backward.
 //
-// One block (4 waves) per (image, head).  Q, K, V (and dO in the backward) of the head sit in LDS as
+// One block (8 waves) per (image, head).  Q, K, V (and dO in the backward) of the head sit in LDS as
 // [token][64] bf16 rows padded to 144 B: a ds_read_b128 fragment read (16 rows x one 16-byte column)
 // then touches 16 distinct 4-bank groups.  A wave owns 16-row strips.
 //
@@ -29,7 +29,10 @@
 
 namespace {
 
-constexpr int AT_THREADS = 256;
+// forward: 8 waves (two per SIMD: one wave's softmax / LDS latency hides under the other's MFMAs);
+// backward: 4 waves (it needs > 128 registers per lane; measured 1.4x slower with 8)
+constexpr int AT_FWD_THREADS = 512;
+constexpr int AT_BWD_THREADS = 256;
 // LDS bytes per token row: HD bf16 + 16 B pad (144 for head dim 64, 80 for 32: in both, 16
 // consecutive rows start on 16 distinct 4-bank groups)
 #define AT_ROWB (HD * 2 + 16)
@@ -62,7 +65,7 @@ __device__ __forceinline__ bf16x8_t pack_slots(const f32x4_t a, const f32x4_t b)
 template <int HD>
 __device__ __forceinline__ void stage_rows(const uint16_t* src, size_t row_stride, int S, int SP, uint8_t* dst) {
   constexpr int CPR = HD / 8;  // 16-byte chunks per row
-  for (int i = threadIdx.x; i < SP * CPR; i += AT_THREADS) {
+  for (int i = threadIdx.x; i < SP * CPR; i += blockDim.x) {
     const int r = i / CPR, c = i % CPR;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (r < S) v = *reinterpret_cast<const uint4*>(src + (size_t)r * row_stride + c * 8);
@@ -71,7 +74,7 @@ __device__ __forceinline__ void stage_rows(const uint16_t* src, size_t row_strid
 }
 
 template <int NT, int HD>
-__global__ __launch_bounds__(AT_THREADS) void attn_fwd(const uint16_t* __restrict__ qkv, int S, int H, float scale,
+__global__ __launch_bounds__(AT_FWD_THREADS) void attn_fwd(const uint16_t* __restrict__ qkv, int S, int H, float scale,
                                                        uint16_t* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) uint8_t at_smem[];
   constexpr int SP = NT * 16;
@@ -89,7 +92,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd(const uint16_t* __restric
   stage_rows<HD>(base + (size_t)2 * H * HD, rs, S, SP, sv);
   __syncthreads();
 
-  for (int qs = wave; qs < NT; qs += 4) {
+  for (int qs = wave; qs < NT; qs += AT_FWD_THREADS / 64) {
     const int q = qs * 16 + fr;
     bf16x8_t qf[KS];
 #pragma unroll
@@ -145,7 +148,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_fwd(const uint16_t* __restric
 }
 
 template <int NT, int HD>
-__global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+__global__ __launch_bounds__(AT_BWD_THREADS) void attn_bwd(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
                                                        const uint16_t* __restrict__ dout, const float* __restrict__ lse,
                                                        int S, int H, float scale, uint16_t* __restrict__ dqkv) {
   extern __shared__ __attribute__((aligned(16))) uint8_t at_smem[];
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restric
   stage_rows<HD>(base + (size_t)H * HD, rs, S, SP, sk);
   stage_rows<HD>(base + (size_t)2 * H * HD, rs, S, SP, sv);
   // dO -> LDS and delta[q] = sum_d dO[q][d] O[q][d] (CPR adjacent lanes per row)
-  for (int i = threadIdx.x; i < SP * CPR; i += AT_THREADS) {
+  for (int i = threadIdx.x; i < SP * CPR; i += AT_BWD_THREADS) {
     const int r = i / CPR, c = i % CPR;
     uint4 dv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
     if (r < S) {
@@ -195,7 +198,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restric
 
   uint16_t* dq_base = dqkv + (size_t)b * S * rs + h * HD;
   // ---- pass A: dQ, by query strips
-  for (int qs = wave; qs < NT; qs += 4) {
+  for (int qs = wave; qs < NT; qs += AT_BWD_THREADS / 64) {
     const int q = qs * 16 + fr;
     bf16x8_t qf[KS], df[KS];
 #pragma unroll
@@ -243,7 +246,7 @@ __global__ __launch_bounds__(AT_THREADS) void attn_bwd(const uint16_t* __restric
     }
   }
   // ---- pass B: dK, dV, by key strips (transposed tiles: lane = key fr, registers = queries)
-  for (int ksn = wave; ksn < NT; ksn += 4) {
+  for (int ksn = wave; ksn < NT; ksn += AT_BWD_THREADS / 64) {
     const int key = ksn * 16 + fr;
     const bool keyok = key < S;
     bf16x8_t kf[KS], vf[KS];
@@ -316,7 +319,7 @@ int launch_fwd(const void* qkv, int B, int S, int H, float scale, void* out, flo
     if (rc != WM_OK) return rc;
     attr = true;
   }
-  attn_fwd<NT, HD><<<B * H, AT_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), S, H, scale,
+  attn_fwd<NT, HD><<<B * H, AT_FWD_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), S, H, scale,
                                                static_cast<uint16_t*>(out), lse);
   WM_LAUNCH_CHECK();
   return WM_OK;
@@ -332,7 +335,7 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
     if (rc != WM_OK) return rc;
     attr = true;
   }
-  attn_bwd<NT, HD><<<B * H, AT_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), static_cast<const uint16_t*>(out),
+  attn_bwd<NT, HD><<<B * H, AT_BWD_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), static_cast<const uint16_t*>(out),
                                                static_cast<const uint16_t*>(dout), lse, S, H, scale,
                                                static_cast<uint16_t*>(dqkv));
   WM_LAUNCH_CHECK();

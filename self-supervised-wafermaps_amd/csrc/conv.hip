@@ -57,6 +57,8 @@ struct ConvArgs {
   // optional tensor added to the result in the epilogue (dgrad: the gradient that reached the same
   // input through a second path, e.g. the identity shortcut of a residual block), same shape as dst
   const uint16_t* res;
+  // optional per-output-channel bias added in the epilogue (forward only: Linear layers)
+  const float* bias;
 };
 
 // 128 zero bytes: the global_load_lds source of padded / out-of-range taps
@@ -72,7 +74,9 @@ __device__ __attribute__((aligned(256))) uint16_t conv_zero_page[128];
 // parity class (h&1, w&1): all 128 rows of a tile then share the set of taps that hit a source
 // pixel (r = r0 + 2 jr, s = s0 + 2 js), so only those k-tiles are executed — 9/4 instead of 9 per
 // pixel for 3x3, and three of four classes of the 1x1 downsample just store zeros.
-template <int BM, int BN, int CPT, int MODE>
+// EPI: epilogue with bias / prefetched residual (Linear layers).  It is a separate instantiation
+// because carrying its registers in the convolution kernels cost them ~8 %.
+template <int BM, int BN, int CPT, int MODE, bool EPI = false>
 __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   constexpr bool DGRAD = MODE != 0;
   extern __shared__ __attribute__((aligned(16))) uint8_t cv_smem[];
@@ -298,33 +302,92 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
       atomicAdd(base + a.DC, sq);
     }
   }
-  constexpr int CPR = BN / 8;
-  for (int p = tid; p < BM * CPR; p += CV_THREADS) {
-    const int row = p / CPR, ch = p - row * CPR;
-    size_t pix = (size_t)(m0 + row);
-    if constexpr (MODE == 2) {  // class-ordered row -> pixel (n, 2 h2 + ph, 2 w2 + pw)
-      const int cls = a.M >> 2;
-      const int pc = m0 / cls;
-      const int m = m0 + row - pc * cls;
-      const int h2w2 = (a.DH >> 1) * (a.DW >> 1);
-      const int n = m / h2w2, rem = m - n * h2w2;
-      const int h2 = rem / (a.DW >> 1), w2 = rem - h2 * (a.DW >> 1);
-      pix = ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
-    }
-    if (m0 + row < a.M) {
-      uint4 v = *reinterpret_cast<const uint4*>(cv_smem + row * CS + ch * 16);
-      if (a.res != nullptr) {
-        const uint4 r4 = *reinterpret_cast<const uint4*>(a.res + pix * a.DC + n0 + ch * 8);
-        const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
-        uint32_t o[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e)
-          o[e] = pack_bf2(bf2f((uint16_t)(vv[e] & 0xffff)) + bf2f((uint16_t)(rr[e] & 0xffff)),
-                          bf2f((uint16_t)(vv[e] >> 16)) + bf2f((uint16_t)(rr[e] >> 16)));
-        v = make_uint4(o[0], o[1], o[2], o[3]);
+  if constexpr (EPI) {
+    constexpr int CPR = BN / 8;
+    constexpr int NIT = BM * CPR / CV_THREADS;  // 16-byte chunks per thread
+    size_t pixs[NIT];
+    uint4 rv[NIT];
+  #pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int p = tid + it * CV_THREADS;
+      const int row = p / CPR, ch = p - row * CPR;
+      size_t pix = (size_t)(m0 + row);
+      if constexpr (MODE == 2) {  // class-ordered row -> pixel (n, 2 h2 + ph, 2 w2 + pw)
+        const int cls = a.M >> 2;
+        const int pc = m0 / cls;
+        const int m = m0 + row - pc * cls;
+        const int h2w2 = (a.DH >> 1) * (a.DW >> 1);
+        const int n = m / h2w2, rem = m - n * h2w2;
+        const int h2 = rem / (a.DW >> 1), w2 = rem - h2 * (a.DW >> 1);
+        pix = ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
       }
-      *reinterpret_cast<uint4*>(a.dst + pix * a.DC + n0 + ch * 8) = v;
+      pixs[it] = pix;
+      // all residual chunks of the thread are requested before the first store (they may alias dst as
+      // far as the compiler knows, so it would not hoist them itself)
+      rv[it] = make_uint4(0, 0, 0, 0);
+      if (a.res != nullptr && m0 + row < a.M) rv[it] = *reinterpret_cast<const uint4*>(a.res + pix * a.DC + n0 + ch * 8);
     }
+  #pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+      const int p = tid + it * CV_THREADS;
+      const int row = p / CPR, ch = p - row * CPR;
+      const size_t pix = pixs[it];
+      if (m0 + row < a.M) {
+        uint4 v = *reinterpret_cast<const uint4*>(cv_smem + row * CS + ch * 16);
+        if constexpr (MODE == 0) {
+          if (a.bias != nullptr) {
+            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + n0 + ch * 8);
+            const float4 b1 = *reinterpret_cast<const float4*>(a.bias + n0 + ch * 8 + 4);
+            v = make_uint4(pack_bf2(bf2f((uint16_t)(v.x & 0xffff)) + b0.x, bf2f((uint16_t)(v.x >> 16)) + b0.y),
+                           pack_bf2(bf2f((uint16_t)(v.y & 0xffff)) + b0.z, bf2f((uint16_t)(v.y >> 16)) + b0.w),
+                           pack_bf2(bf2f((uint16_t)(v.z & 0xffff)) + b1.x, bf2f((uint16_t)(v.z >> 16)) + b1.y),
+                           pack_bf2(bf2f((uint16_t)(v.w & 0xffff)) + b1.z, bf2f((uint16_t)(v.w >> 16)) + b1.w));
+          }
+        }
+        if (a.res != nullptr) {
+          const uint4 r4 = rv[it];
+          const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+          uint32_t o[4];
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] = pack_bf2(bf2f((uint16_t)(vv[e] & 0xffff)) + bf2f((uint16_t)(rr[e] & 0xffff)),
+                            bf2f((uint16_t)(vv[e] >> 16)) + bf2f((uint16_t)(rr[e] >> 16)));
+          v = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        *reinterpret_cast<uint4*>(a.dst + pix * a.DC + n0 + ch * 8) = v;
+      }
+    }
+
+  } else {
+    constexpr int CPR = BN / 8;
+    for (int p = tid; p < BM * CPR; p += CV_THREADS) {
+      const int row = p / CPR, ch = p - row * CPR;
+      size_t pix = (size_t)(m0 + row);
+      if constexpr (MODE == 2) {  // class-ordered row -> pixel (n, 2 h2 + ph, 2 w2 + pw)
+        const int cls = a.M >> 2;
+        const int pc = m0 / cls;
+        const int m = m0 + row - pc * cls;
+        const int h2w2 = (a.DH >> 1) * (a.DW >> 1);
+        const int n = m / h2w2, rem = m - n * h2w2;
+        const int h2 = rem / (a.DW >> 1), w2 = rem - h2 * (a.DW >> 1);
+        pix = ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
+      }
+      if (m0 + row < a.M) {
+        uint4 v = *reinterpret_cast<const uint4*>(cv_smem + row * CS + ch * 16);
+        if (a.res != nullptr) {
+          const uint4 r4 = *reinterpret_cast<const uint4*>(a.res + pix * a.DC + n0 + ch * 8);
+          const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+          uint32_t o[4];
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] = pack_bf2(bf2f((uint16_t)(vv[e] & 0xffff)) + bf2f((uint16_t)(rr[e] & 0xffff)),
+                            bf2f((uint16_t)(vv[e] >> 16)) + bf2f((uint16_t)(rr[e] >> 16)));
+          v = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+        *reinterpret_cast<uint4*>(a.dst + pix * a.DC + n0 + ch * 8) = v;
+      }
+    }
+
   }
 }
 
@@ -563,17 +626,17 @@ int set_lds(K kernel, int bytes) {
   return e == hipSuccess ? WM_OK : (int)e;
 }
 
-template <int BM, int BN, int CPT, int MODE>
+template <int BM, int BN, int CPT, int MODE, bool EPI = false>
 int launch_igemm(const ConvArgs& a, hipStream_t st) {
   constexpr int lds = 2 * (BM * CV_ROW + BN * CV_ROW);
   static bool attr = false;
   if (!attr) {
-    const int rc = set_lds(&conv_igemm<BM, BN, CPT, MODE>, lds);
+    const int rc = set_lds(&conv_igemm<BM, BN, CPT, MODE, EPI>, lds);
     if (rc != WM_OK) return rc;
     attr = true;
   }
   dim3 grid(wm_cdiv(a.M, BM), a.DC / BN);
-  conv_igemm<BM, BN, CPT, MODE><<<grid, CV_THREADS, lds, st>>>(a);
+  conv_igemm<BM, BN, CPT, MODE, EPI><<<grid, CV_THREADS, lds, st>>>(a);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -636,11 +699,18 @@ static int conv_check(int N, int H, int W, int C, int K, int R, int S, int P, in
 
 static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int R,
                          int S, int P, int Q, int stride, int pad, float* stat, int stat_nb, int stat_rpg,
-                         void* stream);
+                         void* stream, const float* bias = nullptr, const void* residual = nullptr);
 
 extern "C" int wm_conv2d_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C,
                              int K, int R, int S, int P, int Q, int stride, int pad, void* stream) {
   return conv_fwd_impl(x, w_krsc, y, N, H, W, C, K, R, S, P, Q, stride, pad, nullptr, 0, 0, stream);
+}
+
+extern "C" int wm_conv2d_fwd_bias_res(const void* x, const void* w_krsc, const float* bias, const void* residual,
+                                      void* y, int N, int H, int W, int C, int K, int R, int S, int P, int Q,
+                                      int stride, int pad, void* stream) {
+  WM_REQUIRE((reinterpret_cast<uintptr_t>(bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(residual) & 15) == 0, WM_EALIGN);
+  return conv_fwd_impl(x, w_krsc, y, N, H, W, C, K, R, S, P, Q, stride, pad, nullptr, 0, 0, stream, bias, residual);
 }
 
 extern "C" int wm_conv2d_fwd_stats(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C,
@@ -654,7 +724,7 @@ extern "C" int wm_conv2d_fwd_stats(const void* x, const void* w_krsc, void* y, i
 
 static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int R,
                          int S, int P, int Q, int stride, int pad, float* stat, int stat_nb, int stat_rpg,
-                         void* stream) {
+                         void* stream, const float* bias, const void* residual) {
   WM_REQUIRE(x && w_krsc && y, WM_EINVAL);
   const int rc = conv_check(N, H, W, C, K, R, S, P, Q, stride, pad);
   if (rc != WM_OK) return rc;
@@ -665,13 +735,18 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   a.dst = static_cast<uint16_t*>(y);
   a.N = N; a.SH = H; a.SW = W; a.SC = C; a.DH = P; a.DW = Q; a.DC = K;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.M = N * P * Q;
-  a.stat = stat; a.stat_nb = stat_nb; a.stat_rpg = stat_rpg; a.res = nullptr;
+  a.stat = stat; a.stat_nb = stat_nb; a.stat_rpg = stat_rpg;
+  a.res = static_cast<const uint16_t*>(residual);
+  a.bias = bias;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (C == 16) {
+    WM_REQUIRE(bias == nullptr && residual == nullptr, WM_EUNSUPPORTED);
     a.nkt = R;
     return K % 128 == 0 ? launch_igemm<128, 128, 2, 0>(a, st) : launch_igemm<128, 64, 2, 0>(a, st);
   }
   a.nkt = R * S * (C / 64);
+  if (bias != nullptr || residual != nullptr)
+    return K % 128 == 0 ? launch_igemm<128, 128, 8, 0, true>(a, st) : launch_igemm<128, 64, 8, 0, true>(a, st);
   return K % 128 == 0 ? launch_igemm<128, 128, 8, 0>(a, st) : launch_igemm<128, 64, 8, 0>(a, st);
 }
 

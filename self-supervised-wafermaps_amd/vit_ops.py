@@ -130,13 +130,11 @@ class _LinearBias(torch.autograd.Function):
         krsc, _ = ops._WCACHE.get(weight, kind="linear", need_crsk=train and x.requires_grad)
         lib = _lib.load()
         y = torch.empty((rows, k), dtype=torch.bfloat16, device=x.device)
-        check(lib.wm_conv2d_fwd(ptr(x), ptr(krsc), ptr(y), rows, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
-              "wm_conv2d_fwd(linear)")
         if residual is not None:
             residual = _bf16_rows(residual)
-        # epilogue in place: element t is read and written by the same lane
-        check(lib.wm_bias_act_fwd(ptr(y), ptr(bias), ptr(residual), ACT_NONE, rows, k, ptr(y), stream_ptr()),
-              "wm_bias_act_fwd")
+        # bias and residual are added in the GEMM kernel's epilogue
+        check(lib.wm_conv2d_fwd_bias_res(ptr(x), ptr(krsc), ptr(bias), ptr(residual), ptr(y), rows, 1, 1, c, k, 1, 1, 1, 1,
+                                         1, 0, stream_ptr()), "wm_conv2d_fwd_bias_res(linear)")
         ctx.save_for_backward(x)
         ctx.params = (weight, bias)
         ctx.geom = (rows, c, k)
