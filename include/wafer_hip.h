@@ -259,9 +259,11 @@ int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, int r
                     long long rows, int C, int G, float* dgamma, float* dbeta, int accumulate, void* dy,
                     void* dz, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the fused stem tail max_pool3x3s2(relu(BN(y))): y [N][H][W][C]; the gradient entering
- * the BN is gathered from pooled_dy / pool_idx [N][P][Q][C] inside the two BN backward passes. */
-int wm_bn_relu_maxpool_bwd(const void* y, const void* pooled_dy, const void* pool_idx, int N, int H, int W,
-                           int C, const float* gamma, const float* beta, const float* save_mean,
+ * the BN is gathered from pooled_dy / pool_idx [N][P][Q][C] inside the apply pass; with ysel (the
+ * inputs at the selected positions, from the forward; may be NULL) the per-channel sums run over the
+ * pooled tensors alone. */
+int wm_bn_relu_maxpool_bwd(const void* y, const void* ysel, const void* pooled_dy, const void* pool_idx, int N,
+                           int H, int W, int C, const float* gamma, const float* beta, const float* save_mean,
                            const float* save_invstd, int G, float* dgamma, float* dbeta, int accumulate,
                            void* dy, void* workspace, size_t workspace_bytes, void* stream);
 int wm_add_bf16(const void* a, const void* b, long long n, void* out, void* stream);
@@ -272,7 +274,7 @@ int wm_maxpool3x3s2_fwd(const void* x, int N, int H, int W, int C, void* y, void
 /* ResNet stem: maxpool(relu(x*scale + shift)) in one pass (scale/shift [G][C], G groups of N/G
  * images); the normalised 112x112 activation is never materialised.  Same idx semantics. */
 int wm_bn_relu_maxpool3x3s2_fwd(const void* x, const float* scale, const float* shift, int N, int H, int W, int C,
-                                int G, void* y, void* idx, void* stream);
+                                int G, void* y, void* idx, void* xsel, void* stream);
 int wm_maxpool3x3s2_bwd(const void* dy, const void* idx, int N, int H, int W, int C, void* dx, void* stream);
 int wm_gap_fwd(const void* x, int N, int HW, int C, void* y, void* stream);
 int wm_gap_bwd(const void* dy, int N, int HW, int C, void* dx, void* stream);

@@ -120,13 +120,13 @@ SIGNATURES = {
     ),
     "wm_bn_relu_maxpool_bwd": (
         c_int,
-        [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int,
          c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "wm_add_bf16": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),
     "wm_maxpool3x3s2_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "wm_bn_relu_maxpool3x3s2_fwd": (
-        c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+        c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wm_maxpool3x3s2_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_gap_fwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_gap_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -641,7 +641,7 @@ extern "C" int wm_bn_eval_fwd(const void* y, const void* residual, const float* 
 static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, int relu_from_y, const float* gamma,
                        const float* beta, const float* save_mean, const float* save_invstd, long long rows, int C,
                        int G, float* dgamma, float* dbeta, int accumulate, void* dy, void* dz, void* workspace,
-                       size_t workspace_bytes, void* stream, const PoolSrc ps);
+                       size_t workspace_bytes, void* stream, const PoolSrc ps, const void* ysel = nullptr);
 
 extern "C" int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, int relu_from_y,
                                const float* gamma, const float* beta, const float* save_mean,
@@ -655,8 +655,9 @@ extern "C" int wm_bn_train_bwd(const void* y, const void* dout, const void* out_
 
 // Backward of max_pool3x3s2(relu(BN(y))) (the fused stem): the gradient entering the BN is gathered
 // from the pooled gradient + window positions instead of being materialised by wm_maxpool3x3s2_bwd.
-extern "C" int wm_bn_relu_maxpool_bwd(const void* y, const void* pooled_dy, const void* pool_idx, int N, int H,
-                                      int W, int C, const float* gamma, const float* beta, const float* save_mean,
+extern "C" int wm_bn_relu_maxpool_bwd(const void* y, const void* ysel, const void* pooled_dy, const void* pool_idx,
+                                      int N, int H, int W, int C, const float* gamma, const float* beta,
+                                      const float* save_mean,
                                       const float* save_invstd, int G, float* dgamma, float* dbeta, int accumulate,
                                       void* dy, void* workspace, size_t workspace_bytes, void* stream) {
   WM_REQUIRE(pooled_dy && pool_idx && gamma && beta, WM_EINVAL);
@@ -666,13 +667,13 @@ extern "C" int wm_bn_relu_maxpool_bwd(const void* y, const void* pooled_dy, cons
   ps.idx = static_cast<const uint8_t*>(pool_idx);
   ps.H = H; ps.W = W; ps.P = (H + 2 - 3) / 2 + 1; ps.Q = (W + 2 - 3) / 2 + 1;
   return bn_bwd_impl(y, nullptr, nullptr, 1, gamma, beta, save_mean, save_invstd, (long long)N * H * W, C, G, dgamma,
-                     dbeta, accumulate, dy, nullptr, workspace, workspace_bytes, stream, ps);
+                     dbeta, accumulate, dy, nullptr, workspace, workspace_bytes, stream, ps, ysel);
 }
 
 static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, int relu_from_y, const float* gamma,
                        const float* beta, const float* save_mean, const float* save_invstd, long long rows, int C,
                        int G, float* dgamma, float* dbeta, int accumulate, void* dy, void* dz, void* workspace,
-                       size_t workspace_bytes, void* stream, const PoolSrc ps) {
+                       size_t workspace_bytes, void* stream, const PoolSrc ps, const void* ysel) {
   WM_REQUIRE(y && (dout || ps.dy) && save_mean && save_invstd && dy && workspace, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
   if (rc != WM_OK) return rc;
@@ -686,12 +687,26 @@ static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, in
   const size_t lds = (size_t)2 * rpp * C * sizeof(float);
   const bool remask = relu_from_y && !out_relu;
   WM_REQUIRE(!remask || (gamma && beta), WM_EINVAL);
-  bn_reduce<1><<<dim3(nblk, G), BN_THREADS, lds, st>>>(
-      static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
-      save_mean, save_invstd, remask ? gamma : nullptr, remask ? beta : nullptr, rpg, C, wm_cdiv(rpg, nblk), part, ps);
+  int nblk_used = nblk;
+  if (ps.dy != nullptr && ysel != nullptr) {
+    // pooled source with the selected inputs at hand: the sums run over the pooled tensor (a quarter of
+    // the rows, no gather); 1/M in the finalize stays the full row count
+    const long long prow = (long long)(rows / ((long long)ps.H * ps.W)) * ps.P * ps.Q;
+    WM_REQUIRE(prow % G == 0, WM_EUNSUPPORTED);
+    const int prpg = (int)(prow / G);
+    nblk_used = reduce_blocks(prpg, C);
+    if (nblk_used > nblk) nblk_used = nblk;  // the workspace was sized for nblk
+    bn_reduce<1><<<dim3(nblk_used, G), BN_THREADS, lds, st>>>(
+        static_cast<const uint16_t*>(ysel), ps.dy, nullptr, save_mean, save_invstd, gamma, beta, prpg, C,
+        wm_cdiv(prpg, nblk_used), part, PoolSrc{});
+  } else {
+    bn_reduce<1><<<dim3(nblk, G), BN_THREADS, lds, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
+        save_mean, save_invstd, remask ? gamma : nullptr, remask ? beta : nullptr, rpg, C, wm_cdiv(rpg, nblk), part, ps);
+  }
   WM_LAUNCH_CHECK();
-  bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, gamma, beta, save_mean, save_invstd, dgamma,
-                                                   dbeta, accumulate, coef);
+  bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk_used, G, C, rpg, gamma, beta, save_mean, save_invstd,
+                                                   dgamma, dbeta, accumulate, coef);
   WM_LAUNCH_CHECK();
   int csh = 0;
   if (chunk_pow2(C, &csh))

@@ -74,7 +74,8 @@ __global__ __launch_bounds__(PL_THREADS) void bn_relu_maxpool_fwd(const uint16_t
                                                                   int H, int W, int C, int P, int Q,
                                                                   int imgs_per_group,
                                                                   uint16_t* __restrict__ y,
-                                                                  uint8_t* __restrict__ idx) {
+                                                                  uint8_t* __restrict__ idx,
+                                                                  uint16_t* __restrict__ xsel) {
   const int cpr = C >> 3;
   const long long total = (long long)N * P * Q * cpr;
   for (long long t = (long long)blockIdx.x * PL_THREADS + threadIdx.x; t < total;
@@ -85,7 +86,7 @@ __global__ __launch_bounds__(PL_THREADS) void bn_relu_maxpool_fwd(const uint16_t
     pix /= Q;
     const int p = (int)(pix % P), n = (int)(pix / P);
     const int g = n / imgs_per_group;
-    float sc[8], sh[8];
+    float sc[8], sh[8], bx[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       sc[e] = scale[(size_t)g * C + c0 + e];
@@ -114,6 +115,7 @@ __global__ __launch_bounds__(PL_THREADS) void bn_relu_maxpool_fwd(const uint16_t
             if (first || v > best[e]) {
               best[e] = v;
               bi[e] = kh * 3 + kw;
+              bx[e] = f[e];
             }
           }
           first = false;
@@ -126,6 +128,11 @@ __global__ __launch_bounds__(PL_THREADS) void bn_relu_maxpool_fwd(const uint16_t
     pk.x = bi[0] | (bi[1] << 8) | (bi[2] << 16) | (bi[3] << 24);
     pk.y = bi[4] | (bi[5] << 8) | (bi[6] << 16) | (bi[7] << 24);
     *reinterpret_cast<uint2*>(idx + o) = pk;
+    // the selected INPUT values: with them the backward's per-channel sums run over the pooled tensor
+    // only (sum_pixels dz f(x) = sum_windows dy_pooled f(x at argmax), dz being a scatter of dy_pooled)
+    if (xsel != nullptr)
+      *reinterpret_cast<uint4*>(xsel + o) = make_uint4(pack_bf2(bx[0], bx[1]), pack_bf2(bx[2], bx[3]),
+                                                       pack_bf2(bx[4], bx[5]), pack_bf2(bx[6], bx[7]));
   }
 }
 
@@ -229,14 +236,14 @@ extern "C" int wm_maxpool3x3s2_fwd(const void* x, int N, int H, int W, int C, vo
 }
 
 extern "C" int wm_bn_relu_maxpool3x3s2_fwd(const void* x, const float* scale, const float* shift, int N, int H,
-                                           int W, int C, int G, void* y, void* idx, void* stream) {
+                                           int W, int C, int G, void* y, void* idx, void* xsel, void* stream) {
   WM_REQUIRE(x && scale && shift && y && idx, WM_EINVAL);
   WM_REQUIRE(N > 0 && H > 1 && W > 1 && C > 0 && G > 0, WM_EINVAL);
   WM_REQUIRE(C % 8 == 0 && N % G == 0, WM_EUNSUPPORTED);
   const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
   bn_relu_maxpool_fwd<<<grid_for((long long)N * P * Q * (C >> 3)), PL_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
       static_cast<const uint16_t*>(x), scale, shift, N, H, W, C, P, Q, N / G, static_cast<uint16_t*>(y),
-      static_cast<uint8_t*>(idx));
+      static_cast<uint8_t*>(idx), static_cast<uint16_t*>(xsel));
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

@@ -450,10 +450,13 @@ class _BnReluMaxPool(torch.autograd.Function):
         p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
         out = _empty_nhwc(n, c, p, q, y.device)
         idx = torch.empty((n, p, q, c), dtype=torch.uint8, device=y.device)
+        # the conv outputs at the selected positions: the backward's reduction then needs only pooled-size tensors
+        ysel = torch.empty((n, p, q, c), dtype=torch.bfloat16, device=y.device) if training and y.requires_grad else None
         check(lib.wm_bn_relu_maxpool3x3s2_fwd(y.data_ptr(), ptr(scale), ptr(shift), n, h, w, c, g, out.data_ptr(), ptr(idx),
-                                              stream_ptr()), "wm_bn_relu_maxpool3x3s2_fwd")
+                                              ptr(ysel), stream_ptr()), "wm_bn_relu_maxpool3x3s2_fwd")
         ctx.training = training
         ctx.idx = idx
+        ctx.ysel = ysel
         ctx.affine = (gamma, beta)
         ctx.meta = (n, c, h, w, g)
         return out
@@ -475,7 +478,7 @@ class _BnReluMaxPool(torch.autograd.Function):
         dbeta = sb if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
         ws = _bn_workspace(rows, c, g, y.device)
         # the pooled gradient is scattered back inside the two BN backward passes (no 112x112 dout tensor)
-        check(lib.wm_bn_relu_maxpool_bwd(y.data_ptr(), dpooled.data_ptr(), ptr(ctx.idx), n, h, w, c, ptr(gamma), ptr(beta),
+        check(lib.wm_bn_relu_maxpool_bwd(y.data_ptr(), ptr(ctx.ysel), dpooled.data_ptr(), ptr(ctx.idx), n, h, w, c, ptr(gamma), ptr(beta),
                                          ptr(mean), ptr(invstd), g, ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(),
                                          ptr(ws), ws.numel(), stream_ptr()), "wm_bn_relu_maxpool_bwd")
         if direct:

@@ -332,7 +332,21 @@ def test_bn_relu_maxpool_fused_matches_unfused(groups, training, hw):
     a, b = res
     assert torch.equal(a[0], b[0])
     if training:
-        _close(b[1], a[1].float().cpu(), rel=1e-3, what="dy")
-        torch.testing.assert_close(b[2], a[2], rtol=1e-4, atol=1e-4)
-        torch.testing.assert_close(b[3], a[3], rtol=1e-4, atol=1e-4)
+        # the fused path sums the pooled gradient unrounded; the unfused one rounds the scattered
+        # gradient to bf16 first (two windows can select one pixel), which shows in dy (one bf16 ulp)
+        # and in the per-channel sums (~sqrt(n) * 2^-9): both are checked against float32 autograd
+        _close(b[1], a[1].float().cpu(), rel=5e-3, what="dy")
+        yr = y.float().cpu().requires_grad_(True)
+        gr, br_ = gamma.cpu().clone().requires_grad_(True), beta.cpu().clone().requires_grad_(True)
+        parts = [F.batch_norm(part, None, None, gr, br_, True, 0.1, 1e-5) for part in yr.chunk(groups)]
+        ref = F.max_pool2d(F.relu(torch.cat(parts)), 3, 2, 1)
+        ref.backward(dp.float().cpu())
+        _close(b[2], gr.grad, rel=3e-3, what="dgamma (fused)")
+        _close(b[3], br_.grad, rel=3e-3, what="dbeta (fused)")
+        _close(a[2], gr.grad, rel=1e-2, what="dgamma (unfused)")
+        _close(a[3], br_.grad, rel=1e-2, what="dbeta (unfused)")
+        # dy against float32: identical except where two window entries tie after the bf16 rounding of the
+        # forward (the kernel then routes the gradient to the first of them, float32 to the larger)
+        d = (b[1].float().cpu() - yr.grad).abs()
+        assert (d <= 1e-2 * yr.grad.abs().max()).float().mean() > 0.995
         torch.testing.assert_close(b[4], a[4]); torch.testing.assert_close(b[5], a[5])
