@@ -454,6 +454,95 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __res
   }
 }
 
+// Stem variant of the apply pass (max-pool 3x3 / stride 2 / pad 1 source, H and W even): one thread owns
+// a 2 x 2 pixel quad x 8 channels.  The quad's pixels are covered by the four windows (a, b), (a, b+1),
+// (a+1, b), (a+1, b+1) only, so the pooled gradient and the window positions are read 4 times per
+// quad instead of 9 (1 + 2 + 2 + 4 per pixel), with fixed position codes per (pixel, window).
+__global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply(const uint16_t* __restrict__ y,
+                                                                const float* __restrict__ coef, int N, int C,
+                                                                int imgs_per_group, int remask,
+                                                                uint16_t* __restrict__ dy, const PoolSrc ps) {
+  const int cpr = C >> 3;
+  const int HA = ps.H >> 1, WB = ps.W >> 1;
+  const long long total = (long long)N * HA * WB * cpr;
+  int cur_g = -1;
+  float k[7][8];
+  for (long long t = (long long)blockIdx.x * BN_THREADS + threadIdx.x; t < total;
+       t += (long long)gridDim.x * BN_THREADS) {
+    const int c0 = (int)(t % cpr) * 8;
+    long long u = t / cpr;
+    const int b = (int)(u % WB);
+    u /= WB;
+    const int a = (int)(u % HA), n = (int)(u / HA);
+    const int g = n / imgs_per_group;
+    if (g != cur_g) {
+      const float* cf = coef + (size_t)g * 7 * C + c0;
+#pragma unroll
+      for (int q = 0; q < 7; ++q) {
+        const float4 lo = *reinterpret_cast<const float4*>(cf + (size_t)q * C);
+        const float4 hi = *reinterpret_cast<const float4*>(cf + (size_t)q * C + 4);
+        k[q][0] = lo.x; k[q][1] = lo.y; k[q][2] = lo.z; k[q][3] = lo.w;
+        k[q][4] = hi.x; k[q][5] = hi.y; k[q][6] = hi.z; k[q][7] = hi.w;
+      }
+      cur_g = g;
+    }
+    // the four windows (clamped addresses; an out-of-range window contributes nothing)
+    uint2 pk[4];
+    uint4 dv[4];
+    bool wok[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int p = a + (j >> 1), q = b + (j & 1);
+      wok[j] = p < ps.P && q < ps.Q;
+      const int pc = p < ps.P ? p : ps.P - 1, qc = q < ps.Q ? q : ps.Q - 1;
+      const size_t o = ((size_t)(n * ps.P + pc) * ps.Q + qc) * C + c0;
+      pk[j] = *reinterpret_cast<const uint2*>(ps.idx + o);
+      dv[j] = *reinterpret_cast<const uint4*>(ps.dy + o);
+    }
+    float dw[4][8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) unpack8(dv[j], dw[j]);
+    // pixel (dh, dw) of the quad, window j = (jp, jq): position code (2 dh + 1 - 2 jp... ) = kh * 3 + kw with
+    // kh = 2a + dh - (2 (a + jp) - 1) = dh + 1 - 2 jp, kw likewise; valid when 0 <= kh, kw <= 2
+#pragma unroll
+    for (int pix = 0; pix < 4; ++pix) {
+      const int dh = pix >> 1, dwp = pix & 1;
+      float fd[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fd[e] = 0.f;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kh = dh + 1 - 2 * (j >> 1), kw = dwp + 1 - 2 * (j & 1);
+        if (kh < 0 || kw < 0) continue;  // compile-time after unrolling
+        const int code = kh * 3 + kw;
+        if (wok[j]) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const int ie = (int)(((e < 4 ? pk[j].x : pk[j].y) >> (8 * (e & 3))) & 0xff);
+            fd[e] += ie == code ? dw[j][e] : 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 8; ++e) fd[e] = bf2f(f2bf(fd[e]));  // as maxpool_bwd would have stored it
+      const size_t off = ((size_t)(n * ps.H + 2 * a + dh) * ps.W + 2 * b + dwp) * C + c0;
+      float fy[8];
+      unpack8(*reinterpret_cast<const uint4*>(y + off), fy);
+      if (remask) {
+#pragma unroll
+        for (int e = 0; e < 8; ++e) fd[e] = bf2f(f2bf(fmaf(fy[e], k[5][e], k[6][e]))) > 0.f ? fd[e] : 0.f;
+      }
+      float r[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const float xh = (fy[e] - k[0][e]) * k[1][e];
+        r[e] = k[2][e] * (fd[e] - k[3][e] - xh * k[4][e]);
+      }
+      *reinterpret_cast<uint4*>(dy + off) = pack8(r);
+    }
+  }
+}
+
 inline bool chunk_pow2(int C, int* shift) {
   const int cpr = C >> 3;
   if (cpr <= 0 || (cpr & (cpr - 1)) || BN_THREADS % cpr) return false;
@@ -709,6 +798,13 @@ static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, in
                                                    dgamma, dbeta, accumulate, coef);
   WM_LAUNCH_CHECK();
   int csh = 0;
+  if (ps.dy != nullptr && !dz && !out_relu && (ps.H & 1) == 0 && (ps.W & 1) == 0 && BN_THREADS % tpr == 0) {
+    const int n_img = (int)(rows / ((long long)ps.H * ps.W));
+    bn_pool_bwd_apply<<<stream_grid(rows / 4 * tpr), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), coef, n_img, C, n_img / G, remask ? 1 : 0, static_cast<uint16_t*>(dy), ps);
+    WM_LAUNCH_CHECK();
+    return WM_OK;
+  }
   if (chunk_pow2(C, &csh))
     bn_bwd_apply<true><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
