@@ -35,7 +35,15 @@ class BasicBlock(nn.Module):
         nn.init.zeros_(self.bn2.weight)  # timm zero_init_last
 
     def forward(self, x):
-        if self.downsample is not None:
+        if self.downsample is not None and torch.is_grad_enabled() and x.requires_grad:
+            # the block input feeds conv1 and the 1x1 downsample: conv1 hands it on, so the downsample's
+            # input gradient comes back to conv1's backward and is added in its dgrad epilogue
+            g = ops.current_bn_groups()
+            st = self.bn1.stats_buffer(g) if self.bn1.training else None
+            y, x_alias = self.conv1(x, stats=st, groups=g, passthrough=True)
+            out = self.bn1(y, relu=True, stats=st)
+            shortcut = conv_bn(self.downsample[0], self.downsample[1], x_alias)
+        elif self.downsample is not None:
             out = conv_bn(self.conv1, self.bn1, x, relu=True)
             shortcut = conv_bn(self.downsample[0], self.downsample[1], x)
         elif torch.is_grad_enabled() and x.requires_grad:
