@@ -826,6 +826,27 @@ extern "C" int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_krs
     if (K % 128 == 0) return coltiles % 2 == 0 ? launch_wgrad<128, 2, 2>(a, st) : launch_wgrad<128, 2, 1>(a, st);
     return coltiles % 4 == 0 ? launch_wgrad<64, 2, 4>(a, st) : launch_wgrad<64, 2, 1>(a, st);
   }
-  if (K % 128 == 0) return (coltiles % 2 == 0 && C > 128) ? launch_wgrad<128, 8, 2>(a, st) : launch_wgrad<128, 8, 1>(a, st);
+  if (K % 128 == 0) {
+    static int force_nt = -1;  // WM_WGRAD_NT: experiment switch (1, 2 or 3 column tiles per block)
+    if (force_nt < 0) {
+      const char* e = getenv("WM_WGRAD_NT");
+      force_nt = e ? atoi(e) : 0;
+    }
+    if (force_nt == 3 && coltiles % 3 == 0) return launch_wgrad<128, 8, 3>(a, st);
+    if (force_nt == 2 && coltiles % 2 == 0) return launch_wgrad<128, 8, 2>(a, st);
+    if (force_nt == 1) return launch_wgrad<128, 8, 1>(a, st);
+    // column tiles per block, measured per ResNet-18 shape at batch 512 (profiles/r01_conv_layers_v3.txt):
+    // three taps per block where the dY tile is the larger share of the traffic (C <= 128 with K = 128)
+    // and for the 512-channel layers, two for 256 channels, one for the stride-2 128 -> 256 layer
+    int nt = (coltiles % 2 == 0 && C > 128) ? 2 : 1;
+    if (R * S == 9) {
+      if (C <= 128 && K == 128) nt = 3;
+      else if (C == 128) nt = 1;
+      else if (C >= 512) nt = 3;
+    }
+    if (nt == 3 && coltiles % 3 == 0) return launch_wgrad<128, 8, 3>(a, st);
+    if (nt == 2 && coltiles % 2 == 0) return launch_wgrad<128, 8, 2>(a, st);
+    return launch_wgrad<128, 8, 1>(a, st);
+  }
   return coltiles % 3 == 0 ? launch_wgrad<64, 8, 3>(a, st) : launch_wgrad<64, 8, 1>(a, st);
 }
