@@ -285,6 +285,13 @@ int wm_gap_bwd(const void* dy, int N, int HW, int C, void* dx, void* stream);
 int wm_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, const float* hyper,
                 void* stream);
 
+/* NT-Xent against a memory bank (lightly NTXentLoss(memory_bank_size > 0), the reference's MoCo:
+ * scripts/WM811k_benchmark.py:305-307).  q, kpos: L2-normalised [B][D] float32; bank [D][K] float32
+ * (lightly's layout, one stored key per column).  logits_i = [<q_i,kpos_i>, <q_i,bank>] / T, label 0.
+ * loss[0] += mean CE (zero it first); dq, dk [B][D] = d loss / d q, d kpos.  K + 2 D <= 16384. */
+int wm_ntxent_bank_fwd_bwd(const float* q, const float* kpos, const float* bank, int B, int D, int K,
+                           float temperature, float* loss, float* dq, float* dk, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Vision-transformer path (SURVEY §8 a13 DINOViT, a14 MAE).
  * Replaces, in the reference: the facebookresearch/dino `dino_vits16` backbone called at
@@ -302,9 +309,11 @@ int wm_layernorm_fwd(const void* x, const float* gamma, const float* beta, float
 int wm_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
                      long long rows, int C, void* dx, float* dgamma, float* dbeta, void* stream);
 
-/* y = act(x + bias) (+ residual).  act: 0 identity, 1 exact GELU (erf).  bias / residual may be NULL. */
+/* y = act(x + bias) (+ residual).  act: 0 identity, 1 exact GELU (erf), 2 ReLU (the bias-carrying heads:
+ * lightly MoCoProjectionHead).  bias / residual may be NULL. */
 #define WM_ACT_NONE 0
 #define WM_ACT_GELU 1
+#define WM_ACT_RELU 2
 int wm_bias_act_fwd(const void* x, const float* bias, const void* residual, int act, long long rows, int C,
                     void* y, void* stream);
 /* dx = dy * act'(x + bias) (dx may be NULL for act 0: only the bias gradient is wanted);

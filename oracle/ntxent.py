@@ -46,3 +46,28 @@ def ntxent_closed_form_f64(out0, out1, temperature=0.5):
     s.fill_diagonal_(float("-inf"))
     pos = torch.cat([torch.arange(b, n), torch.arange(0, b)])
     return (torch.logsumexp(s, dim=1) - s[torch.arange(n), pos]).mean()
+
+
+def ntxent_memory_bank(out0, out1, bank, temperature=0.1):
+    """lightly NTXentLoss.forward with memory_bank_size > 0 (the reference's MoCo,
+    scripts/WM811k_benchmark.py:305-307,337-338): positives <out0, out1>, negatives out0 . bank [D, K],
+    logits [B, 1 + K] / T, labels 0."""
+    out0 = F.normalize(out0, dim=1)
+    out1 = F.normalize(out1, dim=1)
+    sim_pos = torch.einsum("nc,nc->n", out0, out1).unsqueeze(-1)
+    sim_neg = torch.einsum("nc,ck->nk", out0, bank)
+    logits = torch.cat([sim_pos, sim_neg], dim=1) / temperature
+    labels = torch.zeros(logits.shape[0], dtype=torch.long, device=out0.device)
+    return F.cross_entropy(logits, labels, reduction="mean")
+
+
+def memory_bank_enqueue(bank, ptr, batch):
+    """lightly MemoryBankModule._dequeue_and_enqueue: returns the new pointer; writes normalised keys as
+    columns; a batch that reaches the end fills the tail and wraps the pointer to 0."""
+    size = bank.shape[1]
+    b = batch.shape[0]
+    if ptr + b >= size:
+        bank[:, ptr:] = batch[: size - ptr].T.detach()
+        return 0
+    bank[:, ptr:ptr + b] = batch.T.detach()
+    return ptr + b

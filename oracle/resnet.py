@@ -73,3 +73,9 @@ def sgd_step(params, grads, bufs, lr, momentum=0.9, weight_decay=5e-4):
         else:
             bufs[k].mul_(momentum).add_(d)
         params[k].sub_(lr * bufs[k])
+
+
+def moco_head(f, sd, prefix="projection_head."):
+    """lightly MoCoProjectionHead: Linear(+bias)-ReLU, Linear(+bias) (layers.0, layers.2)."""
+    x = F.relu(F.linear(f, sd[prefix + "layers.0.weight"], sd[prefix + "layers.0.bias"]))
+    return F.linear(x, sd[prefix + "layers.2.weight"], sd[prefix + "layers.2.bias"])

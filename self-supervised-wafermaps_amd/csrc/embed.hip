@@ -324,3 +324,84 @@ extern "C" int wm_ntxent_bwd(const float* zn, const float* zall, const float* ls
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
+
+// ------------------------------------------------------------------------------------ MoCo bank
+// NT-Xent against a memory bank (lightly.loss.NTXentLoss(memory_bank_size > 0), the reference's MoCo:
+// scripts/WM811k_benchmark.py:305-307,337-338).  Per query row i:
+//   logits = [ <q_i, k_i> , <q_i, bank[:, 0..K)> ] / T,  label 0,  loss = mean_i (lse_i - logit_i0)
+//   dq_i = ((p_i0 - 1) k_i + sum_k p_ik bank[:, k]) / (B T),   dk_i = (p_i0 - 1) q_i / (B T)
+// bank is lightly's [D][K] (column = one stored key).  One block per query row: threads stride over
+// the K columns (coalesced across k for every d), the K logits live in LDS between the two passes.
+namespace {
+constexpr int MB_THREADS = 256;
+
+__device__ __forceinline__ float mb_block_reduce(float v, float* red, bool is_max) {
+  v = is_max ? wave_max(v) : wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return is_max ? fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) : (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+__global__ __launch_bounds__(MB_THREADS) void ntxent_bank_kernel(const float* __restrict__ q, const float* __restrict__ kpos,
+                                                                 const float* __restrict__ bank, int B, int D, int K,
+                                                                 float inv_t, float* __restrict__ loss,
+                                                                 float* __restrict__ dq, float* __restrict__ dk) {
+  extern __shared__ float mb_smem[];  // q[D], kp[D], s[K]
+  __shared__ float red[4];
+  float* sq = mb_smem;
+  float* skp = sq + D;
+  float* ss = skp + D;
+  const int i = blockIdx.x, tid = threadIdx.x;
+  for (int d = tid; d < D; d += MB_THREADS) {
+    sq[d] = q[(size_t)i * D + d];
+    skp[d] = kpos[(size_t)i * D + d];
+  }
+  __syncthreads();
+  float part = 0.f;
+  for (int d = tid; d < D; d += MB_THREADS) part = fmaf(sq[d], skp[d], part);
+  const float s0 = mb_block_reduce(part, red, false) * inv_t;
+  float m = s0;
+  for (int k = tid; k < K; k += MB_THREADS) {
+    float s = 0.f;
+    for (int d = 0; d < D; ++d) s = fmaf(sq[d], bank[(size_t)d * K + k], s);
+    s *= inv_t;
+    ss[k] = s;
+    m = fmaxf(m, s);
+  }
+  m = mb_block_reduce(m, red, true);
+  float sum = 0.f;
+  for (int k = tid; k < K; k += MB_THREADS) sum += expf(ss[k] - m);
+  sum = mb_block_reduce(sum, red, false) + expf(s0 - m);
+  const float lse = m + logf(sum);
+  const float w = inv_t / (float)B;
+  const float p0 = expf(s0 - lse);
+  if (tid == 0) atomicAdd(loss, (lse - s0) / (float)B);
+  for (int k = tid; k < K; k += MB_THREADS) ss[k] = expf(ss[k] - lse);  // own entries only: no sync needed yet
+  __syncthreads();
+  // dq[d] = w ((p0 - 1) kp[d] + sum_k p_k bank[d][k]): a wave per d, lanes stride over k (coalesced)
+  const int lane = tid & 63, wave = tid >> 6;
+  for (int d = wave; d < D; d += MB_THREADS / 64) {
+    float acc = 0.f;
+    const float* row = bank + (size_t)d * K;
+    for (int k = lane; k < K; k += 64) acc = fmaf(ss[k], row[k], acc);
+    acc = wave_sum(acc);
+    if (lane == 0) {
+      dq[(size_t)i * D + d] = w * ((p0 - 1.f) * skp[d] + acc);
+      dk[(size_t)i * D + d] = w * (p0 - 1.f) * sq[d];
+    }
+  }
+}
+}  // namespace
+
+extern "C" int wm_ntxent_bank_fwd_bwd(const float* q, const float* kpos, const float* bank, int B, int D, int K,
+                                      float temperature, float* loss, float* dq, float* dk, void* stream) {
+  WM_REQUIRE(q && kpos && bank && loss && dq && dk, WM_EINVAL);
+  WM_REQUIRE(B > 0 && D > 0 && K > 0 && temperature > 1e-8f, WM_EINVAL);
+  const size_t lds = ((size_t)2 * D + K) * sizeof(float);
+  WM_REQUIRE(lds <= 64 * 1024, WM_EUNSUPPORTED);  // K + 2 D <= 16384 floats
+  ntxent_bank_kernel<<<B, MB_THREADS, lds, static_cast<hipStream_t>(stream)>>>(q, kpos, bank, B, D, K, 1.f / temperature,
+                                                                              loss, dq, dk);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

@@ -184,6 +184,9 @@ __global__ __launch_bounds__(TF_THREADS) void bias_act_fwd(const uint16_t* __res
     if (ACT == WM_ACT_GELU) {
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = gelu_f(f[e]);
+    } else if (ACT == WM_ACT_RELU) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
     }
     if (res != nullptr) {
       float r[8];
@@ -198,7 +201,7 @@ __global__ __launch_bounds__(TF_THREADS) void bias_act_fwd(const uint16_t* __res
 // Column slabs of CB chunks (8 channels each) x RL row lanes per block: a thread keeps its chunk and
 // walks rows, so the per-channel sums stay in registers until the end of the block.
 // MODE 0: colsum of src only.  MODE 1: dx = dy (identity act) is not written, colsum of dy.
-// MODE 2: GELU: dx = dy * gelu'(x + bias), colsum of dx.
+// MODE 2: GELU: dx = dy * gelu'(x + bias), colsum of dx.  MODE 3: ReLU: dx = dy * (x + bias > 0).
 template <int MODE>
 __global__ __launch_bounds__(TF_THREADS) void colsum_kernel(const uint16_t* __restrict__ x, const float* __restrict__ bias,
                                                             const uint16_t* __restrict__ dy, long long rows, int C,
@@ -214,7 +217,7 @@ __global__ __launch_bounds__(TF_THREADS) void colsum_kernel(const uint16_t* __re
 #pragma unroll
   for (int e = 0; e < 8; ++e) acc[e] = b[e] = 0.f;
   if (on) {
-    if (MODE == 2 && bias != nullptr) load8f(bias + ch * 8, b);
+    if (MODE >= 2 && bias != nullptr) load8f(bias + ch * 8, b);
     const long long r0 = (long long)blockIdx.x * rows_per_block;
     long long r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
@@ -226,17 +229,17 @@ __global__ __launch_bounds__(TF_THREADS) void colsum_kernel(const uint16_t* __re
       for (int u = 0; u < 4; ++u) {
         const size_t off = (size_t)(r + u * RL) * C + ch * 8;
         vd[u] = *reinterpret_cast<const uint4*>(dy + off);
-        if (MODE == 2) vx[u] = *reinterpret_cast<const uint4*>(x + off);
+        if (MODE >= 2) vx[u] = *reinterpret_cast<const uint4*>(x + off);
       }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         float fd[8];
         unpack8(vd[u], fd);
-        if (MODE == 2) {
+        if (MODE >= 2) {
           float fx[8];
           unpack8(vx[u], fx);
 #pragma unroll
-          for (int e = 0; e < 8; ++e) fd[e] *= gelu_grad(fx[e] + b[e]);
+          for (int e = 0; e < 8; ++e) fd[e] *= MODE == 2 ? gelu_grad(fx[e] + b[e]) : (fx[e] + b[e] > 0.f ? 1.f : 0.f);
           const uint4 pk = pack8(fd);
           *reinterpret_cast<uint4*>(dx + (size_t)(r + u * RL) * C + ch * 8) = pk;
           unpack8(pk, fd);  // the sums see the rounded gradient, like a separate reduction would
@@ -249,11 +252,11 @@ __global__ __launch_bounds__(TF_THREADS) void colsum_kernel(const uint16_t* __re
       const size_t off = (size_t)r * C + ch * 8;
       float fd[8];
       unpack8(*reinterpret_cast<const uint4*>(dy + off), fd);
-      if (MODE == 2) {
+      if (MODE >= 2) {
         float fx[8];
         unpack8(*reinterpret_cast<const uint4*>(x + off), fx);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) fd[e] *= gelu_grad(fx[e] + b[e]);
+        for (int e = 0; e < 8; ++e) fd[e] *= MODE == 2 ? gelu_grad(fx[e] + b[e]) : (fx[e] + b[e] > 0.f ? 1.f : 0.f);
         const uint4 pk = pack8(fd);
         *reinterpret_cast<uint4*>(dx + off) = pk;
         unpack8(pk, fd);
@@ -674,11 +677,15 @@ extern "C" int wm_bias_act_fwd(const void* x, const float* bias, const void* res
                                void* y, void* stream) {
   WM_REQUIRE(x && y, WM_EINVAL);
   WM_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
-  WM_REQUIRE(act == WM_ACT_NONE || act == WM_ACT_GELU, WM_EUNSUPPORTED);
+  WM_REQUIRE(act == WM_ACT_NONE || act == WM_ACT_GELU || act == WM_ACT_RELU, WM_EUNSUPPORTED);
   WM_REQUIRE(al16(x) && al16(y) && al16(bias) && al16(residual), WM_EALIGN);
   const int blocks = ew_blocks(rows * (C >> 3));
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (act == WM_ACT_GELU)
+  if (act == WM_ACT_RELU)
+    bias_act_fwd<WM_ACT_RELU><<<blocks, TF_THREADS, 0, st>>>(static_cast<const uint16_t*>(x), bias,
+                                                             static_cast<const uint16_t*>(residual), rows, C,
+                                                             static_cast<uint16_t*>(y));
+  else if (act == WM_ACT_GELU)
     bias_act_fwd<WM_ACT_GELU><<<blocks, TF_THREADS, 0, st>>>(static_cast<const uint16_t*>(x), bias,
                                                              static_cast<const uint16_t*>(residual), rows, C,
                                                              static_cast<uint16_t*>(y));
@@ -700,9 +707,10 @@ extern "C" int wm_bias_act_bwd(const void* x, const float* bias, const void* dy,
     if (dbias == nullptr) return WM_OK;
     return launch_colsum<1>(nullptr, nullptr, dy, rows, C, nullptr, dbias, st);
   }
-  WM_REQUIRE(act == WM_ACT_GELU, WM_EUNSUPPORTED);
+  WM_REQUIRE(act == WM_ACT_GELU || act == WM_ACT_RELU, WM_EUNSUPPORTED);
   WM_REQUIRE(x && dx, WM_EINVAL);
-  return launch_colsum<2>(x, bias, dy, rows, C, dx, dbias, st);
+  return act == WM_ACT_GELU ? launch_colsum<2>(x, bias, dy, rows, C, dx, dbias, st)
+                            : launch_colsum<3>(x, bias, dy, rows, C, dx, dbias, st);
 }
 
 extern "C" int wm_colsum_bf16(const void* x, long long rows, int C, float* out, int accumulate, void* stream) {

@@ -44,8 +44,10 @@ class ProjectionHead(nn.Module):
                     x = self.layers[i_bn](x, relu=act is not None)
             elif isinstance(act, hnn.GELU):
                 x = lin(x, act=vit_ops.ACT_GELU)
+            elif isinstance(act, hnn.ReLU):
+                x = lin(x, act=vit_ops.ACT_RELU)
             elif act is not None:
-                raise NotImplementedError("bias + ReLU epilogue is not built (no reference head on this path uses it)")
+                raise NotImplementedError(f"ProjectionHead: activation {type(act).__name__} has no HIP path")
             else:
                 x = lin(x)
         return x
@@ -64,6 +66,14 @@ class SimCLRProjectionHead(ProjectionHead):
             blocks.append((hidden_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.ReLU()))
         blocks.append((hidden_dim, output_dim, hnn.BatchNorm1d(output_dim), None))
         super().__init__(blocks)
+
+
+class MoCoProjectionHead(ProjectionHead):
+    """lightly MoCoProjectionHead: Linear(+bias)-ReLU, Linear(+bias)  (reference: heads.MoCoProjectionHead(512, 2048,
+    128), scripts/WM811k_benchmark.py:298)."""
+
+    def __init__(self, input_dim: int = 2048, hidden_dim: int = 2048, output_dim: int = 128):
+        super().__init__([(input_dim, hidden_dim, None, hnn.ReLU()), (hidden_dim, output_dim, None, None)])
 
 
 class DINOProjectionHead(ProjectionHead):

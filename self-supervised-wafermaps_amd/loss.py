@@ -51,25 +51,82 @@ class _NTXentCore(torch.autograd.Function):
         return dzn * grad_out, None, None, None
 
 
-class NTXentLoss(nn.Module):
-    """Contrastive cross-entropy over all pairs of the two views' batches (SimCLR).
+class _NTXentBank(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, bank, temperature):
+        from . import _lib
+        from ._lib import check, ptr, stream_ptr
 
-    Same constructor and call as lightly.loss.NTXentLoss.  The MoCo memory-bank variant
-    (memory_bank_size > 0) is not built yet and fails loudly."""
+        b, d = q.shape
+        loss = torch.zeros(1, dtype=torch.float32, device=q.device)
+        dq, dk = torch.empty_like(q), torch.empty_like(k)
+        check(_lib.load().wm_ntxent_bank_fwd_bwd(ptr(q), ptr(k), ptr(bank), b, d, bank.shape[1], temperature, ptr(loss),
+                                                 ptr(dq), ptr(dk), stream_ptr()), "wm_ntxent_bank_fwd_bwd")
+        ctx.save_for_backward(dq, dk)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dq, dk = ctx.saved_tensors
+        return dq * g, dk * g, None, None
+
+
+class NTXentLoss(nn.Module):
+    """Contrastive cross-entropy (lightly.loss.NTXentLoss: same constructor and call).
+
+    memory_bank_size = 0 (SimCLR): all pairs of the two views' batches, optionally gathered across
+    ranks.  memory_bank_size > 0 (MoCo): logits [<out0, out1>, out0 . bank] / T with label 0; the bank is
+    lightly's [dim, size] FIFO of L2-normalised `out1` rows, initialised with normalised Gaussian
+    columns on first use and updated AFTER the negatives for this call were taken, only when out0
+    requires grad."""
 
     def __init__(self, temperature: float = 0.5, memory_bank_size: int = 0, gather_distributed: bool = False):
         super().__init__()
         if abs(temperature) < 1e-8:
             raise ValueError(f"Illegal temperature: abs({temperature}) < 1e-8")
-        if memory_bank_size:
-            raise NotImplementedError("NTXentLoss with a memory bank (MoCo) has no HIP path yet")
+        if memory_bank_size < 0:
+            raise ValueError(f"Illegal memory bank size {memory_bank_size}")
         self.temperature = float(temperature)
         self.gather_distributed = bool(gather_distributed)
+        self.size = int(memory_bank_size)
+        self.register_buffer("bank", torch.empty(0, dtype=torch.float32), persistent=False)
+        self.register_buffer("bank_ptr", torch.zeros(1, dtype=torch.long), persistent=False)
+        self._ptr = 0  # host copy of bank_ptr (the enqueue offsets are host-side slicing)
+
+    @torch.no_grad()
+    def _init_memory_bank(self, dim: int, device) -> None:
+        bank = torch.randn(dim, self.size, device=device)
+        self.bank = torch.nn.functional.normalize(bank, dim=0).contiguous()
+        self.bank_ptr = torch.zeros(1, dtype=torch.long, device=device)
+        self._ptr = 0
+
+    @torch.no_grad()
+    def _dequeue_and_enqueue(self, batch: torch.Tensor) -> None:
+        b = batch.shape[0]
+        ptr_ = self._ptr
+        if ptr_ + b >= self.size:
+            self.bank[:, ptr_:] = batch[: self.size - ptr_].T
+            self._ptr = 0
+        else:
+            self.bank[:, ptr_:ptr_ + b] = batch.T
+            self._ptr = ptr_ + b
+        self.bank_ptr[0] = self._ptr
 
     def forward(self, out0: torch.Tensor, out1: torch.Tensor) -> torch.Tensor:
         if out0.shape != out1.shape or out0.dim() != 2:
             raise ValueError("NTXentLoss expects two [batch, dim] tensors of equal shape")
         b = out0.shape[0]
+        if self.size > 0:
+            if self.gather_distributed and _world() > 1:
+                raise NotImplementedError("NTXentLoss: memory bank with gather_distributed is not built")
+            q = F_hip.l2_normalize(out0.float().contiguous())
+            k = F_hip.l2_normalize(out1.float().contiguous())
+            if self.bank.numel() == 0 or self.bank.shape[0] != q.shape[1] or self.bank.device != q.device:
+                self._init_memory_bank(q.shape[1], q.device)
+            loss = _NTXentBank.apply(q, k, self.bank, self.temperature)  # the kernel has read the bank ...
+            if out0.requires_grad:
+                self._dequeue_and_enqueue(k.detach())                     # ... before this call's keys enter it
+            return loss
         z = torch.cat([out0, out1], dim=0).float().contiguous()
         zn = F_hip.l2_normalize(z)
         return _NTXentCore.apply(zn, b, self.temperature, self.gather_distributed)

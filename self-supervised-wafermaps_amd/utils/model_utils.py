@@ -136,3 +136,19 @@ def set_at_index(tokens: torch.Tensor, index: torch.Tensor, value: torch.Tensor)
 def mask_at_index(tokens: torch.Tensor, index: torch.Tensor, mask_token: torch.Tensor) -> torch.Tensor:
     b, k = index.shape
     return set_at_index(tokens, index, mask_token.to(tokens.dtype).expand(b, k, tokens.shape[2]))
+
+
+def batch_shuffle(batch: torch.Tensor, distributed: bool = False):
+    """lightly.models.utils.batch_shuffle: random permutation of the batch dimension (MoCo's guard against
+    BatchNorm leaking the positive pair across GPUs).  Returns (shuffled batch, permutation)."""
+    if distributed:
+        raise NotImplementedError("batch_shuffle(distributed=True) is not built (the reference runs single-GPU)")
+    shuffle = torch.randperm(batch.shape[0], device=batch.device)
+    return batch[shuffle], shuffle
+
+
+def batch_unshuffle(batch: torch.Tensor, shuffle: torch.Tensor, distributed: bool = False):
+    if distributed:
+        raise NotImplementedError("batch_unshuffle(distributed=True) is not built")
+    unshuffle = torch.argsort(shuffle)
+    return batch[unshuffle]

@@ -16,7 +16,7 @@ from . import _lib, ops
 from ._lib import check, ptr, stream_ptr
 from .ops import _arena_grad, _need_cuda
 
-ACT_NONE, ACT_GELU = 0, 1
+ACT_NONE, ACT_GELU, ACT_RELU = 0, 1, 2
 
 
 def _bf16_rows(x: torch.Tensor) -> torch.Tensor:

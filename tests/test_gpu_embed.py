@@ -275,3 +275,36 @@ def test_embed_dataset_runs_the_eval_backbone():
     assert model.training  # mode restored
     again = embed_dataset(model, WaferLoader(ds, 25), out_dtype=None)
     assert torch.allclose(again.float(), feats.float(), atol=2e-2, rtol=2e-2)  # batch size does not matter in eval
+
+
+def test_ntxent_memory_bank_matches_oracle_and_enqueues_like_lightly():
+    from ssl_wafermap_amd.loss import NTXentLoss
+
+    g = torch.Generator().manual_seed(3)
+    b, d, k = 48, 128, 200
+    crit = NTXentLoss(temperature=0.1, memory_bank_size=k).to("cuda:0")
+    ref_bank, ref_ptr = None, 0
+    for step in range(6):  # 6 x 48 = 288 > 200: exercises the wrap-around
+        out0 = torch.randn(b, d, generator=g)
+        out1 = out0 + 0.3 * torch.randn(b, d, generator=g)
+        o0 = out0.to("cuda:0").requires_grad_(True)
+        o1 = out1.to("cuda:0").requires_grad_(True)
+        if ref_bank is None:
+            crit._init_memory_bank(d, torch.device("cuda:0"))
+            ref_bank = crit.bank.cpu().clone()
+        loss = crit(o0, o1)
+        loss.backward()
+        r0, r1 = out0.clone().requires_grad_(True), out1.clone().requires_grad_(True)
+        ref = on.ntxent_memory_bank(r0, r1, ref_bank, 0.1)
+        ref.backward()
+        assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach())), (step, float(loss), float(ref))
+        assert torch.allclose(o0.grad.cpu(), r0.grad, rtol=1e-4, atol=1e-7)
+        assert torch.allclose(o1.grad.cpu(), r1.grad, rtol=1e-4, atol=1e-7)
+        ref_ptr = on.memory_bank_enqueue(ref_bank, ref_ptr, torch.nn.functional.normalize(out1, dim=1))
+        assert int(crit.bank_ptr) == ref_ptr
+        assert torch.allclose(crit.bank.cpu(), ref_bank, atol=1e-6)
+    # no gradient on out0 -> lightly leaves the bank alone
+    before = crit.bank.clone()
+    with torch.no_grad():
+        crit(torch.randn(b, d, generator=g).to("cuda:0"), torch.randn(b, d, generator=g).to("cuda:0"))
+    assert torch.equal(before, crit.bank)

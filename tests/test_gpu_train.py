@@ -128,3 +128,64 @@ def test_graphed_step_matches_eager():
     eager, graphed = run(False), run(True)
     assert all(np.isfinite(eager)) and all(np.isfinite(graphed))
     np.testing.assert_allclose(graphed, eager, rtol=5e-2)
+
+
+def test_moco_step_matches_oracle_and_keeps_the_bank_order():
+    """MoCo (reference scripts/WM811k_benchmark.py:289-351) on identical weights: symmetric loss against
+    the float32 oracle, momentum encoders moved by the EMA, the bank holding the first term's keys
+    before the second term reads it, and a falling loss under SGD."""
+    import math
+
+    from oracle import ntxent as ont
+    from oracle import resnet as orn
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models import MoCo
+
+    torch.manual_seed(0)
+    b = 16
+    model = MoCo(None, 9, batch_size=b, memory_bank_size=256, log_rep_std=False).to(DEV).train()
+    (opt,), _ = model.configure_optimizers()
+    g = torch.Generator().manual_seed(1)
+    x0 = torch.randn(b, 3, 224, 224, generator=g).bfloat16().float()
+    x1 = (x0 + 0.5 * torch.randn(b, 3, 224, 224, generator=g)).bfloat16().float()
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    model.criterion._init_memory_bank(128, torch.device(DEV))
+    bank = model.criterion.bank.cpu().clone()
+
+    # oracle: EMA first (teacher == student at init, so it is a no-op), then the two terms in order
+    def enc(x, bb, hd):
+        f = orn.resnet18_features(x, sd, True, prefix=bb + ".")
+        return orn.moco_head(f, sd, prefix=hd + ".")
+
+    q0, q1 = enc(x0, "backbone", "projection_head"), enc(x1, "backbone", "projection_head")
+    with torch.no_grad():
+        k1, k0 = enc(x1, "backbone_momentum", "projection_head_momentum"), enc(x0, "backbone_momentum", "projection_head_momentum")
+    l1 = ont.ntxent_memory_bank(q0, k1, bank, 0.1)
+    ptr = ont.memory_bank_enqueue(bank, 0, torch.nn.functional.normalize(k1, dim=1))
+    l2 = ont.ntxent_memory_bank(q1, k0, bank, 0.1)
+    ont.memory_bank_enqueue(bank, ptr, torch.nn.functional.normalize(k0, dim=1))
+    ref = 0.5 * (l1 + l2)
+
+    batch = ((ops.to_nhwc_bf16(x0.to(DEV)), ops.to_nhwc_bf16(x1.to(DEV))), None)
+    opt.zero_grad()
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref)) <= 2e-2 * abs(float(ref)), (float(loss), float(ref))
+    assert int(model.criterion.bank_ptr) == 2 * b
+    got_bank = model.criterion.bank.cpu()
+    cos = torch.nn.functional.cosine_similarity(got_bank[:, :2 * b].T, bank[:, :2 * b].T, dim=1)
+    assert float(cos.min()) > 0.995  # bf16 encoder vs float32 oracle keys, in the same slots and order
+    assert torch.equal(got_bank[:, 2 * b:], bank[:, 2 * b:])
+    # a few more steps (the same batch re-enters the bank as negatives, so the loss need not fall): the
+    # optimiser moves the query encoder and the momentum encoder follows it by the EMA
+    w0 = model.backbone.conv1.weight.detach().clone()
+    m0 = model.backbone_momentum.conv1.weight.detach().clone()
+    for i in range(4):
+        opt.step()
+        opt.zero_grad()
+        loss = model.training_step(batch, i + 1)
+        loss.backward()
+    assert math.isfinite(float(loss.detach()))
+    dw = (model.backbone.conv1.weight.detach() - w0).abs().max()
+    dm = (model.backbone_momentum.conv1.weight.detach() - m0).abs().max()
+    assert float(dw) > 0 and 0 < float(dm) < float(dw)

@@ -53,7 +53,8 @@ def test_layer_norm(rows, c):
 
 
 @pytest.mark.parametrize("rows,c,act,res", [(197, 384, 0, True), (300, 1536, 1, False), (64, 1152, 0, False),
-                                            (50, 3072, 1, False), (33, 8, 1, True)])
+                                            (50, 3072, 1, False), (33, 8, 1, True), (256, 2048, 2, False),
+                                            (70, 512, 2, True)])
 def test_bias_act(rows, c, act, res):
     from ssl_wafermap_amd import vit_ops
 
@@ -64,8 +65,10 @@ def test_bias_act(rows, c, act, res):
     dy = _bf(torch.randn(rows, c, generator=g))
     xr, br = x.clone().requires_grad_(True), b.clone().requires_grad_(True)
     ref = xr + br
-    if act:
+    if act == 1:
         ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.relu(ref)
     if res:
         rr = r.clone().requires_grad_(True)
         ref = ref + rr

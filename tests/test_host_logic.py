@@ -118,8 +118,10 @@ def test_ntxent_constructor_checks_and_scheduler():
 
     with pytest.raises(ValueError):
         NTXentLoss(temperature=0.0)
-    with pytest.raises(NotImplementedError):
-        NTXentLoss(memory_bank_size=4096)
+    with pytest.raises(ValueError):
+        NTXentLoss(memory_bank_size=-1)
+    crit = NTXentLoss(temperature=0.1, memory_bank_size=4096)
+    assert crit.size == 4096 and crit.bank.numel() == 0  # the bank is created on first use (lightly)
     assert cosine_warmup_factor(0, 20, 150) == pytest.approx(1 / 20)
     assert cosine_warmup_factor(19, 20, 150) == pytest.approx(1.0)
     assert cosine_warmup_factor(20, 20, 150) == pytest.approx(1.0)
