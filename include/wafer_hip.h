@@ -285,6 +285,12 @@ int wm_gap_bwd(const void* dy, int N, int HW, int C, void* dx, void* stream);
 int wm_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, const float* hyper,
                 void* stream);
 
+/* lightly.loss.NegativeCosineSimilarity (BYOL, SimSiam: scripts/WM811k_benchmark.py:446,613):
+ * loss[0] += -mean_i cos(x0_i, x1_i) (zero it first; norms clamped at eps as torch.cosine_similarity does);
+ * dx0 / dx1 [B][D] float32 gradients, either may be NULL.  x0, x1: WM_F32 or WM_BF16 [B][D]. */
+int wm_neg_cosine_fwd_bwd(const void* x0, const void* x1, int dtype, int B, int D, float eps, float* loss, float* dx0,
+                          float* dx1, void* stream);
+
 /* NT-Xent against a memory bank (lightly NTXentLoss(memory_bank_size > 0), the reference's MoCo:
  * scripts/WM811k_benchmark.py:305-307).  q, kpos: L2-normalised [B][D] float32; bank [D][K] float32
  * (lightly's layout, one stored key per column).  logits_i = [<q_i,kpos_i>, <q_i,bank>] / T, label 0.

@@ -79,3 +79,30 @@ def moco_head(f, sd, prefix="projection_head."):
     """lightly MoCoProjectionHead: Linear(+bias)-ReLU, Linear(+bias) (layers.0, layers.2)."""
     x = F.relu(F.linear(f, sd[prefix + "layers.0.weight"], sd[prefix + "layers.0.bias"]))
     return F.linear(x, sd[prefix + "layers.2.weight"], sd[prefix + "layers.2.bias"])
+
+
+def _bn1d(x, sd, key, training, groups=1, relu=False, momentum=0.1, eps=1e-5):
+    """BatchNorm1d with statistics per view group (what per-view forward calls compute); affine
+    parameters are optional (lightly's SimSiam projection head ends with BatchNorm1d(affine=False))."""
+    w, b = sd.get(key + ".weight"), sd.get(key + ".bias")
+    parts = [F.batch_norm(p, sd[key + ".running_mean"], sd[key + ".running_var"], w, b, training, momentum, eps)
+             for p in x.chunk(groups)]
+    y = torch.cat(parts)
+    return F.relu(y) if relu else y
+
+
+def byol_head(f, sd, prefix, training=True, groups=1):
+    """lightly BYOLProjectionHead / BYOLPredictionHead: Linear-BN-ReLU (layers.0-2), Linear+bias (layers.3)."""
+    x = _bn1d(F.linear(f, sd[prefix + "layers.0.weight"]), sd, prefix + "layers.1", training, groups, relu=True)
+    return F.linear(x, sd[prefix + "layers.3.weight"], sd[prefix + "layers.3.bias"])
+
+
+def simsiam_projection_head(f, sd, prefix="projection_head.", training=True, groups=1):
+    """(Linear-BN-ReLU) x2 (layers.0-5), Linear-BN(affine=False) (layers.6-7)."""
+    x = _bn1d(F.linear(f, sd[prefix + "layers.0.weight"]), sd, prefix + "layers.1", training, groups, relu=True)
+    x = _bn1d(F.linear(x, sd[prefix + "layers.3.weight"]), sd, prefix + "layers.4", training, groups, relu=True)
+    return _bn1d(F.linear(x, sd[prefix + "layers.6.weight"]), sd, prefix + "layers.7", training, groups)
+
+
+def neg_cosine(x0, x1, eps=1e-8):
+    return -F.cosine_similarity(x0, x1, dim=1, eps=eps).mean()

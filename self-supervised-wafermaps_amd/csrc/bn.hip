@@ -595,9 +595,103 @@ inline void launch_bn_apply(const void* y, const void* residual, const float* sc
         static_cast<uint16_t*>(out));
 }
 
+// ---- wide, short matrices (projection heads: C > 2048, a few hundred rows): one thread per channel walks
+// the rows of every statistics group (coalesced across channels); the whole BatchNorm is one launch.
+constexpr int BN_WIDE_MAX_C = 16384;
+
+__global__ __launch_bounds__(BN_THREADS) void bn_col_fwd(const uint16_t* __restrict__ y, const uint16_t* __restrict__ res,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         float* __restrict__ rmean, float* __restrict__ rvar, int rpg,
+                                                         int C, int G, float eps, float momentum, int relu, int training,
+                                                         float* __restrict__ save_mean, float* __restrict__ save_invstd,
+                                                         uint16_t* __restrict__ out) {
+  const int c = blockIdx.x * BN_THREADS + threadIdx.x;
+  if (c >= C) return;
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  for (int g = 0; g < G; ++g) {
+    const size_t base = (size_t)g * rpg;
+    float mu, is;
+    if (training) {
+      float s = 0.f;
+      for (int r = 0; r < rpg; ++r) s += bf2f(y[(base + r) * C + c]);
+      mu = s / (float)rpg;
+      float q = 0.f;
+      for (int r = 0; r < rpg; ++r) {
+        const float d = bf2f(y[(base + r) * C + c]) - mu;
+        q = fmaf(d, d, q);
+      }
+      const float var = q / (float)rpg;
+      is = rsqrtf(var + eps);
+      save_mean[(size_t)g * C + c] = mu;
+      save_invstd[(size_t)g * C + c] = is;
+      if (rmean) {
+        rmean[c] = (1.f - momentum) * rmean[c] + momentum * mu;
+        rvar[c] = (1.f - momentum) * rvar[c] + momentum * (rpg > 1 ? var * (float)rpg / (float)(rpg - 1) : var);
+      }
+    } else {
+      mu = rmean[c];
+      is = rsqrtf(rvar[c] + eps);
+    }
+    const float sc = ga * is, sh = be - mu * sc;
+    for (int r = 0; r < rpg; ++r) {
+      const size_t o = (base + r) * C + c;
+      float v = fmaf(bf2f(y[o]), sc, sh);
+      if (res) v += bf2f(res[o]);
+      if (relu) v = fmaxf(v, 0.f);
+      out[o] = f2bf(v);
+    }
+  }
+}
+
+__global__ __launch_bounds__(BN_THREADS) void bn_col_bwd(const uint16_t* __restrict__ y, const uint16_t* __restrict__ dout,
+                                                         const uint16_t* __restrict__ out_relu, int remask,
+                                                         const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                         int rpg, int C, int G, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta, int accumulate,
+                                                         uint16_t* __restrict__ dy, uint16_t* __restrict__ dz) {
+  const int c = blockIdx.x * BN_THREADS + threadIdx.x;
+  if (c >= C) return;
+  const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
+  float dg = 0.f, db = 0.f;
+  for (int g = 0; g < G; ++g) {
+    const size_t base = (size_t)g * rpg;
+    const float mu = mean[(size_t)g * C + c], is = invstd[(size_t)g * C + c];
+    const float sc = ga * is, sh = be - mu * sc;
+    float s1 = 0.f, s2 = 0.f;
+    for (int r = 0; r < rpg; ++r) {
+      const size_t o = (base + r) * C + c;
+      const float yv = bf2f(y[o]);
+      float d = bf2f(dout[o]);
+      if (out_relu) d = bf2f(out_relu[o]) > 0.f ? d : 0.f;
+      else if (remask) d = bf2f(f2bf(fmaf(yv, sc, sh))) > 0.f ? d : 0.f;
+      s1 += d;
+      s2 = fmaf(d, (yv - mu) * is, s2);
+    }
+    dg += s2;
+    db += s1;
+    const float c1 = s1 / (float)rpg, c2 = s2 / (float)rpg;
+    for (int r = 0; r < rpg; ++r) {
+      const size_t o = (base + r) * C + c;
+      const float yv = bf2f(y[o]);
+      float d = bf2f(dout[o]);
+      if (out_relu) d = bf2f(out_relu[o]) > 0.f ? d : 0.f;
+      else if (remask) d = bf2f(f2bf(fmaf(yv, sc, sh))) > 0.f ? d : 0.f;
+      if (dz) dz[o] = f2bf(d);
+      dy[o] = f2bf(sc * (d - c1 - (yv - mu) * is * c2));
+    }
+  }
+  if (dgamma) dgamma[c] = accumulate ? dgamma[c] + dg : dg;
+  if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
+}
+
+inline bool bn_wide(long long rows, int C, int G) {
+  return C > 2048 && C <= BN_WIDE_MAX_C && rows / G <= 65536;
+}
+
 int bn_shape_check(long long rows, int C, int G) {
   WM_REQUIRE(rows > 0 && C > 0 && G > 0, WM_EINVAL);
-  WM_REQUIRE(C % 8 == 0 && C <= 2048, WM_EUNSUPPORTED);
+  WM_REQUIRE(C % 8 == 0 && (C <= 2048 || bn_wide(rows, C, G)), WM_EUNSUPPORTED);
   WM_REQUIRE(rows % G == 0 && rows / G < (1ll << 31), WM_EUNSUPPORTED);
   return WM_OK;
 }
@@ -622,6 +716,13 @@ extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float*
   WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rpg = (int)(rows / G);
+  if (bn_wide(rows, C, G)) {
+    bn_col_fwd<<<wm_cdiv(C, BN_THREADS), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(residual), gamma, beta, running_mean, running_var,
+        rpg, C, G, eps, momentum, relu, 1, save_mean, save_invstd, static_cast<uint16_t*>(out));
+    WM_LAUNCH_CHECK();
+    return WM_OK;
+  }
   const int nblk = reduce_blocks(rpg, C);
   float* part = static_cast<float*>(workspace);
   float* scale = part + (size_t)G * nblk * 2 * C;  // reuse the coefficient planes: scale, shift
@@ -716,6 +817,14 @@ extern "C" int wm_bn_eval_fwd(const void* y, const void* residual, const float* 
   if (rc != WM_OK) return rc;
   WM_REQUIRE(workspace_bytes >= (size_t)2 * C * sizeof(float), WM_EWORKSPACE);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (bn_wide(rows, C, 1)) {
+    bn_col_fwd<<<wm_cdiv(C, BN_THREADS), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(residual), gamma, beta,
+        const_cast<float*>(running_mean), const_cast<float*>(running_var), (int)rows, C, 1, eps, 0.f, relu, 0, nullptr,
+        nullptr, static_cast<uint16_t*>(out));
+    WM_LAUNCH_CHECK();
+    return WM_OK;
+  }
   float* scale = static_cast<float*>(workspace);
   float* shift = scale + C;
   bn_eval_params<<<1, C < 1024 ? ((C + 63) / 64) * 64 : 1024, 0, st>>>(gamma, beta, running_mean, running_var, eps,
@@ -769,6 +878,16 @@ static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, in
   WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rpg = (int)(rows / G);
+  if (bn_wide(rows, C, G)) {
+    WM_REQUIRE(ps.dy == nullptr && dout, WM_EUNSUPPORTED);
+    const bool rm = relu_from_y && !out_relu;
+    bn_col_bwd<<<wm_cdiv(C, BN_THREADS), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
+        rm ? 1 : 0, gamma, beta, save_mean, save_invstd, rpg, C, G, dgamma, dbeta, accumulate, static_cast<uint16_t*>(dy),
+        static_cast<uint16_t*>(dz));
+    WM_LAUNCH_CHECK();
+    return WM_OK;
+  }
   const int nblk = reduce_blocks(rpg, C);
   float* part = static_cast<float*>(workspace);
   float* coef = part + (size_t)G * nblk * 2 * C;

@@ -405,3 +405,63 @@ extern "C" int wm_ntxent_bank_fwd_bwd(const float* q, const float* kpos, const f
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
+
+// ------------------------------------------------------------------------------------ -cos
+// lightly.loss.NegativeCosineSimilarity (BYOL / SimSiam in the reference, scripts/WM811k_benchmark.py:
+// 446,613): loss = -mean_i cos(x0_i, x1_i) with torch's cosine_similarity (each norm clamped at eps).
+// One wave per row; x bf16 or f32 [B][D]; gradients f32, either may be NULL (SimSiam detaches z).
+namespace {
+template <typename T>
+__device__ __forceinline__ float nc_ld(const T* p, size_t i);
+template <>
+__device__ __forceinline__ float nc_ld<float>(const float* p, size_t i) { return p[i]; }
+template <>
+__device__ __forceinline__ float nc_ld<uint16_t>(const uint16_t* p, size_t i) { return bf2f(p[i]); }
+
+template <typename T>
+__global__ __launch_bounds__(256) void neg_cosine_kernel(const T* __restrict__ x0, const T* __restrict__ x1, int B, int D,
+                                                         float eps, float* __restrict__ loss, float* __restrict__ d0,
+                                                         float* __restrict__ d1) {
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float dot = 0.f, n0 = 0.f, n1 = 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float a = nc_ld<T>(x0, (size_t)row * D + d), b = nc_ld<T>(x1, (size_t)row * D + d);
+    dot = fmaf(a, b, dot);
+    n0 = fmaf(a, a, n0);
+    n1 = fmaf(b, b, n1);
+  }
+  dot = wave_sum(dot);
+  n0 = wave_sum(n0);
+  n1 = wave_sum(n1);
+  const float l0 = sqrtf(n0), l1 = sqrtf(n1);
+  const float c0 = fmaxf(l0, eps), c1 = fmaxf(l1, eps);
+  const float cosv = dot / (c0 * c1);
+  if (lane == 0) atomicAdd(loss, -cosv / (float)B);
+  // d(-cos/B)/dx0 = -(x1 / (c0 c1) - cos x0 / c0^2 [if l0 > eps]) / B
+  const float w = -1.f / (float)B, inv = 1.f / (c0 * c1);
+  const float k0 = l0 > eps ? cosv / (c0 * c0) : 0.f, k1 = l1 > eps ? cosv / (c1 * c1) : 0.f;
+  for (int d = lane; d < D; d += 64) {
+    const float a = nc_ld<T>(x0, (size_t)row * D + d), b = nc_ld<T>(x1, (size_t)row * D + d);
+    if (d0) d0[(size_t)row * D + d] = w * (b * inv - k0 * a);
+    if (d1) d1[(size_t)row * D + d] = w * (a * inv - k1 * b);
+  }
+}
+}  // namespace
+
+extern "C" int wm_neg_cosine_fwd_bwd(const void* x0, const void* x1, int dtype, int B, int D, float eps, float* loss,
+                                     float* dx0, float* dx1, void* stream) {
+  WM_REQUIRE(x0 && x1 && loss, WM_EINVAL);
+  WM_REQUIRE(B > 0 && D > 0 && eps >= 0.f, WM_EINVAL);
+  WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == WM_F32)
+    neg_cosine_kernel<float><<<wm_cdiv(B, 4), 256, 0, st>>>(static_cast<const float*>(x0), static_cast<const float*>(x1), B,
+                                                            D, eps, loss, dx0, dx1);
+  else
+    neg_cosine_kernel<uint16_t><<<wm_cdiv(B, 4), 256, 0, st>>>(static_cast<const uint16_t*>(x0),
+                                                               static_cast<const uint16_t*>(x1), B, D, eps, loss, dx0, dx1);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

@@ -76,6 +76,35 @@ class MoCoProjectionHead(ProjectionHead):
         super().__init__([(input_dim, hidden_dim, None, hnn.ReLU()), (hidden_dim, output_dim, None, None)])
 
 
+class BYOLProjectionHead(ProjectionHead):
+    """lightly BYOLProjectionHead: Linear-BN-ReLU, Linear(+bias) (reference: (512, 4096, 256), :437)."""
+
+    def __init__(self, input_dim: int = 2048, hidden_dim: int = 4096, output_dim: int = 256):
+        super().__init__([(input_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.ReLU()),
+                          (hidden_dim, output_dim, None, None)])
+
+
+class BYOLPredictionHead(BYOLProjectionHead):
+    """lightly BYOLPredictionHead: same form (reference: (256, 4096, 256), :438)."""
+
+
+class SimSiamProjectionHead(ProjectionHead):
+    """lightly SimSiamProjectionHead: (Linear-BN-ReLU) x2, Linear-BN(affine=False) (reference: (512, 2048, 2048), :611)."""
+
+    def __init__(self, input_dim: int = 2048, hidden_dim: int = 2048, output_dim: int = 2048):
+        super().__init__([(input_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.ReLU()),
+                          (hidden_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.ReLU()),
+                          (hidden_dim, output_dim, hnn.BatchNorm1d(output_dim, affine=False), None)])
+
+
+class SimSiamPredictionHead(ProjectionHead):
+    """lightly SimSiamPredictionHead: Linear-BN-ReLU, Linear(+bias) (reference: (2048, 512, 2048), :612)."""
+
+    def __init__(self, input_dim: int = 2048, hidden_dim: int = 512, output_dim: int = 2048):
+        super().__init__([(input_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.ReLU()),
+                          (hidden_dim, output_dim, None, None)])
+
+
 class DINOProjectionHead(ProjectionHead):
     """lightly.models.modules.heads.DINOProjectionHead (reference: scripts/WM811k_benchmark.py:553-559,
     MixedWM38_pretrain.py:146-152): Linear-[BN]-GELU x2, Linear -> bottleneck, L2-normalise,

@@ -71,6 +71,49 @@ class _NTXentBank(torch.autograd.Function):
         return dq * g, dk * g, None, None
 
 
+class _NegCosine(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x0, x1, eps):
+        from . import _lib
+        from ._lib import check, dtype_code, ptr, stream_ptr
+
+        if x0.dtype != x1.dtype or x0.dtype not in (torch.float32, torch.bfloat16):
+            x0, x1 = x0.float(), x1.float()
+        x0, x1 = x0.contiguous(), x1.contiguous()
+        b, d = x0.shape
+        loss = torch.zeros(1, dtype=torch.float32, device=x0.device)
+        need0, need1 = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        d0 = torch.empty((b, d), dtype=torch.float32, device=x0.device) if need0 else None
+        d1 = torch.empty((b, d), dtype=torch.float32, device=x0.device) if need1 else None
+        check(_lib.load().wm_neg_cosine_fwd_bwd(ptr(x0), ptr(x1), dtype_code(x0), b, d, eps, ptr(loss), ptr(d0), ptr(d1),
+                                                stream_ptr()), "wm_neg_cosine_fwd_bwd")
+        ctx.save_for_backward(d0, d1)
+        ctx.dtypes = (x0.dtype, x1.dtype)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d0, d1 = ctx.saved_tensors
+        return (None if d0 is None else (d0 * g).to(ctx.dtypes[0]), None if d1 is None else (d1 * g).to(ctx.dtypes[1]),
+                None)
+
+
+class NegativeCosineSimilarity(nn.Module):
+    """lightly.loss.NegativeCosineSimilarity (BYOL / SimSiam in the reference, scripts/WM811k_benchmark.py:446,613):
+    -mean(cosine_similarity(x0, x1, dim, eps)); dim must be the feature dim of [B, D] inputs."""
+
+    def __init__(self, dim: int = 1, eps: float = 1e-8):
+        super().__init__()
+        if dim != 1:
+            raise NotImplementedError("NegativeCosineSimilarity: only dim=1 of [batch, dim] inputs is built")
+        self.dim, self.eps = dim, float(eps)
+
+    def forward(self, x0: torch.Tensor, x1: torch.Tensor) -> torch.Tensor:
+        if x0.shape != x1.shape or x0.dim() != 2:
+            raise ValueError("NegativeCosineSimilarity expects two [batch, dim] tensors of equal shape")
+        return _NegCosine.apply(x0, x1, self.eps)
+
+
 class NTXentLoss(nn.Module):
     """Contrastive cross-entropy (lightly.loss.NTXentLoss: same constructor and call).
 

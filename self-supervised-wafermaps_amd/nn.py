@@ -36,11 +36,15 @@ class StemConv(Conv2d):
 
 
 class _BatchNorm(nn.Module):
-    def __init__(self, num_features, eps=1e-5, momentum=0.1):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True):
         super().__init__()
-        self.num_features, self.eps, self.momentum = num_features, eps, momentum
-        self.weight = nn.Parameter(torch.ones(num_features))
-        self.bias = nn.Parameter(torch.zeros(num_features))
+        self.num_features, self.eps, self.momentum, self.affine = num_features, eps, momentum, affine
+        if affine:
+            self.weight = nn.Parameter(torch.ones(num_features))
+            self.bias = nn.Parameter(torch.zeros(num_features))
+        else:  # constants that stay out of the state_dict, like torch's affine=False
+            self.register_buffer("weight", torch.ones(num_features), persistent=False)
+            self.register_buffer("bias", torch.zeros(num_features), persistent=False)
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))

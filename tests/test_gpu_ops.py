@@ -87,7 +87,8 @@ def test_stem_conv(n, hw):
 
 @pytest.mark.parametrize("shape,groups,relu,res", [((4, 64, 14, 14), 1, True, False), ((4, 128, 7, 7), 2, True, True),
                                                    ((6, 512, 3, 3), 2, False, False), ((64, 512), 2, True, False),
-                                                   ((32, 128), 1, False, False), ((2, 64, 112, 112), 1, True, False)])
+                                                   ((32, 128), 1, False, False), ((2, 64, 112, 112), 1, True, False),
+                                                   ((48, 4096), 2, True, False), ((40, 8192), 1, False, True)])
 def test_batch_norm_train(shape, groups, relu, res):
     from ssl_wafermap_amd import ops
 

@@ -189,3 +189,52 @@ def test_moco_step_matches_oracle_and_keeps_the_bank_order():
     dw = (model.backbone.conv1.weight.detach() - w0).abs().max()
     dm = (model.backbone_momentum.conv1.weight.detach() - m0).abs().max()
     assert float(dw) > 0 and 0 < float(dm) < float(dw)
+
+
+@pytest.mark.parametrize("name", ["simsiam", "byol"])
+def test_siamese_steps_match_oracle(name):
+    """SimSiam / BYOL (reference scripts/WM811k_benchmark.py:605-640, 429-488) on identical weights: loss
+    against the float32 oracle, then a few SGD steps stay finite and move the loss."""
+    import math
+
+    from oracle import resnet as orn
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models import BYOL, SimSiam
+
+    torch.manual_seed(0)
+    b = 16
+    model = (SimSiam(None, 9, log_rep_std=False) if name == "simsiam" else BYOL(None, 9, batch_size=b, log_rep_std=False))
+    model = model.to(DEV).train()
+    (opt,), _ = model.configure_optimizers()
+    g = torch.Generator().manual_seed(2)
+    x0 = torch.randn(b, 3, 224, 224, generator=g).bfloat16().float()
+    x1 = (x0 + 0.5 * torch.randn(b, 3, 224, 224, generator=g)).bfloat16().float()
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+
+    def feats(x, bb):
+        return orn.resnet18_features(x, sd, True, prefix=bb + ".")
+
+    if name == "simsiam":
+        z0 = orn.simsiam_projection_head(feats(x0, "backbone"), sd)
+        z1 = orn.simsiam_projection_head(feats(x1, "backbone"), sd)
+        p0, p1 = orn.byol_head(z0, sd, "prediction_head."), orn.byol_head(z1, sd, "prediction_head.")
+        ref = 0.5 * (orn.neg_cosine(z0.detach(), p1) + orn.neg_cosine(z1.detach(), p0))
+    else:
+        p0 = orn.byol_head(orn.byol_head(feats(x0, "backbone"), sd, "projection_head."), sd, "prediction_head.")
+        p1 = orn.byol_head(orn.byol_head(feats(x1, "backbone"), sd, "projection_head."), sd, "prediction_head.")
+        with torch.no_grad():
+            z0 = orn.byol_head(feats(x0, "backbone_momentum"), sd, "projection_head_momentum.")
+            z1 = orn.byol_head(feats(x1, "backbone_momentum"), sd, "projection_head_momentum.")
+        ref = 0.5 * (orn.neg_cosine(p0, z1) + orn.neg_cosine(p1, z0))
+    batch = ((ops.to_nhwc_bf16(x0.to(DEV)), ops.to_nhwc_bf16(x1.to(DEV))), None)
+    opt.zero_grad()
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref)) <= 2e-2 * abs(float(ref)) + 2e-3, (float(loss), float(ref))
+    first = float(loss.detach())
+    for i in range(6):
+        opt.step()
+        opt.zero_grad()
+        loss = model.training_step(batch, i + 1)
+        loss.backward()
+    assert math.isfinite(float(loss.detach())) and float(loss.detach()) < first  # -cos falls on a repeated batch
