@@ -285,6 +285,18 @@ int wm_gap_bwd(const void* dy, int N, int HW, int C, void* dx, void* stream);
 int wm_sgd_step(float* params, const float* grads, float* momentum_buf, long long n, const float* hyper,
                 void* stream);
 
+/* torch.nn.CrossEntropyLoss(weight) (= nll_loss(log_softmax)) for the supervised baseline and the linear probe
+ * (scripts/WM811k_benchmark.py:211-217; src/ssl_wafermap/models/evals.py:20): logits WM_F32 / WM_BF16 [B][C],
+ * labels int64 [B] (outside [0, C): ignored), weight [C] or NULL.  acc2[0] += sum w_y nll, acc2[1] += sum w_y
+ * (zero both first; loss = acc2[0] / acc2[1]); dlogits [B][C] f32 = w_y (softmax - onehot), to be divided by
+ * acc2[1] by the caller. */
+int wm_cross_entropy_fwd_bwd(const void* logits, int dtype, const long long* labels, const float* weight, int B, int C,
+                             float* acc2, float* dlogits, void* stream);
+/* torch.nn.BCEWithLogitsLoss(pos_weight) (multi-label linear probe, evals.py:93): target f32 [B][C], pos_weight [C]
+ * or NULL; loss[0] += mean (zero it first); dlogits [B][C] f32 = d loss / d logits. */
+int wm_bce_logits_fwd_bwd(const void* logits, int dtype, const float* target, const float* pos_weight, int B, int C,
+                          float* loss, float* dlogits, void* stream);
+
 /* lightly.loss.NegativeCosineSimilarity (BYOL, SimSiam: scripts/WM811k_benchmark.py:446,613):
  * loss[0] += -mean_i cos(x0_i, x1_i) (zero it first; norms clamped at eps as torch.cosine_similarity does);
  * dx0 / dx1 [B][D] float32 gradients, either may be NULL.  x0, x1: WM_F32 or WM_BF16 [B][D]. */

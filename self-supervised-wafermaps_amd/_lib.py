@@ -132,6 +132,8 @@ SIGNATURES = {
     "wm_gap_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_sgd_step": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),
     # ---- vision-transformer path
+    "wm_cross_entropy_fwd_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "wm_bce_logits_fwd_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "wm_neg_cosine_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
                                       c_void_p]),
     "wm_ntxent_bank_fwd_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p,

@@ -465,3 +465,94 @@ extern "C" int wm_neg_cosine_fwd_bwd(const void* x0, const void* x1, int dtype, 
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
+
+// ------------------------------------------------------------------------------------ classification
+// torch.nn.CrossEntropyLoss(weight=w) / F.nll_loss(log_softmax) and torch.nn.BCEWithLogitsLoss(pos_weight) as the
+// reference's supervised baseline and linear probes use them (scripts/WM811k_benchmark.py:211-217;
+// src/ssl_wafermap/models/evals.py:20,93).  Logits float32 or bf16 [B][C] compact; gradients float32.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void cross_entropy_kernel(const T* __restrict__ logits, const long long* __restrict__ labels,
+                                                            const float* __restrict__ weight, int B, int C,
+                                                            float* __restrict__ acc, float* __restrict__ dlogits) {
+  // acc[0] += w_y * nll, acc[1] += w_y (the weighted mean divides the two; gradients are scaled later)
+  const int lane = threadIdx.x & 63;
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= B) return;
+  float m = -INFINITY;
+  for (int c = lane; c < C; c += 64) m = fmaxf(m, nc_ld<T>(logits, (size_t)row * C + c));
+  m = wave_max(m);
+  float s = 0.f;
+  for (int c = lane; c < C; c += 64) s += expf(nc_ld<T>(logits, (size_t)row * C + c) - m);
+  s = wave_sum(s);
+  const float lse = m + logf(s);
+  const long long y = labels[row];
+  const bool valid = y >= 0 && y < C;
+  const float wy = valid ? (weight ? weight[y] : 1.f) : 0.f;
+  if (lane == 0 && valid) {
+    atomicAdd(acc, wy * (lse - nc_ld<T>(logits, (size_t)row * C + y)));
+    atomicAdd(acc + 1, wy);
+  }
+  for (int c = lane; c < C; c += 64) {
+    const float p = expf(nc_ld<T>(logits, (size_t)row * C + c) - lse);
+    dlogits[(size_t)row * C + c] = wy * (p - (c == y ? 1.f : 0.f));
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bce_logits_kernel(const T* __restrict__ logits, const float* __restrict__ target,
+                                                         const float* __restrict__ pos_weight, long long n, int C,
+                                                         float* __restrict__ loss, float* __restrict__ dlogits) {
+  __shared__ float red[4];
+  const float inv = 1.f / (float)n;
+  float s = 0.f;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const float x = nc_ld<T>(logits, (size_t)i), t = target[i];
+    const float pw = pos_weight ? pos_weight[i % C] : 1.f;
+    // loss = (1 - t) x + (1 + (pw - 1) t) softplus(-x)   (torch's stable form)
+    const float lw = 1.f + (pw - 1.f) * t;
+    const float sp = fmaxf(-x, 0.f) + log1pf(expf(-fabsf(x)));
+    s += (1.f - t) * x + lw * sp;
+    const float sig = 1.f / (1.f + expf(-x));
+    dlogits[i] = ((1.f - t) - lw * (1.f - sig)) * inv;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) * inv);
+}
+}  // namespace
+
+extern "C" int wm_cross_entropy_fwd_bwd(const void* logits, int dtype, const long long* labels, const float* weight,
+                                        int B, int C, float* acc2, float* dlogits, void* stream) {
+  WM_REQUIRE(logits && labels && acc2 && dlogits, WM_EINVAL);
+  WM_REQUIRE(B > 0 && C > 0, WM_EINVAL);
+  WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dtype == WM_F32)
+    cross_entropy_kernel<float><<<wm_cdiv(B, 4), 256, 0, st>>>(static_cast<const float*>(logits), labels, weight, B, C, acc2,
+                                                               dlogits);
+  else
+    cross_entropy_kernel<uint16_t><<<wm_cdiv(B, 4), 256, 0, st>>>(static_cast<const uint16_t*>(logits), labels, weight, B, C,
+                                                                  acc2, dlogits);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_bce_logits_fwd_bwd(const void* logits, int dtype, const float* target, const float* pos_weight, int B,
+                                     int C, float* loss, float* dlogits, void* stream) {
+  WM_REQUIRE(logits && target && loss && dlogits, WM_EINVAL);
+  WM_REQUIRE(B > 0 && C > 0, WM_EINVAL);
+  WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const long long n = (long long)B * C;
+  const int blocks = (int)((n + 255) / 256 > 1024 ? 1024 : (n + 255) / 256);
+  if (dtype == WM_F32)
+    bce_logits_kernel<float><<<blocks, 256, 0, st>>>(static_cast<const float*>(logits), target, pos_weight, n, C, loss,
+                                                     dlogits);
+  else
+    bce_logits_kernel<uint16_t><<<blocks, 256, 0, st>>>(static_cast<const uint16_t*>(logits), target, pos_weight, n, C, loss,
+                                                        dlogits);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

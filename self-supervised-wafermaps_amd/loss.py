@@ -71,6 +71,85 @@ class _NTXentBank(torch.autograd.Function):
         return dq * g, dk * g, None, None
 
 
+class _CrossEntropy(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels, weight):
+        from . import _lib
+        from ._lib import check, dtype_code, ptr, stream_ptr
+
+        if logits.dtype not in (torch.float32, torch.bfloat16):
+            logits = logits.float()
+        logits = logits.contiguous()
+        b, c = logits.shape
+        acc = torch.zeros(2, dtype=torch.float32, device=logits.device)
+        dl = torch.empty((b, c), dtype=torch.float32, device=logits.device)
+        check(_lib.load().wm_cross_entropy_fwd_bwd(ptr(logits), dtype_code(logits), ptr(labels.to(torch.int64).contiguous()),
+                                                   ptr(weight), b, c, ptr(acc), ptr(dl), stream_ptr()),
+              "wm_cross_entropy_fwd_bwd")
+        ctx.save_for_backward(dl, acc)
+        ctx.dtype = logits.dtype
+        return acc[0] / acc[1]
+
+    @staticmethod
+    def backward(ctx, g):
+        dl, acc = ctx.saved_tensors
+        return (dl * (g / acc[1])).to(ctx.dtype), None, None
+
+
+class CrossEntropyLoss(nn.Module):
+    """torch.nn.CrossEntropyLoss(weight=None, reduction="mean") on [B, C] logits and int64 labels (the
+    reference's linear probe, src/ssl_wafermap/models/evals.py:20; F.nll_loss(F.log_softmax(.)) in its
+    supervised baseline is the same function)."""
+
+    def __init__(self, weight: torch.Tensor = None):
+        super().__init__()
+        self.register_buffer("weight", None if weight is None else torch.as_tensor(weight, dtype=torch.float32).clone())
+
+    def forward(self, logits: torch.Tensor, labels: torch.Tensor) -> torch.Tensor:
+        if logits.dim() != 2 or labels.shape != logits.shape[:1]:
+            raise ValueError("CrossEntropyLoss expects [B, C] logits and [B] labels")
+        return _CrossEntropy.apply(logits, labels, self.weight)
+
+
+class _BCEWithLogits(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, target, pos_weight):
+        from . import _lib
+        from ._lib import check, dtype_code, ptr, stream_ptr
+
+        if logits.dtype not in (torch.float32, torch.bfloat16):
+            logits = logits.float()
+        logits = logits.contiguous()
+        b, c = logits.shape
+        loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
+        dl = torch.empty((b, c), dtype=torch.float32, device=logits.device)
+        check(_lib.load().wm_bce_logits_fwd_bwd(ptr(logits), dtype_code(logits), ptr(target.float().contiguous()),
+                                                ptr(pos_weight), b, c, ptr(loss), ptr(dl), stream_ptr()),
+              "wm_bce_logits_fwd_bwd")
+        ctx.save_for_backward(dl)
+        ctx.dtype = logits.dtype
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return (dl * g).to(ctx.dtype), None, None
+
+
+class BCEWithLogitsLoss(nn.Module):
+    """torch.nn.BCEWithLogitsLoss(pos_weight) (the multi-label probe on MixedWM38, evals.py:93)."""
+
+    def __init__(self, pos_weight: torch.Tensor = None):
+        super().__init__()
+        self.register_buffer("pos_weight",
+                             None if pos_weight is None else torch.as_tensor(pos_weight, dtype=torch.float32).clone())
+
+    def forward(self, logits: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        if logits.shape != target.shape or logits.dim() != 2:
+            raise ValueError("BCEWithLogitsLoss expects [B, C] logits and targets")
+        return _BCEWithLogits.apply(logits, target, self.pos_weight)
+
+
 class _NegCosine(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x0, x1, eps):

@@ -6,3 +6,4 @@ from .dino import DINOViT  # noqa: F401
 from .mae import MAE, MAEBackbone, MAEDecoder, masked_autoencoder, vit_b_32  # noqa: F401
 from .moco import MoCo  # noqa: F401
 from .siamese import BYOL, FastSiam, SimSiam  # noqa: F401
+from .evals import LinearClassifier, MultilabelLinearClassifier, SupervisedR18, fit_linear_probe  # noqa: F401

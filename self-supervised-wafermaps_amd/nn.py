@@ -95,6 +95,16 @@ class Linear(nn.Module):
             self.register_parameter("bias", None)
 
     def forward(self, x, act: int = vit_ops.ACT_NONE, residual=None):
+        if self.out_features % 64:
+            # classifier heads (9 / 8 outputs): the GEMM kernel works on 64-column tiles, so the weight is
+            # zero-padded to the next multiple and the logits sliced back (gradients flow through both)
+            if residual is not None:
+                raise NotImplementedError("Linear: residual with out_features % 64 != 0")
+            pad = 64 - self.out_features % 64
+            w = torch.cat([self.weight, self.weight.new_zeros(pad, self.in_features)], dim=0)
+            b = None if self.bias is None else torch.cat([self.bias, self.bias.new_zeros(pad)])
+            y = ops.linear(x, w) if b is None and act == vit_ops.ACT_NONE else vit_ops.linear(x, w, b, act, None)
+            return y[:, : self.out_features]
         if self.bias is None and act == vit_ops.ACT_NONE and residual is None:
             return ops.linear(x, self.weight)
         return vit_ops.linear(x, self.weight, self.bias, act, residual)

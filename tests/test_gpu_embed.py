@@ -334,3 +334,87 @@ def test_negative_cosine_similarity_matches_torch(dtype):
     NegativeCosineSimilarity()(b.to("cuda:0"), ad2).backward()
     assert torch.allclose(ad2.grad.cpu()[4:], br.grad[4:] * 0 + (-torch.autograd.grad(
         torch.nn.functional.cosine_similarity(b, ar, dim=1).mean(), ar)[0])[4:], atol=1e-6)
+
+
+def test_cross_entropy_and_bce_match_torch():
+    from ssl_wafermap_amd.loss import BCEWithLogitsLoss, CrossEntropyLoss
+
+    g = torch.Generator().manual_seed(11)
+    logits = torch.randn(70, 9, generator=g) * 3
+    labels = torch.randint(0, 9, (70,), generator=g)
+    w = torch.rand(9, generator=g) + 0.2
+    for weight in (None, w):
+        for dtype in (torch.float32, torch.bfloat16):
+            lr = logits.clone().to(dtype).float().requires_grad_(True)
+            ref = torch.nn.functional.cross_entropy(lr, labels, weight=weight)
+            ref.backward()
+            ld = logits.clone().to("cuda:0").to(dtype).requires_grad_(True)
+            crit = CrossEntropyLoss(weight=weight).to("cuda:0")
+            loss = crit(ld, labels.to("cuda:0"))
+            loss.backward()
+            assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-6 * abs(float(ref.detach())) + 1e-6
+            assert torch.allclose(ld.grad.float().cpu(), lr.grad, atol=1e-6 if dtype == torch.float32 else 1e-3)
+    target = (torch.rand(70, 8, generator=g) > 0.7).float()
+    ml = torch.randn(70, 8, generator=g) * 2
+    pw = torch.rand(8, generator=g) * 3 + 0.5
+    for pos_weight in (None, pw):
+        lr = ml.clone().requires_grad_(True)
+        ref = torch.nn.functional.binary_cross_entropy_with_logits(lr, target, pos_weight=pos_weight)
+        ref.backward()
+        ld = ml.to("cuda:0").requires_grad_(True)
+        loss = BCEWithLogitsLoss(pos_weight=pos_weight).to("cuda:0")(ld, target.to("cuda:0"))
+        loss.backward()
+        assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach()))
+        assert torch.allclose(ld.grad.cpu(), lr.grad, atol=1e-6, rtol=1e-4)
+
+
+def test_linear_probes_learn_separable_features():
+    """LinearClassifier / MultilabelLinearClassifier on frozen features, trained by the Adam loop."""
+    from ssl_wafermap_amd.models import LinearClassifier, MultilabelLinearClassifier, fit_linear_probe
+
+    g = torch.Generator().manual_seed(5)
+    centers = torch.randn(9, 512, generator=g) * 2
+    y = torch.randint(0, 9, (1800,), generator=g)
+    x = centers[y] + torch.randn(1800, 512, generator=g)
+    counts = torch.bincount(y, minlength=9).float()
+    clf = LinearClassifier(512, 9, weight=counts.sum() / (9 * counts)).to("cuda:0")
+    losses = fit_linear_probe(clf, x[:1500].to("cuda:0"), y[:1500].to("cuda:0"), epochs=6, batch_size=128)
+    assert losses[-1] < losses[0] * 0.5
+    m = clf.evaluate(x[1500:].to("cuda:0").bfloat16(), y[1500:].to("cuda:0"))
+    assert m["acc"] > 0.9 and m["f1"] > 0.9
+    wdir = torch.randn(8, 512, generator=g)
+    xm = torch.randn(1200, 512, generator=g)
+    ym = (xm @ wdir.T > 0.5).float()
+    mclf = MultilabelLinearClassifier(512, 8, pos_weight=(1 - ym.mean(0)) / ym.mean(0)).to("cuda:0")
+    before = mclf.evaluate(xm[1000:].to("cuda:0").bfloat16(), ym[1000:].to("cuda:0"))
+    losses = fit_linear_probe(mclf, xm[:1000].to("cuda:0"), ym[:1000].to("cuda:0"), epochs=30, batch_size=100)
+    assert losses[-1] < 0.7 * losses[0]
+    mm = mclf.evaluate(xm[1000:].to("cuda:0").bfloat16(), ym[1000:].to("cuda:0"))
+    assert mm["acc"] > before["acc"] + 0.1 and mm["f1"] > before["f1"]
+
+
+def test_supervised_r18_step_matches_oracle():
+    from oracle import resnet as orn
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models import SupervisedR18
+
+    torch.manual_seed(0)
+    model = SupervisedR18(None, 9, log_rep_std=False).to("cuda:0").train()
+    (opt,), _ = model.configure_optimizers()
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(16, 3, 224, 224, generator=g).bfloat16().float()
+    y = torch.randint(0, 9, (16,), generator=g)
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    f = orn.resnet18_features(x, sd, True, prefix="backbone.")
+    ref = torch.nn.functional.nll_loss(torch.log_softmax(torch.nn.functional.linear(f, sd["fc.weight"], sd["fc.bias"]), 1), y)
+    opt.zero_grad()
+    loss = model.training_step((ops.to_nhwc_bf16(x.to("cuda:0")), y.to("cuda:0")), 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref)) <= 2e-2 * abs(float(ref)), (float(loss), float(ref))
+    first = float(loss.detach())
+    for i in range(5):
+        opt.step()
+        opt.zero_grad()
+        loss = model.training_step((ops.to_nhwc_bf16(x.to("cuda:0")), y.to("cuda:0")), i + 1)
+        loss.backward()
+    assert float(loss.detach()) < first
