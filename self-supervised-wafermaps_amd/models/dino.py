@@ -74,14 +74,14 @@ class DINOViT(KNNBenchmarkModule):
         views = batch[0]
         b = views[0].shape[0]
         n_views = len(views)
-        with torch.no_grad():
+        with torch.no_grad(), ops.bn_groups(2):  # statistics per view wherever the networks have BatchNorm
             g = self._stack(views, 0, 2)
             yt = self.teacher_backbone(g).flatten(start_dim=1)
-            with ops.bn_groups(2):
-                teacher_out = self.teacher_head(yt)
+            teacher_out = self.teacher_head(yt)
         feats = []
         for i, j in self._group_by_size(views):
-            feats.append(self.backbone(self._stack(views, i, j)).flatten(start_dim=1))
+            with ops.bn_groups(j - i):
+                feats.append(self.backbone(self._stack(views, i, j)).flatten(start_dim=1))
         y = feats[0] if len(feats) == 1 else torch.cat(feats, dim=0)
         if self.log_rep_std:
             self.log("rep_std", debug.std_of_l2_normalized(y[-b:]))
@@ -96,3 +96,30 @@ class DINOViT(KNNBenchmarkModule):
         opt = optim.AdamW(param, lr=1.5e-4 * self.lr_factor, weight_decay=0.05, betas=(0.9, 0.95))
         cosine = scheduler.CosineWarmupScheduler(opt, self.warmup_epochs, self.max_epochs)
         return [opt], [cosine]
+
+
+class DINO(DINOViT):
+    """DINO on ResNet-18 (scripts/WM811k_benchmark.py:491-543): the same step with the convolutional
+    backbone (BatchNorm statistics per crop), SGD + cosine annealing instead of AdamW + warm-up."""
+
+    def __init__(self, dataloader_kNN=None, num_classes=9, batch_size: int = 64, max_epochs: int = 150,
+                 log_rep_std: bool = True, **kwargs):
+        from .resnet import create_model
+
+        KNNBenchmarkModule.__init__(self, dataloader_kNN, num_classes, **kwargs)
+        self.backbone = create_model("resnet18", num_classes=0, pretrained=False)
+        feature_dim = self.backbone.num_features
+        self.head = heads.DINOProjectionHead(feature_dim, 2048, 256, 2048, batch_norm=True)
+        self.teacher_backbone = copy.deepcopy(self.backbone)
+        self.teacher_head = heads.DINOProjectionHead(feature_dim, 2048, 256, 2048, batch_norm=True)
+        model_utils.deactivate_requires_grad(self.teacher_backbone)
+        model_utils.deactivate_requires_grad(self.teacher_head)
+        self.criterion = DINOLoss(output_dim=2048)
+        self.lr_factor = batch_size / 256
+        self.max_epochs = max_epochs
+        self.log_rep_std = log_rep_std
+
+    def configure_optimizers(self):
+        param = list(self.backbone.parameters()) + list(self.head.parameters())
+        opt = optim.SGD(param, lr=6e-2 * self.lr_factor, momentum=0.9, weight_decay=5e-4)
+        return [opt], [torch.optim.lr_scheduler.CosineAnnealingLR(opt, self.max_epochs)]

@@ -238,3 +238,31 @@ def test_siamese_steps_match_oracle(name):
         loss = model.training_step(batch, i + 1)
         loss.backward()
     assert math.isfinite(float(loss.detach())) and float(loss.detach()) < first  # -cos falls on a repeated batch
+
+
+def test_dino_resnet_step_matches_oracle():
+    """DINO on ResNet-18 (reference :491-543): 2 global + 2 local crops, BatchNorm statistics per crop."""
+    from oracle import resnet as orn
+    from oracle import vit as ov
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models import DINO
+
+    torch.manual_seed(0)
+    b = 8
+    model = DINO(None, 9, batch_size=b, log_rep_std=False).to(DEV).train()
+    (opt,), _ = model.configure_optimizers()
+    g = torch.Generator().manual_seed(3)
+    views = [torch.randn(b, 3, 224, 224, generator=g).bfloat16().float() for _ in range(2)] + \
+            [torch.randn(b, 3, 96, 96, generator=g).bfloat16().float() for _ in range(2)]
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+    t_hd = {k[len("teacher_head."):]: v for k, v in sd.items() if k.startswith("teacher_head.")}
+    s_hd = {k[len("head."):]: v for k, v in sd.items() if k.startswith("head.")}
+    with torch.no_grad():
+        t_out = [ov.dino_head(orn.resnet18_features(v, sd, True, prefix="teacher_backbone."), t_hd) for v in views[:2]]
+        s_out = [ov.dino_head(orn.resnet18_features(v, sd, True, prefix="backbone."), s_hd) for v in views]
+        ref, _ = ov.dino_loss(t_out, s_out, torch.zeros(1, 1, 2048), 0.04, 0.1)
+    opt.zero_grad()
+    loss = model.training_step(([ops.to_nhwc_bf16(v.to(DEV)) for v in views], None), 0)
+    loss.backward()
+    opt.step()
+    assert abs(float(loss.detach()) - float(ref)) <= 1e-2 * abs(float(ref)), (float(loss), float(ref))
