@@ -303,6 +303,15 @@ int wm_bce_logits_fwd_bwd(const void* logits, int dtype, const float* target, co
 int wm_neg_cosine_fwd_bwd(const void* x0, const void* x1, int dtype, int B, int D, float eps, float* loss, float* dx0,
                           float* dx1, void* stream);
 
+/* lightly.loss.DCLLoss / DCLWLoss (decoupled contrastive learning; the reference's DCLW model,
+ * scripts/WM811k_benchmark.py:258-287): z0, z1 L2-normalised [B][D] float32.  Per direction (a, b) and row i:
+ * -w_i <a_i,b_i>/T + lse_{k!=i} <a_i,a_k>/T + lse_{k!=i} <a_i,b_k>/T, averaged over rows and both directions;
+ * w_i = 1, or 2 - B softmax_i(<z0_i,z1_i>/sigma) when weighted.  loss[0] += the loss (zero it first);
+ * dz0, dz1 [B][D] gradients.  Workspace: wm_dcl_workspace_bytes(B). */
+size_t wm_dcl_workspace_bytes(int B);
+int wm_dcl_fwd_bwd(const float* z0, const float* z1, int B, int D, float temperature, float sigma, int weighted,
+                   float* loss, float* dz0, float* dz1, void* workspace, size_t workspace_bytes, void* stream);
+
 /* NT-Xent against a memory bank (lightly NTXentLoss(memory_bank_size > 0), the reference's MoCo:
  * scripts/WM811k_benchmark.py:305-307).  q, kpos: L2-normalised [B][D] float32; bank [D][K] float32
  * (lightly's layout, one stored key per column).  logits_i = [<q_i,kpos_i>, <q_i,bank>] / T, label 0.

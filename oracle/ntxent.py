@@ -71,3 +71,30 @@ def memory_bank_enqueue(bank, ptr, batch):
         return 0
     bank[:, ptr:ptr + b] = batch.T.detach()
     return ptr + b
+
+
+def dcl_loss(out0, out1, temperature=0.1, sigma=None):
+    """lightly DCLLoss (sigma None) / DCLWLoss (negative von Mises-Fisher weights, sigma 0.5), no gathering:
+    per direction -w <a_i,b_i>/T + logsumexp_{k!=i} <a_i,a_k>/T + logsumexp_{k!=i} <a_i,b_k>/T, mean over rows,
+    mean of the two directions.  Restated from the DCL paper (Yeh et al. 2021, arXiv:2110.06848, eq. 6-7) and
+    lightly's layout; PARITY UNPINNED upstream."""
+    out0 = F.normalize(out0, dim=1)
+    out1 = F.normalize(out1, dim=1)
+
+    def weights(a, b):
+        if sigma is None:
+            return 1.0
+        sim = torch.einsum("nm,nm->n", a.detach(), b.detach()) / sigma
+        return 2 - a.shape[0] * F.softmax(sim, dim=0)
+
+    def one(a, b):
+        n = a.shape[0]
+        sim_aa = a @ a.t() / temperature
+        sim_ab = a @ b.t() / temperature
+        positive = -sim_ab.diagonal() * weights(a, b)
+        eye = torch.eye(n, dtype=torch.bool, device=a.device)
+        neg_aa = torch.logsumexp(sim_aa[~eye].view(n, -1), dim=1)
+        neg_ab = torch.logsumexp(sim_ab[~eye].view(n, -1), dim=1)
+        return (positive + neg_aa + neg_ab).mean()
+
+    return 0.5 * (one(out0, out1) + one(out1, out0))

@@ -556,3 +556,128 @@ extern "C" int wm_bce_logits_fwd_bwd(const void* logits, int dtype, const float*
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
+
+// ------------------------------------------------------------------------------------ DCL / DCLW
+// lightly.loss.DCLLoss / DCLWLoss (decoupled contrastive learning, the reference's DCLW model:
+// scripts/WM811k_benchmark.py:258-287).  For L2-normalised z0, z1 [B][D], per direction (a, b) in
+// {(z0, z1), (z1, z0)} and row i:
+//     l_i = -w_i <a_i, b_i>/T + lse_{k != i} <a_i, a_k>/T + lse_{k != i} <a_i, b_k>/T
+// w_i = 1 (DCL) or 2 - B softmax_i(<z0_i, z1_i>/sigma) (DCLW, detached);  loss = mean over rows and directions.
+// Kernel 1 (block = direction x row): the two similarity rows, their log-sum-exps, the softmax rows P_aa, P_ab
+// into global memory, the loss.  Kernel 2 (block = row i): the gradient as small matrix products with P.
+namespace {
+__global__ __launch_bounds__(256) void dcl_rows_kernel(const float* __restrict__ z0, const float* __restrict__ z1, int B, int D,
+                                                       float inv_t, float sigma_inv, int weighted,
+                                                       float* __restrict__ P, float* __restrict__ wts,
+                                                       float* __restrict__ loss) {
+  extern __shared__ float dc_smem[];  // a_i[D], s_aa[B], s_ab[B]
+  __shared__ float red[4];
+  float* sa = dc_smem;
+  float* saa = sa + D;
+  float* sab = saa + B;
+  const int dir = blockIdx.x / B, i = blockIdx.x - dir * B, tid = threadIdx.x;
+  const float* a = dir == 0 ? z0 : z1;
+  const float* b = dir == 0 ? z1 : z0;
+  for (int d = tid; d < D; d += 256) sa[d] = a[(size_t)i * D + d];
+  __syncthreads();
+  // mises-fisher weight of row i: needs the softmax over the whole batch of the positive similarities
+  float w = 1.f;
+  if (weighted) {
+    float m = -INFINITY;
+    for (int k = tid; k < B; k += 256) {
+      float s = 0.f;
+      for (int d = 0; d < D; ++d) s = fmaf(z0[(size_t)k * D + d], z1[(size_t)k * D + d], s);
+      saa[k] = s * sigma_inv;
+      m = fmaxf(m, saa[k]);
+    }
+    m = mb_block_reduce(m, red, true);
+    float sum = 0.f;
+    for (int k = tid; k < B; k += 256) sum += expf(saa[k] - m);
+    sum = mb_block_reduce(sum, red, false);
+    w = 2.f - (float)B * expf(saa[i] - m) / sum;
+    __syncthreads();
+  }
+  float maa = -INFINITY, mab = -INFINITY;
+  for (int k = tid; k < B; k += 256) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int d = 0; d < D; ++d) {
+      s0 = fmaf(sa[d], a[(size_t)k * D + d], s0);
+      s1 = fmaf(sa[d], b[(size_t)k * D + d], s1);
+    }
+    saa[k] = s0 * inv_t;
+    sab[k] = s1 * inv_t;
+    if (k != i) {
+      maa = fmaxf(maa, saa[k]);
+      mab = fmaxf(mab, sab[k]);
+    }
+  }
+  maa = mb_block_reduce(maa, red, true);
+  mab = mb_block_reduce(mab, red, true);
+  float eaa = 0.f, eab = 0.f;
+  for (int k = tid; k < B; k += 256)
+    if (k != i) {
+      eaa += expf(saa[k] - maa);
+      eab += expf(sab[k] - mab);
+    }
+  eaa = mb_block_reduce(eaa, red, false);
+  eab = mb_block_reduce(eab, red, false);
+  const float lse_aa = maa + logf(eaa), lse_ab = mab + logf(eab);
+  float* paa = P + ((size_t)(dir * 2 + 0) * B + i) * B;
+  float* pab = P + ((size_t)(dir * 2 + 1) * B + i) * B;
+  for (int k = tid; k < B; k += 256) {
+    paa[k] = k == i ? 0.f : expf(saa[k] - lse_aa);
+    pab[k] = k == i ? 0.f : expf(sab[k] - lse_ab);
+  }
+  if (tid == 0) {
+    wts[dir * B + i] = w;
+    atomicAdd(loss, (-w * sab[i] + lse_aa + lse_ab) * 0.5f / (float)B);
+  }
+}
+
+// d loss / d z0_i and d z1_i.  With direction 0 = (a, b) = (z0, z1) and direction 1 = (z1, z0):
+//   dz0_i = c [ sum_k (Paa0[i][k] + Paa0[k][i]) z0_k + sum_k Pab0[i][k] z1_k - w0_i z1_i        (direction 0, a role)
+//             + sum_j Pab1[j][i] z1_j - w1_i z1_i ]                                              (direction 1, b role)
+//   dz1_i likewise with the directions exchanged;  c = 0.5 / (T B).
+__global__ __launch_bounds__(256) void dcl_grad_kernel(const float* __restrict__ z0, const float* __restrict__ z1, int B, int D,
+                                                       float inv_t, const float* __restrict__ P,
+                                                       const float* __restrict__ wts, float* __restrict__ dz0,
+                                                       float* __restrict__ dz1) {
+  const int which = blockIdx.x / B, i = blockIdx.x - which * B;  // which: 0 -> dz0, 1 -> dz1
+  const float* a = which == 0 ? z0 : z1;                          // the tensor whose row i we differentiate
+  const float* b = which == 0 ? z1 : z0;
+  const int da = which, db = 1 - which;                           // direction where `a` is the anchor / where it is the target
+  const float* Paa = P + (size_t)(da * 2 + 0) * B * B;
+  const float* Pab = P + (size_t)(da * 2 + 1) * B * B;
+  const float* Qab = P + (size_t)(db * 2 + 1) * B * B;           // anchor b, target a
+  const float c = 0.5f * inv_t / (float)B;
+  for (int d = threadIdx.x; d < D; d += 256) {
+    float g = 0.f;
+    for (int k = 0; k < B; ++k) {
+      g = fmaf(Paa[(size_t)i * B + k] + Paa[(size_t)k * B + i], a[(size_t)k * D + d], g);
+      g = fmaf(Pab[(size_t)i * B + k] + Qab[(size_t)k * B + i], b[(size_t)k * D + d], g);
+    }
+    g -= (wts[da * B + i] + wts[db * B + i]) * b[(size_t)i * D + d];
+    (which == 0 ? dz0 : dz1)[(size_t)i * D + d] = c * g;
+  }
+}
+}  // namespace
+
+extern "C" size_t wm_dcl_workspace_bytes(int B) { return B > 0 ? ((size_t)4 * B * B + (size_t)2 * B) * sizeof(float) : 0; }
+
+extern "C" int wm_dcl_fwd_bwd(const float* z0, const float* z1, int B, int D, float temperature, float sigma, int weighted,
+                              float* loss, float* dz0, float* dz1, void* workspace, size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(z0 && z1 && loss && dz0 && dz1 && workspace, WM_EINVAL);
+  WM_REQUIRE(B > 1 && D > 0 && temperature > 1e-8f && (!weighted || sigma > 1e-8f), WM_EINVAL);
+  WM_REQUIRE(workspace_bytes >= wm_dcl_workspace_bytes(B), WM_EWORKSPACE);
+  const size_t lds = ((size_t)D + 2 * B) * sizeof(float);
+  WM_REQUIRE(lds <= 64 * 1024, WM_EUNSUPPORTED);
+  float* P = static_cast<float*>(workspace);
+  float* wts = P + (size_t)4 * B * B;
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dcl_rows_kernel<<<2 * B, 256, lds, st>>>(z0, z1, B, D, 1.f / temperature, weighted ? 1.f / sigma : 0.f, weighted, P, wts,
+                                          loss);
+  WM_LAUNCH_CHECK();
+  dcl_grad_kernel<<<2 * B, 256, 0, st>>>(z0, z1, B, D, 1.f / temperature, P, wts, dz0, dz1);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

@@ -254,6 +254,56 @@ class NTXentLoss(nn.Module):
         return _NTXentCore.apply(zn, b, self.temperature, self.gather_distributed)
 
 
+class _DCL(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z0, z1, temperature, sigma, weighted):
+        from . import _lib
+        from ._lib import check, ptr, stream_ptr
+
+        b, d = z0.shape
+        lib = _lib.load()
+        need = lib.wm_dcl_workspace_bytes(b)
+        ws = torch.empty(need, dtype=torch.uint8, device=z0.device)
+        loss = torch.zeros(1, dtype=torch.float32, device=z0.device)
+        d0, d1 = torch.empty_like(z0), torch.empty_like(z1)
+        check(lib.wm_dcl_fwd_bwd(ptr(z0), ptr(z1), b, d, temperature, sigma, int(weighted), ptr(loss), ptr(d0), ptr(d1),
+                                 ptr(ws), need, stream_ptr()), "wm_dcl_fwd_bwd")
+        ctx.save_for_backward(d0, d1)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        d0, d1 = ctx.saved_tensors
+        return d0 * g, d1 * g, None, None, None
+
+
+class DCLLoss(nn.Module):
+    """lightly.loss.DCLLoss (decoupled contrastive learning): the positive term is taken out of both
+    denominators.  `weight_fn` is not a free callable here: DCLWLoss is the weighted form."""
+
+    def __init__(self, temperature: float = 0.1, gather_distributed: bool = False):
+        super().__init__()
+        if gather_distributed and _world() > 1:
+            raise NotImplementedError("DCLLoss(gather_distributed=True) is not built")
+        self.temperature, self.sigma, self.weighted = float(temperature), 0.5, False
+
+    def forward(self, out0: torch.Tensor, out1: torch.Tensor) -> torch.Tensor:
+        if out0.shape != out1.shape or out0.dim() != 2 or out0.shape[0] < 2:
+            raise ValueError("DCLLoss expects two [batch >= 2, dim] tensors of equal shape")
+        z0 = F_hip.l2_normalize(out0.float().contiguous())
+        z1 = F_hip.l2_normalize(out1.float().contiguous())
+        return _DCL.apply(z0, z1, self.temperature, self.sigma, self.weighted)
+
+
+class DCLWLoss(DCLLoss):
+    """lightly.loss.DCLWLoss() as the reference's DCLW model builds it (scripts/WM811k_benchmark.py:265):
+    temperature 0.1, negative von Mises-Fisher weights with sigma 0.5 on the positive term."""
+
+    def __init__(self, temperature: float = 0.1, sigma: float = 0.5, gather_distributed: bool = False):
+        super().__init__(temperature, gather_distributed)
+        self.sigma, self.weighted = float(sigma), True
+
+
 class DINOLoss(nn.Module):
     """lightly.loss.DINOLoss as the reference calls it (scripts/WM811k_benchmark.py:564,586:
     `DINOLoss(output_dim=2048)`, `criterion(teacher_out, student_out, epoch=...)`).

@@ -7,3 +7,4 @@ from .mae import MAE, MAEBackbone, MAEDecoder, masked_autoencoder, vit_b_32  # n
 from .moco import MoCo  # noqa: F401
 from .siamese import BYOL, FastSiam, SimSiam  # noqa: F401
 from .evals import LinearClassifier, MultilabelLinearClassifier, SupervisedR18, fit_linear_probe  # noqa: F401
+from .dclw import DCLW  # noqa: F401

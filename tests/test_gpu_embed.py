@@ -418,3 +418,23 @@ def test_supervised_r18_step_matches_oracle():
         loss = model.training_step((ops.to_nhwc_bf16(x.to("cuda:0")), y.to("cuda:0")), i + 1)
         loss.backward()
     assert float(loss.detach()) < first
+
+
+@pytest.mark.parametrize("weighted", [False, True])
+def test_dcl_losses_match_oracle(weighted):
+    from ssl_wafermap_amd.loss import DCLLoss, DCLWLoss
+
+    g = torch.Generator().manual_seed(13)
+    b, d = 96, 128
+    a = torch.randn(b, d, generator=g)
+    c = a + 0.5 * torch.randn(b, d, generator=g)
+    ar, cr = a.clone().requires_grad_(True), c.clone().requires_grad_(True)
+    ref = on.dcl_loss(ar, cr, 0.1, 0.5 if weighted else None)
+    ref.backward()
+    ad, cd = a.to("cuda:0").requires_grad_(True), c.to("cuda:0").requires_grad_(True)
+    crit = (DCLWLoss() if weighted else DCLLoss()).to("cuda:0")
+    loss = crit(ad, cd)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach())), (float(loss), float(ref))
+    assert torch.allclose(ad.grad.cpu(), ar.grad, rtol=1e-3, atol=2e-6)
+    assert torch.allclose(cd.grad.cpu(), cr.grad, rtol=1e-3, atol=2e-6)
