@@ -312,6 +312,13 @@ size_t wm_dcl_workspace_bytes(int B);
 int wm_dcl_fwd_bwd(const float* z0, const float* z1, int B, int D, float temperature, float sigma, int weighted,
                    float* loss, float* dz0, float* dz1, void* workspace, size_t workspace_bytes, void* stream);
 
+/* lightly.loss.BarlowTwinsLoss on the cross-correlation matrix (scripts/WM811k_benchmark.py:364-366):
+ * raw_cc [D][D] f32 = sum over the batch of za_norm (x) zb_norm (wm_conv2d_wgrad on the two standardised
+ * projections); c = scale * raw_cc; loss[0] += sum_i (c_ii - 1)^2 + lambda sum_{i!=j} c_ij^2 (zero it first);
+ * draw_cc = d loss / d raw_cc. */
+int wm_barlow_twins_fwd_bwd(const float* raw_cc, int D, float scale, float lambda, float* loss, float* draw_cc,
+                            void* stream);
+
 /* NT-Xent against a memory bank (lightly NTXentLoss(memory_bank_size > 0), the reference's MoCo:
  * scripts/WM811k_benchmark.py:305-307).  q, kpos: L2-normalised [B][D] float32; bank [D][K] float32
  * (lightly's layout, one stored key per column).  logits_i = [<q_i,kpos_i>, <q_i,bank>] / T, label 0.
@@ -400,6 +407,14 @@ int wm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
                   const float* hyper, void* stream);
 /* lightly update_momentum: ema = ema * m + p * (1 - m). */
 int wm_ema_update(float* ema, const float* params, long long n, float m, void* stream);
+
+/* timm.optim.lars.Lars step (BarlowTwins / VICReg in the reference, scripts/WM811k_benchmark.py:383-392,
+ * 418-427) over a flat arena: seg_offsets [n_seg + 1] int64 = element offsets of the parameters; per parameter
+ * r = trust_coeff |w| / (|g| + wd |w| + eps) (1 if either norm is 0; no adaptation when wd == 0),
+ * g <- (g + wd w) r, buf = momentum buf + g, p -= lr buf.  hyper (device) = {lr, momentum, weight_decay,
+ * trust_coeff, eps, grad_scale}; norms_ws: 2 * n_seg floats of scratch. */
+int wm_lars_step(float* params, const float* grads, float* momentum_buf, const long long* seg_offsets, int n_seg,
+                 const float* hyper, float* norms_ws, void* stream);
 
 #ifdef __cplusplus
 }

@@ -98,3 +98,16 @@ def dcl_loss(out0, out1, temperature=0.1, sigma=None):
         return (positive + neg_aa + neg_ab).mean()
 
     return 0.5 * (one(out0, out1) + one(out1, out0))
+
+
+def barlow_twins_loss(z_a, z_b, lambda_param=5e-3):
+    """lightly BarlowTwinsLoss (Zbontar et al. 2021, arXiv:2103.03230 Algorithm 1 with lightly's scaling):
+    standardise over the batch with the unbiased std, c = z_a^T z_b / N, on-diagonal (c_ii - 1)^2 plus
+    lambda times the squared off-diagonal.  PARITY UNPINNED upstream."""
+    n, d = z_a.shape
+    za = (z_a - z_a.mean(0)) / z_a.std(0)
+    zb = (z_b - z_b.mean(0)) / z_b.std(0)
+    c = za.t() @ zb / n
+    on = (torch.diagonal(c) - 1).pow(2).sum()
+    off = c.pow(2).sum() - torch.diagonal(c).pow(2).sum()
+    return on + lambda_param * off

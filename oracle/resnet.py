@@ -106,3 +106,18 @@ def simsiam_projection_head(f, sd, prefix="projection_head.", training=True, gro
 
 def neg_cosine(x0, x1, eps=1e-8):
     return -F.cosine_similarity(x0, x1, dim=1, eps=eps).mean()
+
+
+def lars_step(params, grads, bufs, lr, momentum=0.9, weight_decay=0.0, trust_coeff=0.001, eps=1e-8):
+    """timm.optim.lars.Lars (dampening 0, no nesterov, no trust clip, always_adapt False), in place."""
+    for k, p in params.items():
+        g = grads[k].clone()
+        if weight_decay != 0:
+            w_norm, g_norm = p.norm(2.0), g.norm(2.0)
+            ratio = trust_coeff * w_norm / (g_norm + w_norm * weight_decay + eps)
+            ratio = torch.where(w_norm > 0, torch.where(g_norm > 0, ratio, torch.ones_like(ratio)), torch.ones_like(ratio))
+            g = (g + weight_decay * p) * ratio
+        buf = bufs.get(k)
+        buf = g.clone() if buf is None else buf.mul_(momentum).add_(g)
+        bufs[k] = buf
+        p.add_(buf, alpha=-lr)

@@ -681,3 +681,43 @@ extern "C" int wm_dcl_fwd_bwd(const float* z0, const float* z1, int B, int D, fl
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
+
+// ------------------------------------------------------------------------------------ Barlow Twins
+// lightly.loss.BarlowTwinsLoss (the reference's BarlowTwins model, scripts/WM811k_benchmark.py:364-366):
+// c = scale * raw  (raw [D][D] = za_norm^T zb_norm summed over the batch, from the weight-gradient GEMM);
+// loss = sum_i (c_ii - 1)^2 + lambda sum_{i != j} c_ij^2;  dc/draw folded in: draw = scale * dloss/dc.
+namespace {
+__global__ __launch_bounds__(256) void barlow_kernel(const float* __restrict__ raw, int D, float scale, float lambda,
+                                                     float* __restrict__ loss, float* __restrict__ draw) {
+  __shared__ float red[4];
+  const long long n = (long long)D * D;
+  float s = 0.f;
+  for (long long t = (long long)blockIdx.x * 256 + threadIdx.x; t < n; t += (long long)gridDim.x * 256) {
+    const int i = (int)(t / D), j = (int)(t - (long long)i * D);
+    const float c = raw[t] * scale;
+    float g;
+    if (i == j) {
+      s = fmaf(c - 1.f, c - 1.f, s);
+      g = 2.f * (c - 1.f);
+    } else {
+      s = fmaf(lambda * c, c, s);
+      g = 2.f * lambda * c;
+    }
+    draw[t] = g * scale;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, red[0] + red[1] + red[2] + red[3]);
+}
+}  // namespace
+
+extern "C" int wm_barlow_twins_fwd_bwd(const float* raw_cc, int D, float scale, float lambda, float* loss,
+                                       float* draw_cc, void* stream) {
+  WM_REQUIRE(raw_cc && loss && draw_cc && D > 0, WM_EINVAL);
+  const long long n = (long long)D * D;
+  const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
+  barlow_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(raw_cc, D, scale, lambda, loss, draw_cc);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

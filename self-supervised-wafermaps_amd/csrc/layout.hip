@@ -200,3 +200,70 @@ extern "C" int wm_sgd_step(float* params, const float* grads, float* momentum_bu
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
+
+// ------------------------------------------------------------------------------------ LARS
+// timm.optim.lars.Lars as the reference's BarlowTwins / VICReg use it (scripts/WM811k_benchmark.py:383-392,
+// 418-427): per PARAMETER trust ratio  r = trust_coeff |w| / (|g| + wd |w| + eps)  (1 when |w| or |g| is 0),
+// g <- (g + wd w) r, then SGD with momentum.  Parameters live in one flat arena; seg[] holds the element
+// offsets of the parameters (seg[n_seg] = end), a block handles one chunk of one parameter.
+namespace {
+__global__ void segment_sqnorms(const float* __restrict__ p, const float* __restrict__ g, const long long* __restrict__ seg,
+                                const float* __restrict__ hyper, float* __restrict__ out /* [n_seg][2], zeroed */) {
+  __shared__ float red[2][4];
+  const float gscale = hyper[5];
+  const int s = blockIdx.y;
+  const long long b = seg[s], e = seg[s + 1];
+  float a = 0.f, c = 0.f;
+  for (long long i = b + (long long)blockIdx.x * LT_THREADS + threadIdx.x; i < e; i += (long long)gridDim.x * LT_THREADS) {
+    const float pv = p[i], gv = g[i] * gscale;
+    a = fmaf(pv, pv, a);
+    c = fmaf(gv, gv, c);
+  }
+  a = wave_sum(a);
+  c = wave_sum(c);
+  if ((threadIdx.x & 63) == 0) {
+    red[0][threadIdx.x >> 6] = a;
+    red[1][threadIdx.x >> 6] = c;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(out + 2 * s, red[0][0] + red[0][1] + red[0][2] + red[0][3]);
+    atomicAdd(out + 2 * s + 1, red[1][0] + red[1][1] + red[1][2] + red[1][3]);
+  }
+}
+
+// hyper: {lr, momentum, weight_decay, trust_coeff, eps, grad_scale}
+__global__ void lars_step(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ mom,
+                          const long long* __restrict__ seg, const float* __restrict__ norms,
+                          const float* __restrict__ hyper) {
+  const float lr = hyper[0], mu = hyper[1], wd = hyper[2], tc = hyper[3], eps = hyper[4], gs = hyper[5];
+  const int s = blockIdx.y;
+  const long long b = seg[s], e = seg[s + 1];
+  float ratio = 1.f;
+  if (wd != 0.f) {
+    const float wn = sqrtf(norms[2 * s]), gn = sqrtf(norms[2 * s + 1]);
+    if (wn > 0.f && gn > 0.f) ratio = tc * wn / (gn + wn * wd + eps);
+  }
+  for (long long i = b + (long long)blockIdx.x * LT_THREADS + threadIdx.x; i < e; i += (long long)gridDim.x * LT_THREADS) {
+    const float pv = p[i];
+    float gv = g[i] * gs;
+    if (wd != 0.f) gv = fmaf(wd, pv, gv) * ratio;
+    const float bu = fmaf(mu, mom[i], gv);
+    mom[i] = bu;
+    p[i] = pv - lr * bu;
+  }
+}
+}  // namespace
+
+extern "C" int wm_lars_step(float* params, const float* grads, float* momentum_buf, const long long* seg_offsets,
+                            int n_seg, const float* hyper, float* norms_ws, void* stream) {
+  WM_REQUIRE(params && grads && momentum_buf && seg_offsets && hyper && norms_ws && n_seg > 0 && n_seg <= 65535, WM_EINVAL);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e = hipMemsetAsync(norms_ws, 0, (size_t)2 * n_seg * sizeof(float), st);
+  if (e != hipSuccess) return (int)e;
+  segment_sqnorms<<<dim3(32, n_seg), LT_THREADS, 0, st>>>(params, grads, seg_offsets, hyper, norms_ws);
+  WM_LAUNCH_CHECK();
+  lars_step<<<dim3(32, n_seg), LT_THREADS, 0, st>>>(params, grads, momentum_buf, seg_offsets, norms_ws, hyper);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

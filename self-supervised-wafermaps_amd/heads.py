@@ -76,6 +76,15 @@ class MoCoProjectionHead(ProjectionHead):
         super().__init__([(input_dim, hidden_dim, None, hnn.ReLU()), (hidden_dim, output_dim, None, None)])
 
 
+class BarlowTwinsProjectionHead(ProjectionHead):
+    """lightly BarlowTwinsProjectionHead: (Linear-BN-ReLU) x2, Linear(+bias)  (reference: (512, 2048, 2048), :363, :400)."""
+
+    def __init__(self, input_dim: int = 2048, hidden_dim: int = 8192, output_dim: int = 8192):
+        super().__init__([(input_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.ReLU()),
+                          (hidden_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.ReLU()),
+                          (hidden_dim, output_dim, None, None)])
+
+
 class BYOLProjectionHead(ProjectionHead):
     """lightly BYOLProjectionHead: Linear-BN-ReLU, Linear(+bias) (reference: (512, 4096, 256), :437)."""
 

@@ -304,6 +304,67 @@ class DCLWLoss(DCLLoss):
         self.sigma, self.weighted = float(sigma), True
 
 
+class _CrossCorrBarlow(torch.autograd.Function):
+    """loss(za_n, zb_n) on the cross-correlation of two standardised [B, D] bf16 projections.  The [D, D]
+    matrix is the weight-gradient GEMM of the implicit-GEMM kernel (sum over rows of za (x) zb), its
+    gradient goes back through two ordinary GEMMs against the saved d loss / d matrix."""
+
+    @staticmethod
+    def forward(ctx, za, zb, scale, lambda_param):
+        from . import _lib, ops
+        from ._lib import check, ptr, stream_ptr
+
+        za, zb = za.to(torch.bfloat16).contiguous(), zb.to(torch.bfloat16).contiguous()
+        b, d = za.shape
+        lib = _lib.load()
+        raw = torch.zeros((d, d), dtype=torch.float32, device=za.device)
+        check(lib.wm_conv2d_wgrad(ptr(za), ptr(zb), ptr(raw), b, 1, 1, d, d, 1, 1, 1, 1, 1, 0, stream_ptr()),
+              "wm_conv2d_wgrad(cross-correlation)")
+        loss = torch.zeros(1, dtype=torch.float32, device=za.device)
+        draw = torch.empty_like(raw)
+        check(lib.wm_barlow_twins_fwd_bwd(ptr(raw), d, scale, lambda_param, ptr(loss), ptr(draw), stream_ptr()),
+              "wm_barlow_twins_fwd_bwd")
+        ctx.save_for_backward(za, zb, draw)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+
+        za, zb, draw = ctx.saved_tensors
+        # raw[i][j] = sum_n za[n][i] zb[n][j]:  dza = zb @ draw^T (Linear with weight draw), dzb = za @ draw
+        dza = ops.linear(zb, draw).float() * g
+        dzb = ops.linear(za, draw.t().contiguous()).float() * g
+        return dza.to(torch.bfloat16), dzb.to(torch.bfloat16), None, None
+
+
+class BarlowTwinsLoss(nn.Module):
+    """lightly.loss.BarlowTwinsLoss(lambda_param=5e-3): both projections are standardised over the batch
+    (mean 0, unbiased std 1), c = za^T zb / N, loss = sum_i (c_ii - 1)^2 + lambda sum_{i != j} c_ij^2."""
+
+    def __init__(self, lambda_param: float = 5e-3, gather_distributed: bool = False):
+        super().__init__()
+        if gather_distributed and _world() > 1:
+            raise NotImplementedError("BarlowTwinsLoss(gather_distributed=True) is not built")
+        self.lambda_param = float(lambda_param)
+
+    def forward(self, z_a: torch.Tensor, z_b: torch.Tensor) -> torch.Tensor:
+        from . import ops
+
+        if z_a.shape != z_b.shape or z_a.dim() != 2 or z_a.shape[0] < 2:
+            raise ValueError("BarlowTwinsLoss expects two [batch >= 2, dim] tensors of equal shape")
+        n, d = z_a.shape
+        ones = torch.ones(d, dtype=torch.float32, device=z_a.device)
+        zeros = torch.zeros(d, dtype=torch.float32, device=z_a.device)
+        rm, rv = torch.zeros_like(zeros), torch.ones_like(ones)
+        # batch standardisation = BatchNorm without affine, eps 0 (biased variance); the unbiased std of
+        # lightly's (z - mean) / std turns into the factor (N - 1) / N on the correlation matrix
+        with ops.bn_groups(1):
+            za = ops.batch_norm(z_a, ones, zeros, rm, rv, True, eps=0.0)
+            zb = ops.batch_norm(z_b, ones, zeros, rm.clone(), rv.clone(), True, eps=0.0)
+        return _CrossCorrBarlow.apply(za, zb, (n - 1) / (n * n), self.lambda_param)
+
+
 class DINOLoss(nn.Module):
     """lightly.loss.DINOLoss as the reference calls it (scripts/WM811k_benchmark.py:564,586:
     `DINOLoss(output_dim=2048)`, `criterion(teacher_out, student_out, epoch=...)`).

@@ -8,3 +8,4 @@ from .moco import MoCo  # noqa: F401
 from .siamese import BYOL, FastSiam, SimSiam  # noqa: F401
 from .evals import LinearClassifier, MultilabelLinearClassifier, SupervisedR18, fit_linear_probe  # noqa: F401
 from .dclw import DCLW  # noqa: F401
+from .barlow import BarlowTwins  # noqa: F401

@@ -126,3 +126,53 @@ class AdamW(torch.optim.Optimizer):
                                     arena.numel, ptr(hyper), stream_ptr()), "wm_adamw_step")
         ops.bump_weight_epoch()
         return loss
+
+
+class LARS(torch.optim.Optimizer):
+    """timm.optim.lars.Lars (momentum SGD with a per-parameter trust ratio; the reference's BarlowTwins and
+    VICReg optimiser, scripts/WM811k_benchmark.py:383-392): two launches per parameter group over the flat
+    arena (per-parameter squared norms, then the update)."""
+
+    def __init__(self, params, lr: float = 1.0, momentum: float = 0.0, weight_decay: float = 0.0,
+                 trust_coeff: float = 0.001, eps: float = 1e-8, grad_scale: float = 1.0):
+        if lr < 0 or momentum < 0 or weight_decay < 0:
+            raise ValueError("invalid LARS hyper-parameter")
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay, trust_coeff=trust_coeff,
+                                      eps=eps))
+        self.grad_scale = float(grad_scale)
+        self._arenas, self._hyper, self._seg, self._norms = [], [], [], []
+        for group in self.param_groups:
+            ps = [p for p in group["params"] if p.requires_grad]
+            arena = _Arena(ps)
+            dev = arena.params.device
+            ends = [o + p.numel() for o, p in zip(arena.offsets, ps)]
+            # a parameter's segment is [offset, offset + numel): the alignment gaps belong to no segment
+            seg = torch.tensor([v for o, e in zip(arena.offsets, ends) for v in (o, e)], dtype=torch.int64)
+            self._arenas.append(arena)
+            self._hyper.append(torch.zeros(6, dtype=torch.float32, device=dev))
+            self._seg.append((seg.to(dev), len(ps)))
+            self._norms.append(torch.zeros(4 * len(ps), dtype=torch.float32, device=dev))
+        ops.bump_weight_epoch()
+
+    @property
+    def grad_arenas(self) -> List[torch.Tensor]:
+        return [a.grads for a in self._arenas]
+
+    def zero_grad(self, set_to_none: bool = False) -> None:
+        for a in self._arenas:
+            a.grads.zero_()
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        lib = _lib.load()
+        for group, arena, hyper, (seg, n), norms in zip(self.param_groups, self._arenas, self._hyper, self._seg,
+                                                        self._norms):
+            h = (float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]), float(group["trust_coeff"]),
+                 float(group["eps"]), self.grad_scale)
+            hyper.copy_(torch.tensor(h, dtype=torch.float32), non_blocking=False)
+            # segments are (begin, end) pairs: 2n entries = n "segments" of stride 2 -> pass as 2n-1 boundaries
+            check(lib.wm_lars_step(ptr(arena.params), ptr(arena.grads), ptr(arena.momentum), ptr(seg), 2 * n - 1,
+                                   ptr(hyper), ptr(norms), stream_ptr()), "wm_lars_step")
+        ops.bump_weight_epoch()
+        return loss

@@ -438,3 +438,45 @@ def test_dcl_losses_match_oracle(weighted):
     assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-5 * abs(float(ref.detach())), (float(loss), float(ref))
     assert torch.allclose(ad.grad.cpu(), ar.grad, rtol=1e-3, atol=2e-6)
     assert torch.allclose(cd.grad.cpu(), cr.grad, rtol=1e-3, atol=2e-6)
+
+
+def test_barlow_twins_loss_matches_oracle():
+    from ssl_wafermap_amd.loss import BarlowTwinsLoss
+
+    g = torch.Generator().manual_seed(17)
+    n, d = 64, 256
+    a = (torch.randn(n, d, generator=g) * 1.5 + 0.3).bfloat16().float()
+    b = (a + 0.7 * torch.randn(n, d, generator=g)).bfloat16().float()
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = on.barlow_twins_loss(ar, br)
+    ref.backward()
+    ad, bd = a.to("cuda:0").bfloat16().requires_grad_(True), b.to("cuda:0").bfloat16().requires_grad_(True)
+    loss = BarlowTwinsLoss().to("cuda:0")(ad, bd)
+    loss.backward()
+    # standardised projections are stored in bf16 before the correlation GEMM: 2^-9 on each factor
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-2 * abs(float(ref.detach())), (float(loss), float(ref))
+    ca = torch.nn.functional.cosine_similarity(ad.grad.float().cpu().flatten(), ar.grad.flatten(), dim=0)
+    cb = torch.nn.functional.cosine_similarity(bd.grad.float().cpu().flatten(), br.grad.flatten(), dim=0)
+    assert float(ca) > 0.995 and float(cb) > 0.995, (float(ca), float(cb))
+    scale = float(ar.grad.abs().max())
+    assert float((ad.grad.float().cpu() - ar.grad).abs().max()) < 0.05 * scale
+
+
+def test_lars_matches_timm_restatement():
+    from oracle import resnet as orn
+    from ssl_wafermap_amd import optim
+
+    torch.manual_seed(5)
+    shapes = [(64, 64, 3, 3), (64,), (128, 64), (7,)]
+    ps = [torch.nn.Parameter(torch.randn(*s_, device="cuda:0") * 0.1) for s_ in shapes]
+    ref = {str(i): p.detach().cpu().clone() for i, p in enumerate(ps)}
+    bufs = {}
+    opt = optim.LARS(ps, lr=0.2, weight_decay=1.5e-6, momentum=0.9)
+    for step in range(4):
+        grads = {str(i): torch.randn(*s_) * (0.0 if (step == 1 and i == 3) else 1.0) for i, s_ in enumerate(shapes)}
+        for i, p in enumerate(ps):
+            p.grad.copy_(grads[str(i)].to("cuda:0"))
+        opt.step()
+        orn.lars_step(ref, grads, bufs, 0.2, 0.9, 1.5e-6)
+    for i, p in enumerate(ps):
+        torch.testing.assert_close(p.detach().cpu(), ref[str(i)], rtol=2e-5, atol=1e-7)

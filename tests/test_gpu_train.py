@@ -266,3 +266,43 @@ def test_dino_resnet_step_matches_oracle():
     loss.backward()
     opt.step()
     assert abs(float(loss.detach()) - float(ref)) <= 1e-2 * abs(float(ref)), (float(loss), float(ref))
+
+
+def test_barlow_twins_step_matches_oracle_and_lars_moves_it():
+    import math
+
+    from oracle import ntxent as ont
+    from oracle import resnet as orn
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models import BarlowTwins
+
+    torch.manual_seed(0)
+    b = 32
+    model = BarlowTwins(None, 9, batch_size=b, log_rep_std=False).to(DEV).train()
+    (opt,), _ = model.configure_optimizers()
+    g = torch.Generator().manual_seed(4)
+    x0 = torch.randn(b, 3, 224, 224, generator=g).bfloat16().float()
+    x1 = (x0 + 0.5 * torch.randn(b, 3, 224, 224, generator=g)).bfloat16().float()
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+
+    def proj(x):
+        f = orn.resnet18_features(x, sd, True, prefix="backbone.")
+        h = orn._bn1d(torch.nn.functional.linear(f, sd["projection_head.layers.0.weight"]), sd, "projection_head.layers.1", True, 1, relu=True)
+        h = orn._bn1d(torch.nn.functional.linear(h, sd["projection_head.layers.3.weight"]), sd, "projection_head.layers.4", True, 1, relu=True)
+        return torch.nn.functional.linear(h, sd["projection_head.layers.6.weight"], sd["projection_head.layers.6.bias"])
+
+    ref = ont.barlow_twins_loss(proj(x0), proj(x1))
+    batch = ((ops.to_nhwc_bf16(x0.to(DEV)), ops.to_nhwc_bf16(x1.to(DEV))), None)
+    opt.zero_grad()
+    loss = model.training_step(batch, 0)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref)) <= 5e-2 * abs(float(ref)), (float(loss), float(ref))
+    first = float(loss.detach())
+    for grp in opt.param_groups:
+        grp["lr"] = 0.2  # past the warm-up factor of epoch 0
+    for i in range(6):
+        opt.step()
+        opt.zero_grad()
+        loss = model.training_step(batch, i + 1)
+        loss.backward()
+    assert math.isfinite(float(loss.detach())) and float(loss.detach()) < first
