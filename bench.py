@@ -127,6 +127,8 @@ def main():
     rank, world, local = wdist.init_from_env()
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    if os.environ.get("WM_SINGLE_DEVICE") == "1":
+        local = 0  # rehearsal of the N > 1 path on a one-GPU box (with WM_DIST_BACKEND=gloo)
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 

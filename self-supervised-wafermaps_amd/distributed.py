@@ -25,7 +25,9 @@ def init_from_env(backend: Optional[str] = None) -> tuple:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            # WM_DIST_BACKEND=gloo: rehearse the multi-process path with every rank on ONE GPU (RCCL refuses two
+            # ranks per device); together with WM_SINGLE_DEVICE=1 in bench.py
+            backend = os.environ.get("WM_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
