@@ -314,10 +314,16 @@ int wm_dcl_fwd_bwd(const float* z0, const float* z1, int B, int D, float tempera
 
 /* lightly.loss.BarlowTwinsLoss on the cross-correlation matrix (scripts/WM811k_benchmark.py:364-366):
  * raw_cc [D][D] f32 = sum over the batch of za_norm (x) zb_norm (wm_conv2d_wgrad on the two standardised
- * projections); c = scale * raw_cc; loss[0] += sum_i (c_ii - 1)^2 + lambda sum_{i!=j} c_ij^2 (zero it first);
- * draw_cc = d loss / d raw_cc. */
-int wm_barlow_twins_fwd_bwd(const float* raw_cc, int D, float scale, float lambda, float* loss, float* draw_cc,
-                            void* stream);
+ * projections); c = scale * raw_cc; loss[0] += diag_weight sum_i (c_ii - 1)^2 + lambda sum_{i!=j} c_ij^2 (zero it
+ * first); draw_cc = d loss / d raw_cc.  Barlow Twins: diag_weight 1; VICReg's covariance term: diag_weight 0,
+ * lambda 1/D, scale 1/(N-1) on the covariance of the centred projection. */
+int wm_barlow_twins_fwd_bwd(const float* raw_cc, int D, float scale, float lambda, float diag_weight, float* loss,
+                            float* draw_cc, void* stream);
+/* VICReg pieces (lightly.loss.VICRegLoss, scripts/WM811k_benchmark.py:401): out = z - mean (bf16 [rows][C]);
+ * variance term loss[0] += mean_d relu(1 - sqrt(var_biased_d N/(N-1) + eps)) with coef[d] such that
+ * d term / d centred[n][d] = coef[d] * centred[n][d]. */
+int wm_center_columns(const void* z, const float* mean, long long rows, int C, void* out, void* stream);
+int wm_vicreg_variance(const float* var_biased, int N, int D, float eps, float* loss, float* coef, void* stream);
 
 /* NT-Xent against a memory bank (lightly NTXentLoss(memory_bank_size > 0), the reference's MoCo:
  * scripts/WM811k_benchmark.py:305-307).  q, kpos: L2-normalised [B][D] float32; bank [D][K] float32

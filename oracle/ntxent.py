@@ -111,3 +111,21 @@ def barlow_twins_loss(z_a, z_b, lambda_param=5e-3):
     on = (torch.diagonal(c) - 1).pow(2).sum()
     off = c.pow(2).sum() - torch.diagonal(c).pow(2).sum()
     return on + lambda_param * off
+
+
+def vicreg_loss(z_a, z_b, lambda_param=25.0, mu_param=25.0, nu_param=1.0, eps=1e-4):
+    """lightly VICRegLoss (Bardes et al. 2022, arXiv:2105.04906, with lightly's normalisations): MSE invariance,
+    hinge on sqrt(var + eps) averaged over the two branches, squared off-diagonal covariance / D summed over
+    the branches.  PARITY UNPINNED upstream."""
+    def variance(x):
+        return torch.mean(F.relu(1.0 - torch.sqrt(x.var(dim=0) + eps)))
+
+    def covariance(x):
+        x = x - x.mean(dim=0)
+        n, d = x.shape
+        cov = x.t() @ x / (n - 1)
+        off = cov.pow(2).sum() - torch.diagonal(cov).pow(2).sum()
+        return off / d
+
+    return (lambda_param * F.mse_loss(z_a, z_b) + mu_param * 0.5 * (variance(z_a) + variance(z_b))
+            + nu_param * (covariance(z_a) + covariance(z_b)))

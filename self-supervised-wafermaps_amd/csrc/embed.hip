@@ -688,7 +688,8 @@ extern "C" int wm_dcl_fwd_bwd(const float* z0, const float* z1, int B, int D, fl
 // loss = sum_i (c_ii - 1)^2 + lambda sum_{i != j} c_ij^2;  dc/draw folded in: draw = scale * dloss/dc.
 namespace {
 __global__ __launch_bounds__(256) void barlow_kernel(const float* __restrict__ raw, int D, float scale, float lambda,
-                                                     float* __restrict__ loss, float* __restrict__ draw) {
+                                                     float diag_weight, float* __restrict__ loss,
+                                                     float* __restrict__ draw) {
   __shared__ float red[4];
   const long long n = (long long)D * D;
   float s = 0.f;
@@ -697,8 +698,8 @@ __global__ __launch_bounds__(256) void barlow_kernel(const float* __restrict__ r
     const float c = raw[t] * scale;
     float g;
     if (i == j) {
-      s = fmaf(c - 1.f, c - 1.f, s);
-      g = 2.f * (c - 1.f);
+      s = fmaf(diag_weight * (c - 1.f), c - 1.f, s);
+      g = 2.f * diag_weight * (c - 1.f);
     } else {
       s = fmaf(lambda * c, c, s);
       g = 2.f * lambda * c;
@@ -712,12 +713,65 @@ __global__ __launch_bounds__(256) void barlow_kernel(const float* __restrict__ r
 }
 }  // namespace
 
-extern "C" int wm_barlow_twins_fwd_bwd(const float* raw_cc, int D, float scale, float lambda, float* loss,
-                                       float* draw_cc, void* stream) {
+extern "C" int wm_barlow_twins_fwd_bwd(const float* raw_cc, int D, float scale, float lambda, float diag_weight,
+                                       float* loss, float* draw_cc, void* stream) {
   WM_REQUIRE(raw_cc && loss && draw_cc && D > 0, WM_EINVAL);
   const long long n = (long long)D * D;
   const int blocks = (int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256);
-  barlow_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(raw_cc, D, scale, lambda, loss, draw_cc);
+  barlow_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(raw_cc, D, scale, lambda, diag_weight, loss,
+                                                                      draw_cc);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+// ------------------------------------------------------------------------------------ VICReg pieces
+// lightly.loss.VICRegLoss (the reference's VICReg model, scripts/WM811k_benchmark.py:401): per branch
+//   centred = z - mean_0(z)   (wm_center_columns; its covariance is the weight-gradient GEMM + wm_barlow_twins_fwd_bwd
+//                              with diag_weight 0, lambda 1/D, scale 1/(N-1))
+//   variance term = mean_d relu(1 - sqrt(var_unbiased_d + eps)) and its derivative with respect to centred[n][d],
+//                   coef_d * centred[n][d]  (wm_vicreg_variance).
+namespace {
+__global__ __launch_bounds__(256) void center_columns_kernel(const uint16_t* __restrict__ z, const float* __restrict__ mean,
+                                                             long long rows, int C, uint16_t* __restrict__ out) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+    out[i] = f2bf(bf2f(z[i]) - mean[i % C]);
+}
+
+__global__ __launch_bounds__(256) void vicreg_variance_kernel(const float* __restrict__ var_biased, int N, int D, float eps,
+                                                              float* __restrict__ loss, float* __restrict__ coef) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int d = blockIdx.x * 256 + threadIdx.x; d < D; d += gridDim.x * 256) {
+    const float var = var_biased[d] * (float)N / (float)(N - 1);
+    const float sd = sqrtf(var + eps);
+    const float hinge = fmaxf(1.f - sd, 0.f);
+    s += hinge;
+    // d mean_d relu(1 - sd_d) / d centred[n][d] = -[sd < 1] / D * centred[n][d] / ((N - 1) sd)
+    coef[d] = hinge > 0.f ? -1.f / ((float)D * (float)(N - 1) * sd) : 0.f;
+  }
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(loss, (red[0] + red[1] + red[2] + red[3]) / (float)D);
+}
+}  // namespace
+
+extern "C" int wm_center_columns(const void* z, const float* mean, long long rows, int C, void* out, void* stream) {
+  WM_REQUIRE(z && mean && out && rows > 0 && C > 0, WM_EINVAL);
+  const long long n = rows * C;
+  const int blocks = (int)((n + 255) / 256 > 4096 ? 4096 : (n + 255) / 256);
+  center_columns_kernel<<<blocks, 256, 0, static_cast<hipStream_t>(stream)>>>(static_cast<const uint16_t*>(z), mean, rows, C,
+                                                                              static_cast<uint16_t*>(out));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_vicreg_variance(const float* var_biased, int N, int D, float eps, float* loss, float* coef,
+                                  void* stream) {
+  WM_REQUIRE(var_biased && loss && coef && N > 1 && D > 0 && eps >= 0.f, WM_EINVAL);
+  vicreg_variance_kernel<<<wm_cdiv(D, 256) > 64 ? 64 : wm_cdiv(D, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      var_biased, N, D, eps, loss, coef);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

@@ -322,7 +322,7 @@ class _CrossCorrBarlow(torch.autograd.Function):
               "wm_conv2d_wgrad(cross-correlation)")
         loss = torch.zeros(1, dtype=torch.float32, device=za.device)
         draw = torch.empty_like(raw)
-        check(lib.wm_barlow_twins_fwd_bwd(ptr(raw), d, scale, lambda_param, ptr(loss), ptr(draw), stream_ptr()),
+        check(lib.wm_barlow_twins_fwd_bwd(ptr(raw), d, scale, lambda_param, 1.0, ptr(loss), ptr(draw), stream_ptr()),
               "wm_barlow_twins_fwd_bwd")
         ctx.save_for_backward(za, zb, draw)
         return loss[0]
@@ -363,6 +363,70 @@ class BarlowTwinsLoss(nn.Module):
             za = ops.batch_norm(z_a, ones, zeros, rm, rv, True, eps=0.0)
             zb = ops.batch_norm(z_b, ones, zeros, rm.clone(), rv.clone(), True, eps=0.0)
         return _CrossCorrBarlow.apply(za, zb, (n - 1) / (n * n), self.lambda_param)
+
+
+class _VICRegBranch(torch.autograd.Function):
+    """variance term * mu + covariance term * nu of ONE projection z [N, D] (bf16)."""
+
+    @staticmethod
+    def forward(ctx, z, mu, nu, eps):
+        from . import _lib, ops
+        from ._lib import check, dtype_code, ptr, stream_ptr
+
+        z = z.to(torch.bfloat16).contiguous()
+        n, d = z.shape
+        lib = _lib.load()
+        mean = torch.zeros(d, dtype=torch.float32, device=z.device)
+        var = torch.zeros(d, dtype=torch.float32, device=z.device)
+        check(lib.wm_colstats(ptr(z), dtype_code(z), n, d, ptr(mean), ptr(var), stream_ptr()), "wm_colstats")
+        zc = torch.empty_like(z)
+        check(lib.wm_center_columns(ptr(z), ptr(mean), n, d, ptr(zc), stream_ptr()), "wm_center_columns")
+        vloss = torch.zeros(1, dtype=torch.float32, device=z.device)
+        coef = torch.empty(d, dtype=torch.float32, device=z.device)
+        check(lib.wm_vicreg_variance(ptr(var), n, d, eps, ptr(vloss), ptr(coef), stream_ptr()), "wm_vicreg_variance")
+        raw = torch.zeros((d, d), dtype=torch.float32, device=z.device)
+        check(lib.wm_conv2d_wgrad(ptr(zc), ptr(zc), ptr(raw), n, 1, 1, d, d, 1, 1, 1, 1, 1, 0, stream_ptr()),
+              "wm_conv2d_wgrad(covariance)")
+        closs = torch.zeros(1, dtype=torch.float32, device=z.device)
+        draw = torch.empty_like(raw)
+        check(lib.wm_barlow_twins_fwd_bwd(ptr(raw), d, 1.0 / (n - 1), 1.0 / d, 0.0, ptr(closs), ptr(draw), stream_ptr()),
+              "wm_barlow_twins_fwd_bwd(covariance)")
+        ctx.save_for_backward(zc, coef, draw)
+        ctx.w = (mu, nu)
+        return mu * vloss[0] + nu * closs[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        from . import ops
+
+        zc, coef, draw = ctx.saved_tensors
+        mu, nu = ctx.w
+        # covariance: raw = zc^T zc -> d/dzc = zc @ (draw + draw^T) = 2 zc @ draw (draw is symmetric)
+        dzc = 2.0 * nu * ops.linear(zc, draw).float() + mu * coef * zc.float()
+        dz = dzc - dzc.mean(dim=0, keepdim=True)  # through the centring
+        return (dz * g).to(torch.bfloat16), None, None, None
+
+
+class VICRegLoss(nn.Module):
+    """lightly.loss.VICRegLoss(lambda_param=25, mu_param=25, nu_param=1, eps=1e-4): invariance (MSE between the
+    branches) + variance hinge on the per-dimension std + squared off-diagonal covariance."""
+
+    def __init__(self, lambda_param: float = 25.0, mu_param: float = 25.0, nu_param: float = 1.0,
+                 gather_distributed: bool = False, eps: float = 0.0001):
+        super().__init__()
+        if gather_distributed and _world() > 1:
+            raise NotImplementedError("VICRegLoss(gather_distributed=True) is not built")
+        self.lambda_param, self.mu_param, self.nu_param, self.eps = lambda_param, mu_param, nu_param, eps
+
+    def forward(self, z_a: torch.Tensor, z_b: torch.Tensor) -> torch.Tensor:
+        from . import vit_ops
+
+        if z_a.shape != z_b.shape or z_a.dim() != 2 or z_a.shape[0] < 2:
+            raise ValueError("VICRegLoss expects two [batch >= 2, dim] tensors of equal shape")
+        inv = vit_ops.mse_loss(z_a, z_b)
+        branch = _VICRegBranch.apply(z_a, 0.5 * self.mu_param, self.nu_param, self.eps) + \
+            _VICRegBranch.apply(z_b, 0.5 * self.mu_param, self.nu_param, self.eps)
+        return self.lambda_param * inv + branch
 
 
 class DINOLoss(nn.Module):

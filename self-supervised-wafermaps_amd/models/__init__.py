@@ -9,3 +9,4 @@ from .siamese import BYOL, FastSiam, SimSiam  # noqa: F401
 from .evals import LinearClassifier, MultilabelLinearClassifier, SupervisedR18, fit_linear_probe  # noqa: F401
 from .dclw import DCLW  # noqa: F401
 from .barlow import BarlowTwins  # noqa: F401
+from .vicreg import VICReg  # noqa: F401

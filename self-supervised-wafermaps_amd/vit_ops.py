@@ -375,7 +375,8 @@ class _MSE(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
-        return (dpred.float() * g).to(torch.bfloat16), None
+        d = (dpred.float() * g).to(torch.bfloat16)
+        return d, (-d if ctx.needs_input_grad[1] else None)
 
 
 def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:

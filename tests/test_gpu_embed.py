@@ -480,3 +480,23 @@ def test_lars_matches_timm_restatement():
         orn.lars_step(ref, grads, bufs, 0.2, 0.9, 1.5e-6)
     for i, p in enumerate(ps):
         torch.testing.assert_close(p.detach().cpu(), ref[str(i)], rtol=2e-5, atol=1e-7)
+
+
+def test_vicreg_loss_matches_oracle():
+    from ssl_wafermap_amd.loss import VICRegLoss
+
+    g = torch.Generator().manual_seed(19)
+    n, d = 64, 256
+    a = (torch.randn(n, d, generator=g) * torch.rand(d, generator=g) * 1.5).bfloat16().float()  # some stds below 1
+    b = (a + 0.4 * torch.randn(n, d, generator=g)).bfloat16().float()
+    ar, br = a.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    ref = on.vicreg_loss(ar, br)
+    ref.backward()
+    ad, bd = a.to("cuda:0").bfloat16().requires_grad_(True), b.to("cuda:0").bfloat16().requires_grad_(True)
+    loss = VICRegLoss().to("cuda:0")(ad, bd)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 1e-2 * abs(float(ref.detach())), (float(loss), float(ref))
+    for got, want in ((ad.grad, ar.grad), (bd.grad, br.grad)):
+        c = torch.nn.functional.cosine_similarity(got.float().cpu().flatten(), want.flatten(), dim=0)
+        assert float(c) > 0.995, float(c)
+        assert float((got.float().cpu() - want).abs().max()) < 0.05 * float(want.abs().max())
