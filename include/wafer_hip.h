@@ -387,6 +387,8 @@ int wm_scatter_rows(const void* src, const long long* idx, int B, int S, int K, 
 /* MSE over n elements: loss[0] = mean((pred - target)^2); dpred = 2 (pred - target) / n (bf16).
  * loss must be zeroed by the caller. */
 int wm_mse_fwd_bwd(const void* pred, const void* target, long long n, float* loss, void* dpred, void* stream);
+/* torch.nn.L1Loss() (SimMIM, scripts/WM811k_benchmark.py:976): loss[0] += mean |pred - target|; dpred = sign / n. */
+int wm_l1_fwd_bwd(const void* pred, const void* target, long long n, float* loss, void* dpred, void* stream);
 
 /* DINO loss (lightly.loss.DINOLoss).  teacher [Vt*B][D] bf16 -> probs f32 = softmax((t - center)/temp_t). */
 int wm_dino_teacher_probs(const void* teacher, const float* center, float temp_t, long long rows, int D,

@@ -185,3 +185,24 @@ def mae_loss(images, sd, idx_keep, idx_mask, enc_heads=12, dec_heads=16):
     patches = lightly_patchify(images, p)
     target = torch.gather(patches, 1, (idx_mask - 1).unsqueeze(-1).expand(-1, -1, patches.shape[-1]))
     return F.mse_loss(pred, target)
+
+
+def simmim_loss(images, sd, idx_mask, heads=12):
+    """The reference's SimMIM.training_step for given masked indices (scripts/WM811k_benchmark.py:979-1014):
+    tokens (class token prepended, NO positional embedding yet) -> masked ones replaced by the mask token ->
+    encoder (adds the positional embedding) -> Linear decoder on the masked tokens -> L1 against the patches."""
+    g = {k[len("backbone."):]: v for k, v in sd.items() if k.startswith("backbone.")}
+    p = g["conv_proj.weight"].shape[-1]
+    t = F.conv2d(images, g["conv_proj.weight"], g["conv_proj.bias"], stride=p).flatten(2).transpose(1, 2)
+    n = t.shape[0]
+    t = torch.cat([g["class_token"].expand(n, -1, -1), t], dim=1)
+    c = t.shape[-1]
+    idx = idx_mask.unsqueeze(-1).expand(-1, -1, c)
+    t = t.scatter(1, idx, sd["mask_token"].expand(n, idx_mask.shape[1], c))
+    t = t + g["encoder.pos_embedding"]
+    t = _tv_layers(t, g, "encoder.layers.", heads)
+    t = F.layer_norm(t, (c,), g["encoder.ln.weight"], g["encoder.ln.bias"], 1e-6)
+    pred = F.linear(torch.gather(t, 1, idx), sd["decoder.weight"], sd["decoder.bias"])
+    patches = lightly_patchify(images, p)
+    target = torch.gather(patches, 1, (idx_mask - 1).unsqueeze(-1).expand(-1, -1, patches.shape[-1]))
+    return F.l1_loss(pred, target)

@@ -160,6 +160,7 @@ SIGNATURES = {
     "wm_gather_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_scatter_rows": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_mse_fwd_bwd": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
+    "wm_l1_fwd_bwd": (c_int, [c_void_p, c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
     "wm_dino_teacher_probs": (c_int, [c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p, c_void_p]),
     "wm_dino_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                      c_void_p]),

@@ -370,6 +370,7 @@ __global__ __launch_bounds__(TF_THREADS) void rows_by_index(const uint16_t* __re
   }
 }
 
+template <bool L1>
 __global__ __launch_bounds__(TF_THREADS) void mse_kernel(const uint16_t* __restrict__ pred,
                                                          const uint16_t* __restrict__ target, long long n,
                                                          float* __restrict__ loss, uint16_t* __restrict__ dpred) {
@@ -384,8 +385,13 @@ __global__ __launch_bounds__(TF_THREADS) void mse_kernel(const uint16_t* __restr
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
       const float df = a[e] - b[e];
-      s = fmaf(df, df, s);
-      d[e] = 2.f * df * inv;
+      if (L1) {
+        s += fabsf(df);
+        d[e] = df > 0.f ? inv : (df < 0.f ? -inv : 0.f);
+      } else {
+        s = fmaf(df, df, s);
+        d[e] = 2.f * df * inv;
+      }
     }
     *reinterpret_cast<uint4*>(dpred + t * 8) = pack8(d);
   }
@@ -775,7 +781,19 @@ extern "C" int wm_mse_fwd_bwd(const void* pred, const void* target, long long n,
   WM_REQUIRE(pred && target && loss && dpred, WM_EINVAL);
   WM_REQUIRE(n > 0 && n % 8 == 0, WM_EINVAL);
   WM_REQUIRE(al16(pred) && al16(target) && al16(dpred), WM_EALIGN);
-  mse_kernel<<<ew_blocks(n >> 3) > 1024 ? 1024 : ew_blocks(n >> 3), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+  mse_kernel<false><<<ew_blocks(n >> 3) > 1024 ? 1024 : ew_blocks(n >> 3), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(pred), static_cast<const uint16_t*>(target), n, loss,
+      static_cast<uint16_t*>(dpred));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_l1_fwd_bwd(const void* pred, const void* target, long long n, float* loss, void* dpred,
+                             void* stream) {
+  WM_REQUIRE(pred && target && loss && dpred, WM_EINVAL);
+  WM_REQUIRE(n > 0 && n % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(al16(pred) && al16(target) && al16(dpred), WM_EALIGN);
+  mse_kernel<true><<<ew_blocks(n >> 3) > 1024 ? 1024 : ew_blocks(n >> 3), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
       static_cast<const uint16_t*>(pred), static_cast<const uint16_t*>(target), n, loss,
       static_cast<uint16_t*>(dpred));
   WM_LAUNCH_CHECK();

@@ -107,11 +107,20 @@ class MAEBackbone(nn.Module):
     def from_vit(cls, vit) -> "MAEBackbone":
         return cls(vit.image_size, vit.patch_size, vit.num_layers, vit.num_heads, vit.hidden_dim, vit.mlp_dim)
 
-    def images_to_tokens(self, images):
-        """[B,3,S,S] -> bf16 [B*seq, D] rows: class token prepended, positional embedding added."""
+    def images_to_tokens(self, images, add_pos: bool = True):
+        """[B,3,S,S] -> bf16 [B*seq, D] rows: class token prepended; the positional embedding is added here
+        (add_pos) or later by `encode_tokens` (lightly's encoder adds it: SimMIM masks tokens before that)."""
         n = images.shape[0]
         patches = self.conv_proj(images)
-        return vit_ops.tokens_assemble(patches, self.class_token, self.encoder.pos_embedding, n, self.seq_length - 1)
+        pos = self.encoder.pos_embedding if add_pos else torch.zeros_like(self.encoder.pos_embedding)
+        return vit_ops.tokens_assemble(patches, self.class_token, pos, n, self.seq_length - 1)
+
+    def encode_tokens(self, tokens, batch: int):
+        """lightly MAEEncoder.forward(tokens): + positional embedding, encoder blocks, final LayerNorm."""
+        seq, c = self.seq_length, self.hidden_dim
+        pos = self.encoder.pos_embedding.to(torch.bfloat16).expand(batch, seq, c).reshape(batch * seq, c)
+        t = vit_ops.bias_act(tokens.reshape(batch * seq, c), None, vit_ops.ACT_NONE, residual=pos)
+        return self.encoder.run_layers(t, batch, seq).view(batch, seq, c)
 
     def encode(self, images, idx_keep=None):
         """All kept tokens after the encoder: [B, K, D] (lightly MAEBackbone.encode)."""
@@ -225,3 +234,52 @@ class MAE(KNNBenchmarkModule):
         opt = optim.AdamW(self.parameters(), lr=1.5e-4 * self.lr_factor, weight_decay=0.05, betas=(0.9, 0.95))
         cosine = scheduler.CosineWarmupScheduler(opt, self.warmup_epochs, self.max_epochs)
         return [opt], [cosine]
+
+
+class SimMIM(KNNBenchmarkModule):
+    """SimMIM on ViT-B/32 (scripts/WM811k_benchmark.py:960-1030): every token goes through the encoder, the
+    masked ones replaced by a learned mask token BEFORE the positional embedding is added; a Linear decoder
+    predicts the masked patches; L1 loss; AdamW lr 8e-4 x bs/256."""
+
+    def __init__(self, dataloader_kNN=None, num_classes=9, batch_size: int = 64, max_epochs: int = 150, **kwargs):
+        kwargs.pop("log_rep_std", None)
+        super().__init__(dataloader_kNN, num_classes, **kwargs)
+        vit = vit_b_32()
+        self.warmup_epochs = 40 if max_epochs >= 800 else 20
+        self.mask_ratio = 0.75
+        self.patch_size = vit.patch_size
+        self.sequence_length = vit.seq_length
+        self.mask_token = nn.Parameter(torch.zeros(1, 1, vit.hidden_dim))
+        self.backbone = MAEBackbone.from_vit(vit)
+        self.decoder = hnn.Linear(vit.hidden_dim, vit.patch_size ** 2 * 3, bias=True)
+        self.lr_factor = batch_size / 256
+        self.max_epochs = max_epochs
+
+    def criterion(self, pred, target):
+        return vit_ops.l1_loss(pred.reshape(-1, pred.shape[-1]), target.reshape(-1, target.shape[-1]))
+
+    def forward_encoder(self, images, batch_size, idx_mask):
+        tokens = self.backbone.images_to_tokens(images, add_pos=False).view(batch_size, self.sequence_length, -1)
+        tokens_masked = model_utils.mask_at_index(tokens, idx_mask, self.mask_token)
+        return self.backbone.encode_tokens(tokens_masked, batch_size)
+
+    def forward_decoder(self, x_encoded):
+        b, k, c = x_encoded.shape
+        return self.decoder(x_encoded.reshape(b * k, c)).view(b, k, -1)
+
+    def training_step(self, batch, batch_idx, generator: torch.Generator = None):
+        images = batch[0][0]
+        batch_size = images.shape[0]
+        _, idx_mask = model_utils.random_token_mask(size=(batch_size, self.sequence_length), mask_ratio=self.mask_ratio,
+                                                    device=images.device, generator=generator)
+        x_encoded = self.forward_encoder(images, batch_size, idx_mask)
+        x_out = self.forward_decoder(model_utils.get_at_index(x_encoded, idx_mask))
+        patches = model_utils.patchify(images, self.patch_size)
+        target = model_utils.get_at_index(patches, idx_mask - 1)
+        loss = self.criterion(x_out, target)
+        self.log("train_loss_ssl", loss)
+        return loss
+
+    def configure_optimizers(self):
+        opt = optim.AdamW(self.parameters(), lr=8e-4 * self.lr_factor, weight_decay=0.05, betas=(0.9, 0.999))
+        return [opt], [scheduler.CosineWarmupScheduler(opt, self.warmup_epochs, self.max_epochs)]

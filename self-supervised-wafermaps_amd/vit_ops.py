@@ -360,15 +360,16 @@ def scatter_rows(base: torch.Tensor, src: torch.Tensor, idx: torch.Tensor, batch
 
 class _MSE(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, pred, target):
+    def forward(ctx, pred, target, l1=False):
         _need_cuda(pred, "mse_loss")
         pred, target = _bf16_rows(pred), _bf16_rows(target)
         if pred.shape != target.shape or pred.numel() % 8:
             raise ValueError(f"mse_loss: {tuple(pred.shape)} vs {tuple(target.shape)}")
         loss = torch.zeros(1, dtype=torch.float32, device=pred.device)
         dpred = torch.empty_like(pred)
-        check(_lib.load().wm_mse_fwd_bwd(ptr(pred), ptr(target), pred.numel(), ptr(loss), ptr(dpred), stream_ptr()),
-              "wm_mse_fwd_bwd")
+        fn = _lib.load().wm_l1_fwd_bwd if l1 else _lib.load().wm_mse_fwd_bwd
+        check(fn(ptr(pred), ptr(target), pred.numel(), ptr(loss), ptr(dpred), stream_ptr()),
+              "wm_l1_fwd_bwd" if l1 else "wm_mse_fwd_bwd")
         ctx.save_for_backward(dpred)
         return loss[0]
 
@@ -376,12 +377,17 @@ class _MSE(torch.autograd.Function):
     def backward(ctx, g):
         (dpred,) = ctx.saved_tensors
         d = (dpred.float() * g).to(torch.bfloat16)
-        return d, (-d if ctx.needs_input_grad[1] else None)
+        return d, (-d if ctx.needs_input_grad[1] else None), None
 
 
 def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """nn.MSELoss() (mean) on bf16 tensors; the gradient is produced in the same pass."""
-    return _MSE.apply(pred, target)
+    return _MSE.apply(pred, target, False)
+
+
+def l1_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """nn.L1Loss() (mean) on bf16 tensors."""
+    return _MSE.apply(pred, target, True)
 
 
 class _DinoLoss(torch.autograd.Function):
