@@ -325,6 +325,12 @@ int wm_barlow_twins_fwd_bwd(const float* raw_cc, int D, float scale, float lambd
 int wm_center_columns(const void* z, const float* mean, long long rows, int C, void* out, void* stream);
 int wm_vicreg_variance(const float* var_biased, int N, int D, float eps, float* loss, float* coef, void* stream);
 
+/* lightly's SwaV Sinkhorn-Knopp (scripts/WM811k_benchmark.py:832-834 via lightly.loss.SwaVLoss): out WM_F32 / WM_BF16
+ * [B][K] prototype scores; Q [B][K] f32 = the transport plan (rows sum to 1) after `iters` rounds at
+ * temperature eps; workspace: B + K floats. */
+int wm_sinkhorn(const void* out, int dtype, int B, int K, float eps, int iters, float* Q, float* workspace,
+                void* stream);
+
 /* NT-Xent against a memory bank (lightly NTXentLoss(memory_bank_size > 0), the reference's MoCo:
  * scripts/WM811k_benchmark.py:305-307).  q, kpos: L2-normalised [B][D] float32; bank [D][K] float32
  * (lightly's layout, one stored key per column).  logits_i = [<q_i,kpos_i>, <q_i,bank>] / T, label 0.
@@ -409,8 +415,9 @@ int wm_colstats(const void* x, int dtype, long long rows, int C, float* mean, fl
 int wm_standardize(const void* x, int dtype, long long rows, int C, const float* mean, const float* inv_scale,
                    float* out, void* stream);
 
-/* torch.optim.AdamW step over flat f32 arenas; hyper = DEVICE {lr, beta1, beta2, eps, weight_decay,
- * bias_correction1, bias_correction2, grad_scale}. */
+/* torch.optim.AdamW / Adam step over flat f32 arenas; hyper = DEVICE {lr, beta1, beta2, eps, weight_decay,
+ * bias_correction1, bias_correction2, grad_scale, l2_mode}: l2_mode 0 = decoupled decay (AdamW), 1 = the
+ * decay added to the gradient (torch.optim.Adam). */
 int wm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_avg_sq, long long n,
                   const float* hyper, void* stream);
 /* lightly update_momentum: ema = ema * m + p * (1 - m). */

@@ -129,3 +129,31 @@ def vicreg_loss(z_a, z_b, lambda_param=25.0, mu_param=25.0, nu_param=1.0, eps=1e
 
     return (lambda_param * F.mse_loss(z_a, z_b) + mu_param * 0.5 * (variance(z_a) + variance(z_b))
             + nu_param * (covariance(z_a) + covariance(z_b)))
+
+
+def sinkhorn(out, iterations=3, epsilon=0.05):
+    """lightly.loss.swav_loss.sinkhorn (single process), after Caron et al. 2020 (arXiv:2006.09882, Listing 1)."""
+    q = torch.exp(out / epsilon).t()
+    q = q / q.sum()
+    k, b = q.shape
+    for _ in range(iterations):
+        q = q / q.sum(dim=1, keepdim=True) / k
+        q = q / q.sum(dim=0, keepdim=True) / b
+    return (q * b).t()
+
+
+def swav_loss(high, low, temperature=0.1, iterations=3, epsilon=0.05):
+    """lightly SwaVLoss.forward without a queue.  PARITY UNPINNED upstream."""
+    n_crops = len(high) + len(low)
+    loss = 0.0
+    for i in range(len(high)):
+        with torch.no_grad():
+            q = sinkhorn(high[i].detach(), iterations, epsilon)
+        sub = 0.0
+        for v in range(len(high)):
+            if v != i:
+                sub = sub - torch.mean(torch.sum(q * F.log_softmax(high[v] / temperature, dim=1), dim=1))
+        for v in range(len(low)):
+            sub = sub - torch.mean(torch.sum(q * F.log_softmax(low[v] / temperature, dim=1), dim=1))
+        loss = loss + sub / (n_crops - 1)
+    return loss / len(high)

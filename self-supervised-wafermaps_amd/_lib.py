@@ -140,6 +140,7 @@ SIGNATURES = {
     "wm_center_columns": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p]),
     "wm_vicreg_variance": (c_int, [c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
     "wm_lars_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "wm_sinkhorn": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_int, c_void_p, c_void_p, c_void_p]),
     "wm_dcl_workspace_bytes": (c_size_t, [c_int]),
     "wm_dcl_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_size_t, c_void_p]),

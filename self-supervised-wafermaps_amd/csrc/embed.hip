@@ -775,3 +775,80 @@ extern "C" int wm_vicreg_variance(const float* var_biased, int N, int D, float e
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
+
+// ------------------------------------------------------------------------------------ SwaV Sinkhorn
+// lightly.loss.swav_loss.sinkhorn (the reference's SwaV, scripts/WM811k_benchmark.py:832-834): Q = exp(out / eps)^T,
+// then `iters` rounds of { every prototype's row sums to 1/K ; every sample's column sums to 1/B }, finally * B.
+// E = exp(out / eps) stays fixed; the normalisations only rescale prototypes (c[k]) and samples (r[b]):
+// Q[b][k] = E[b][k] r[b] c[k].  Two tiny reductions per round, one launch each.
+namespace {
+template <typename T>
+__global__ __launch_bounds__(256) void sk_proto_kernel(const T* __restrict__ out, const float* __restrict__ r, int B, int K,
+                                                       float inv_eps, float* __restrict__ c) {
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= K) return;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) s = fmaf(expf(nc_ld<T>(out, (size_t)b * K + k) * inv_eps), r[b], s);
+  c[k] = 1.f / (s * (float)K);   // after this, sum_b E r c = 1 / K for every prototype
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sk_sample_kernel(const T* __restrict__ out, const float* __restrict__ c, int B, int K,
+                                                        float inv_eps, float* __restrict__ r) {
+  __shared__ float red[4];
+  const int b = blockIdx.x;
+  float s = 0.f;
+  for (int k = threadIdx.x; k < K; k += 256) s = fmaf(expf(nc_ld<T>(out, (size_t)b * K + k) * inv_eps), c[k], s);
+  s = wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) r[b] = 1.f / ((red[0] + red[1] + red[2] + red[3]) * (float)B);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void sk_write_kernel(const T* __restrict__ out, const float* __restrict__ r,
+                                                       const float* __restrict__ c, int B, int K, float inv_eps,
+                                                       float* __restrict__ Q) {
+  const long long n = (long long)B * K;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    const int b = (int)(i / K), k = (int)(i - (long long)b * K);
+    Q[i] = expf(nc_ld<T>(out, (size_t)i) * inv_eps) * r[b] * c[k] * (float)B;
+  }
+}
+
+__global__ void sk_fill_kernel(float* p, int n, float v) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) p[i] = v;
+}
+
+template <typename T>
+int sinkhorn_impl(const void* out, int B, int K, float eps, int iters, float* Q, float* ws, hipStream_t st) {
+  const T* x = static_cast<const T*>(out);
+  float* r = ws;
+  float* c = ws + B;
+  const float inv = 1.f / eps;
+  // r = 1, c = 1 (the initial Q /= sum(Q) is absorbed by the first prototype pass; iters = 0 leaves exp * B)
+  sk_fill_kernel<<<wm_cdiv(B + K, 256), 256, 0, st>>>(ws, B + K, 1.f);
+  WM_LAUNCH_CHECK();
+  for (int it = 0; it < iters; ++it) {
+    sk_proto_kernel<T><<<wm_cdiv(K, 256), 256, 0, st>>>(x, r, B, K, inv, c);
+    WM_LAUNCH_CHECK();
+    sk_sample_kernel<T><<<B, 256, 0, st>>>(x, c, B, K, inv, r);
+    WM_LAUNCH_CHECK();
+  }
+  const long long n = (long long)B * K;
+  sk_write_kernel<T><<<(int)((n + 255) / 256 > 2048 ? 2048 : (n + 255) / 256), 256, 0, st>>>(x, r, c, B, K, inv, Q);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+}  // namespace
+
+extern "C" int wm_sinkhorn(const void* out, int dtype, int B, int K, float eps, int iters, float* Q, float* workspace,
+                           void* stream) {
+  WM_REQUIRE(out && Q && workspace, WM_EINVAL);
+  WM_REQUIRE(B > 0 && K > 0 && eps > 0.f && iters >= 0 && iters <= 100, WM_EINVAL);
+  WM_REQUIRE(dtype == WM_F32 || dtype == WM_BF16, WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  return dtype == WM_F32 ? sinkhorn_impl<float>(out, B, K, eps, iters, Q, workspace, st)
+                         : sinkhorn_impl<uint16_t>(out, B, K, eps, iters, Q, workspace, st);
+}

@@ -558,10 +558,13 @@ __global__ __launch_bounds__(TF_THREADS) void adamw_kernel(float* __restrict__ p
                                                            const float* __restrict__ hyper) {
   const float lr = hyper[0], b1 = hyper[1], b2 = hyper[2], eps = hyper[3], wd = hyper[4], bc1 = hyper[5],
               bc2s = sqrtf(hyper[6]), gs = hyper[7];
+  const bool l2 = hyper[8] != 0.f;  // torch.optim.Adam: weight decay is added to the gradient, not decoupled
   const float step = lr / bc1;
   for (long long i = (long long)blockIdx.x * TF_THREADS + threadIdx.x; i < n; i += (long long)gridDim.x * TF_THREADS) {
-    const float gi = g[i] * gs;
-    float pi = p[i] * (1.f - lr * wd);
+    float gi = g[i] * gs;
+    float pi = p[i];
+    if (l2) gi = fmaf(wd, pi, gi);
+    else pi *= 1.f - lr * wd;
     const float mi = b1 * m[i] + (1.f - b1) * gi;
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     pi -= step * mi / (sqrtf(vi) / bc2s + eps);

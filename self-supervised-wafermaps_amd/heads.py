@@ -76,6 +76,32 @@ class MoCoProjectionHead(ProjectionHead):
         super().__init__([(input_dim, hidden_dim, None, hnn.ReLU()), (hidden_dim, output_dim, None, None)])
 
 
+class SwaVProjectionHead(ProjectionHead):
+    """lightly SwaVProjectionHead: Linear-BN-ReLU, Linear(+bias)  (reference: (512, 2048, 128), :830)."""
+
+    def __init__(self, input_dim: int = 2048, hidden_dim: int = 2048, output_dim: int = 128):
+        super().__init__([(input_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.ReLU()),
+                          (hidden_dim, output_dim, None, None)])
+
+
+class SwaVPrototypes(nn.Module):
+    """lightly SwaVPrototypes(input_dim, n_prototypes): a bias-free Linear (state_dict key `layers.weight`) whose
+    rows `normalize()` puts on the unit sphere (reference: (128, 3000), :831, :846)."""
+
+    def __init__(self, input_dim: int = 128, n_prototypes: int = 3000):
+        super().__init__()
+        self.layers = hnn.Linear(input_dim, n_prototypes, bias=False)
+
+    def forward(self, x):
+        return self.layers(x)
+
+    @torch.no_grad()
+    def normalize(self) -> None:
+        w = self.layers.weight
+        w.copy_(F_hip.l2_normalize(w.detach().contiguous()))
+        ops.bump_weight_epoch()
+
+
 class BarlowTwinsProjectionHead(ProjectionHead):
     """lightly BarlowTwinsProjectionHead: (Linear-BN-ReLU) x2, Linear(+bias)  (reference: (512, 2048, 2048), :363, :400)."""
 

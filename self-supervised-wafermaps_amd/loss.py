@@ -429,6 +429,52 @@ class VICRegLoss(nn.Module):
         return self.lambda_param * inv + branch
 
 
+def sinkhorn(out: torch.Tensor, iterations: int = 3, epsilon: float = 0.05, gather_distributed: bool = False) -> torch.Tensor:
+    """lightly.loss.swav_loss.sinkhorn: [B, K] prototype scores -> [B, K] float32 assignment (rows sum to 1)."""
+    from . import _lib
+    from ._lib import check, dtype_code, ptr, stream_ptr
+
+    if gather_distributed and _world() > 1:
+        raise NotImplementedError("sinkhorn(gather_distributed=True) is not built")
+    x = out.detach()
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        x = x.float()
+    x = x.contiguous()
+    b, k = x.shape
+    q = torch.empty((b, k), dtype=torch.float32, device=x.device)
+    ws = torch.empty(b + k, dtype=torch.float32, device=x.device)
+    check(_lib.load().wm_sinkhorn(ptr(x), dtype_code(x), b, k, float(epsilon), int(iterations), ptr(q), ptr(ws),
+                                  stream_ptr()), "wm_sinkhorn")
+    return q
+
+
+class SwaVLoss(nn.Module):
+    """lightly.loss.SwaVLoss(temperature=0.1, sinkhorn_iterations=3, sinkhorn_epsilon=0.05): for every
+    high-resolution crop i the Sinkhorn assignment q_i of its prototype scores is the target of all OTHER
+    crops' softmax(scores / T); mean over the pairs and the batch.  That is the DINO loss kernel with q_i as
+    the teacher probabilities (same pairing rule, same normalisation)."""
+
+    def __init__(self, temperature: float = 0.1, sinkhorn_iterations: int = 3, sinkhorn_epsilon: float = 0.05,
+                 sinkhorn_gather_distributed: bool = False):
+        super().__init__()
+        if sinkhorn_gather_distributed and _world() > 1:
+            raise NotImplementedError("SwaVLoss(sinkhorn_gather_distributed=True) is not built")
+        self.temperature = temperature
+        self.sinkhorn_iterations = sinkhorn_iterations
+        self.sinkhorn_epsilon = sinkhorn_epsilon
+
+    def forward(self, high_resolution_outputs, low_resolution_outputs, queue_outputs=None):
+        from . import vit_ops
+
+        if queue_outputs is not None:
+            raise NotImplementedError("SwaVLoss: queue_outputs is not built (the reference passes none)")
+        high, low = list(high_resolution_outputs), list(low_resolution_outputs)
+        b = high[0].shape[0]
+        probs = torch.cat([sinkhorn(h, self.sinkhorn_iterations, self.sinkhorn_epsilon) for h in high], dim=0)
+        student = torch.cat(high + low, dim=0)
+        return vit_ops.dino_loss(student, probs, len(high) + len(low), len(high), b, self.temperature)
+
+
 class DINOLoss(nn.Module):
     """lightly.loss.DINOLoss as the reference calls it (scripts/WM811k_benchmark.py:564,586:
     `DINOLoss(output_dim=2048)`, `criterion(teacher_out, student_out, epoch=...)`).

@@ -10,3 +10,4 @@ from .evals import LinearClassifier, MultilabelLinearClassifier, SupervisedR18, 
 from .dclw import DCLW  # noqa: F401
 from .barlow import BarlowTwins  # noqa: F401
 from .vicreg import VICReg  # noqa: F401
+from .swav import SwaV  # noqa: F401

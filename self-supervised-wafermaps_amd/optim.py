@@ -94,12 +94,13 @@ class AdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay))
         self.grad_scale = float(grad_scale)
+        self._l2 = False
         self._arenas, self._hyper, self._steps = [], [], []
         for group in self.param_groups:
             ps = [p for p in group["params"] if p.requires_grad]
             arena = _Arena(ps, second_moment=True)
             self._arenas.append(arena)
-            self._hyper.append(torch.zeros(8, dtype=torch.float32, device=arena.params.device))
+            self._hyper.append(torch.zeros(9, dtype=torch.float32, device=arena.params.device))
             self._steps.append(0)
         ops.bump_weight_epoch()
 
@@ -120,7 +121,7 @@ class AdamW(torch.optim.Optimizer):
             t = self._steps[i]
             b1, b2 = group["betas"]
             h = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
-                 1.0 - b1 ** t, 1.0 - b2 ** t, self.grad_scale)
+                 1.0 - b1 ** t, 1.0 - b2 ** t, self.grad_scale, 1.0 if self._l2 else 0.0)
             hyper.copy_(torch.tensor(h, dtype=torch.float32), non_blocking=False)
             check(lib.wm_adamw_step(ptr(arena.params), ptr(arena.grads), ptr(arena.momentum), ptr(arena.second),
                                     arena.numel, ptr(hyper), stream_ptr()), "wm_adamw_step")
@@ -176,3 +177,13 @@ class LARS(torch.optim.Optimizer):
                                    ptr(hyper), ptr(norms), stream_ptr()), "wm_lars_step")
         ops.bump_weight_epoch()
         return loss
+
+
+class Adam(AdamW):
+    """torch.optim.Adam: the same kernel with the weight decay added to the gradient (L2) instead of decoupled
+    (the reference's SwaV: Adam(lr 1e-3 x bs/256, weight_decay 1e-6), scripts/WM811k_benchmark.py:866-871)."""
+
+    def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 0.0,
+                 grad_scale: float = 1.0):
+        super().__init__(params, lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, grad_scale=grad_scale)
+        self._l2 = True

@@ -500,3 +500,49 @@ def test_vicreg_loss_matches_oracle():
         c = torch.nn.functional.cosine_similarity(got.float().cpu().flatten(), want.flatten(), dim=0)
         assert float(c) > 0.995, float(c)
         assert float((got.float().cpu() - want).abs().max()) < 0.05 * float(want.abs().max())
+
+
+def test_sinkhorn_and_swav_loss_match_oracle():
+    from ssl_wafermap_amd.loss import SwaVLoss, sinkhorn
+
+    g = torch.Generator().manual_seed(23)
+    b, k = 48, 3000
+    high = [torch.randn(b, k, generator=g).clamp(-1, 1) * 0.9 for _ in range(2)]   # prototype scores are cosines
+    low = [torch.randn(b, k, generator=g).clamp(-1, 1) * 0.9 for _ in range(3)]
+    q = sinkhorn(high[0].to("cuda:0"))
+    qr = on.sinkhorn(high[0])
+    assert torch.allclose(q.sum(1).cpu(), torch.ones(b), atol=1e-4)
+    assert torch.allclose(q.cpu(), qr, rtol=1e-3, atol=1e-7)
+    hr = [t.clone().requires_grad_(True) for t in high]
+    lr = [t.clone().requires_grad_(True) for t in low]
+    ref = on.swav_loss(hr, lr)
+    ref.backward()
+    hd = [t.to("cuda:0").requires_grad_(True) for t in high]
+    ld = [t.to("cuda:0").requires_grad_(True) for t in low]
+    loss = SwaVLoss().to("cuda:0")(hd, ld)
+    loss.backward()
+    # the loss kernel reads bf16 student scores
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 2e-3 * abs(float(ref.detach())), (float(loss), float(ref))
+    for got, want in zip(hd + ld, hr + lr):
+        c = torch.nn.functional.cosine_similarity(got.grad.float().cpu().flatten(), want.grad.flatten(), dim=0)
+        assert float(c) > 0.99, float(c)
+
+
+def test_adam_with_l2_weight_decay_matches_torch():
+    from ssl_wafermap_amd import optim
+
+    torch.manual_seed(9)
+    shapes = [(96, 64), (64,), (3, 5, 7)]
+    ps = [torch.nn.Parameter(torch.randn(*s_, device="cuda:0")) for s_ in shapes]
+    ref = [torch.nn.Parameter(p.detach().clone()) for p in ps]
+    topt = torch.optim.Adam(ref, lr=2e-3, weight_decay=1e-2)
+    opt = optim.Adam(ps, lr=2e-3, weight_decay=1e-2)
+    for _ in range(4):
+        for p, r in zip(ps, ref):
+            gval = torch.randn_like(r)
+            r.grad = gval.clone()
+            p.grad.copy_(gval)
+        opt.step()
+        topt.step()
+    for p, r in zip(ps, ref):
+        torch.testing.assert_close(p.detach(), r.detach(), rtol=2e-5, atol=2e-6)

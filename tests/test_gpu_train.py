@@ -306,3 +306,37 @@ def test_barlow_twins_step_matches_oracle_and_lars_moves_it():
         loss = model.training_step(batch, i + 1)
         loss.backward()
     assert math.isfinite(float(loss.detach())) and float(loss.detach()) < first
+
+
+def test_swav_step_runs_and_matches_oracle_loss():
+    from oracle import ntxent as ont
+    from oracle import resnet as orn
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models import SwaV
+
+    torch.manual_seed(0)
+    b = 8
+    model = SwaV(None, 9, batch_size=b, log_rep_std=False).to(DEV).train()
+    (opt,), _ = model.configure_optimizers()
+    g = torch.Generator().manual_seed(5)
+    views = [torch.randn(b, 3, 224, 224, generator=g).bfloat16().float() for _ in range(2)] + \
+            [torch.randn(b, 3, 96, 96, generator=g).bfloat16().float() for _ in range(2)]
+    model.prototypes.normalize()
+    sd = {k: v.detach().float().cpu().clone() for k, v in model.state_dict().items()}
+
+    def scores(x):
+        f = orn.resnet18_features(x, sd, True, prefix="backbone.")
+        z = orn.byol_head(f, sd, "projection_head.")  # Linear-BN-ReLU, Linear(+bias): the same layer layout
+        return torch.nn.functional.linear(torch.nn.functional.normalize(z, dim=1), sd["prototypes.layers.weight"])
+
+    with torch.no_grad():
+        outs = [scores(v) for v in views]
+        ref = ont.swav_loss(outs[:2], outs[2:])
+    opt.zero_grad()
+    loss = model.training_step(([ops.to_nhwc_bf16(v.to(DEV)) for v in views], None), 0)
+    loss.backward()
+    opt.step()
+    # exp(score / 0.05) amplifies the bf16 encoder's score error 20-fold inside Sinkhorn
+    assert abs(float(loss.detach()) - float(ref)) <= 5e-2 * abs(float(ref)), (float(loss), float(ref))
+    norms = model.prototypes.layers.weight.detach().norm(dim=1)
+    assert norms.shape == (3000,)
