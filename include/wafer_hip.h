@@ -403,6 +403,16 @@ int wm_dino_teacher_probs(const void* teacher, const float* center, float temp_t
  * / (n_terms * B); dstudent = d loss / d student (bf16).  Views with equal index are the same crop. */
 int wm_dino_loss_fwd_bwd(const void* student, const float* probs, int Vs, int Vt, int B, int D, float temp_s,
                          float* loss, void* dstudent, void* stream);
+/* Cross-entropy against soft targets (MSN / PMSN, scripts/WM811k_benchmark.py:684,705): student [Vs][B][D] bf16 logits,
+ * probs [B][D] f32 targets shared by the Vs views; loss[0] += mean over (view, sample) of
+ * -<probs_b, log_softmax(student_vb / temp_s)>; dstudent bf16. */
+int wm_soft_cross_entropy_fwd_bwd(const void* student, const float* probs, int Vs, int B, int D, float temp_s,
+                                  float* loss, void* dstudent, void* stream);
+/* Mean-entropy regulariser of lightly's MSNLoss / PMSNLoss on logits [N][K] bf16: p = softmax(logits / T),
+ * m = mean over rows; loss[0] += sum_k m_k (log m_k - log_prior_k) (log_prior NULL: MSN's me-max term
+ * sum m log m); dlogits [N][K] f32; mean_ws: K floats of scratch. */
+int wm_mean_entropy_reg_fwd_bwd(const void* logits, const float* log_prior, int N, int K, float temperature,
+                                float* loss, float* dlogits, float* mean_ws, void* stream);
 /* center = momentum * center + (1 - momentum) * mean over rows of teacher[rows][D]. */
 int wm_dino_center_update(const void* teacher, long long rows, int D, float momentum, float* center, void* stream);
 

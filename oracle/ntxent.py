@@ -157,3 +157,39 @@ def swav_loss(high, low, temperature=0.1, iterations=3, epsilon=0.05):
             sub = sub - torch.mean(torch.sum(q * F.log_softmax(low[v] / temperature, dim=1), dim=1))
         loss = loss + sub / (n_crops - 1)
     return loss / len(high)
+
+
+def msn_loss(anchors, targets, prototypes, temperature=0.1, sinkhorn_iterations=3, regularization_weight=1.0,
+             target_sharpen_temperature=0.25, power_law_exponent=None):
+    """lightly MSNLoss / PMSNLoss (Assran et al. 2022, arXiv:2204.07141; PMSN: Assran et al. 2023, arXiv:2210.07277),
+    single process.  power_law_exponent None -> MSN's mean-entropy maximisation, else PMSN's KL to the power-law
+    prior.  PARITY UNPINNED upstream."""
+    num_views = anchors.shape[0] // targets.shape[0]
+    anchors = F.normalize(anchors, dim=1)
+    targets = F.normalize(targets, dim=1)
+    prototypes = F.normalize(prototypes, dim=1)
+    anchor_probs = F.softmax(anchors @ prototypes.t() / temperature, dim=1)
+    with torch.no_grad():
+        tp = F.softmax(targets @ prototypes.t() / temperature, dim=1)
+        tp = tp ** (1.0 / target_sharpen_temperature)
+        tp = tp / tp.sum(dim=1, keepdim=True)
+        if sinkhorn_iterations > 0:
+            q = tp.t()
+            q = q / q.sum()
+            k, b = q.shape
+            for _ in range(sinkhorn_iterations):
+                q = q / q.sum(dim=1, keepdim=True) / k
+                q = q / q.sum(dim=0, keepdim=True) / b
+            tp = (q * b).t()
+        tp = tp.repeat(num_views, 1)  # view-major: all samples of view 0, then view 1, ...
+    loss = torch.mean(torch.sum(-tp * torch.log(anchor_probs), dim=1))
+    if regularization_weight > 0:
+        m = anchor_probs.mean(dim=0)
+        if power_law_exponent is None:
+            reg = torch.sum(m * torch.log(m))
+        else:
+            prior = 1.0 / torch.arange(1, m.shape[0] + 1, dtype=torch.float64) ** power_law_exponent
+            prior = (prior / prior.sum()).to(m.dtype)
+            reg = torch.sum(m * (torch.log(m) - torch.log(prior)))
+        loss = loss + regularization_weight * reg
+    return loss

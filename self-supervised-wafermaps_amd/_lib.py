@@ -165,6 +165,9 @@ SIGNATURES = {
     "wm_dino_teacher_probs": (c_int, [c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p, c_void_p]),
     "wm_dino_loss_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p,
                                      c_void_p]),
+    "wm_soft_cross_entropy_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p]),
+    "wm_mean_entropy_reg_fwd_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p,
+                                            c_void_p]),
     "wm_dino_center_update": (c_int, [c_void_p, c_longlong, c_int, c_float, c_void_p, c_void_p]),
     "wm_knn_topk_general_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "wm_knn_topk_general": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,

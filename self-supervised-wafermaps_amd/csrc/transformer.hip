@@ -463,8 +463,8 @@ __global__ __launch_bounds__(TF_THREADS) void dino_teacher_probs(const uint16_t*
 //   loss -= <p_t, lsm> * w;   dx += w/T * (softmax(x/T) - p_t),   w = 1 / (n_terms * B)
 __global__ __launch_bounds__(TF_THREADS) void dino_loss_kernel(const uint16_t* __restrict__ student,
                                                                const float* __restrict__ probs, int Vs, int Vt, int B,
-                                                               int D, float inv_temp, float w, float* __restrict__ loss,
-                                                               uint16_t* __restrict__ dstudent) {
+                                                               int D, float inv_temp, float w, int skip_same,
+                                                               float* __restrict__ loss, uint16_t* __restrict__ dstudent) {
   __shared__ float red[4];
   const int s = blockIdx.x / B, b = blockIdx.x % B;
   const long long row = (long long)s * B + b;
@@ -502,7 +502,7 @@ __global__ __launch_bounds__(TF_THREADS) void dino_loss_kernel(const uint16_t* _
 #pragma unroll
     for (int e = 0; e < 8; ++e) g[i][e] = 0.f;
   for (int t = 0; t < Vt; ++t) {
-    if (t == s) continue;
+    if (skip_same && t == s) continue;
     ++nt;
     const float* p = probs + ((size_t)t * B + b) * D;
 #pragma unroll
@@ -531,6 +531,118 @@ __global__ __launch_bounds__(TF_THREADS) void dino_loss_kernel(const uint16_t* _
       for (int e = 0; e < 8; ++e) o[e] = k * ((float)nt * expf(v[i][e] - lse) + g[i][e]);
       *reinterpret_cast<uint4*>(dstudent + row * D + ch * 8) = pack8(o);
     }
+  }
+}
+
+// Mean-entropy regulariser of MSN / PMSN on rows of logits x [N][K] (bf16): p = softmax(x / T), m = mean_rows p,
+//   reg = sum_k m_k (log m_k - log prior_k)      (prior NULL: the me-max term sum m log m of MSN)
+//   d reg / d x[i][k] = p_ik (u_k - sum_j p_ij u_j) / (N T),  u_k = log m_k - log prior_k + 1.
+// Pass 1 accumulates m (one block per row, f32 atomics); pass 2 forms the gradient and the scalar.
+__global__ __launch_bounds__(TF_THREADS) void memax_mean_kernel(const uint16_t* __restrict__ x, int K, float inv_temp,
+                                                                float inv_n, float* __restrict__ m) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const int nch = K >> 3;
+  float v[DL_MAXV][8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i) {
+    const int ch = threadIdx.x + TF_THREADS * i;
+    if (ch < nch) {
+      unpack8(*reinterpret_cast<const uint4*>(x + row * K + ch * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] *= inv_temp;
+        mx = fmaxf(mx, v[i][e]);
+      }
+    }
+  }
+  mx = block_reduce(mx, red, true);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i)
+    if (threadIdx.x + TF_THREADS * i < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = expf(v[i][e] - mx);
+        s += v[i][e];
+      }
+    }
+  s = inv_n / block_reduce(s, red, false);
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i) {
+    const int ch = threadIdx.x + TF_THREADS * i;
+    if (ch < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) atomicAdd(m + ch * 8 + e, v[i][e] * s);
+    }
+  }
+}
+
+__global__ __launch_bounds__(TF_THREADS) void memax_grad_kernel(const uint16_t* __restrict__ x, const float* __restrict__ m,
+                                                                const float* __restrict__ log_prior, int K,
+                                                                float inv_temp, float inv_n, float* __restrict__ loss,
+                                                                float* __restrict__ dx) {
+  __shared__ float red[4];
+  const long long row = blockIdx.x;
+  const int nch = K >> 3;
+  float v[DL_MAXV][8], u[DL_MAXV][8];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i) {
+    const int ch = threadIdx.x + TF_THREADS * i;
+    if (ch < nch) {
+      unpack8(*reinterpret_cast<const uint4*>(x + row * K + ch * 8), v[i]);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] *= inv_temp;
+        mx = fmaxf(mx, v[i][e]);
+        const float mk = m[ch * 8 + e];
+        u[i][e] = logf(fmaxf(mk, 1e-30f)) - (log_prior ? log_prior[ch * 8 + e] : 0.f) + 1.f;
+      }
+    }
+  }
+  mx = block_reduce(mx, red, true);
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i)
+    if (threadIdx.x + TF_THREADS * i < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] = expf(v[i][e] - mx);
+        s += v[i][e];
+      }
+    }
+  s = 1.f / block_reduce(s, red, false);
+  float pu = 0.f;
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i)
+    if (threadIdx.x + TF_THREADS * i < nch) {
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        v[i][e] *= s;
+        pu = fmaf(v[i][e], u[i][e], pu);
+      }
+    }
+  pu = block_reduce(pu, red, false);
+  const float c = inv_n * inv_temp;
+#pragma unroll
+  for (int i = 0; i < DL_MAXV; ++i) {
+    const int ch = threadIdx.x + TF_THREADS * i;
+    if (ch < nch) {
+      float* o = dx + row * K + ch * 8;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = c * v[i][e] * (u[i][e] - pu);
+    }
+  }
+  if (row == 0) {  // the scalar: sum_k m_k (log m_k - log prior_k)
+    float r = 0.f;
+    for (int k = threadIdx.x; k < K; k += TF_THREADS) {
+      const float mk = m[k];
+      r += mk * (logf(fmaxf(mk, 1e-30f)) - (log_prior ? log_prior[k] : 0.f));
+    }
+    r = block_reduce(r, red, false);
+    if (threadIdx.x == 0) atomicAdd(loss, r);
   }
 }
 
@@ -815,21 +927,31 @@ extern "C" int wm_dino_teacher_probs(const void* teacher, const float* center, f
   return WM_OK;
 }
 
-extern "C" int wm_dino_loss_fwd_bwd(const void* student, const float* probs, int Vs, int Vt, int B, int D,
-                                    float temp_s, float* loss, void* dstudent, void* stream) {
+static int dino_loss_impl(const void* student, const float* probs, int Vs, int Vt, int B, int D, float temp_s,
+                          int skip_same, float* loss, void* dstudent, void* stream) {
   WM_REQUIRE(student && probs && loss && dstudent, WM_EINVAL);
   WM_REQUIRE(Vs > 0 && Vt > 0 && B > 0 && D > 0 && D % 8 == 0 && temp_s > 0.f, WM_EINVAL);
   WM_REQUIRE(D <= TF_THREADS * 8 * DL_MAXV, WM_EUNSUPPORTED);
   WM_REQUIRE(al16(student) && al16(probs) && al16(dstudent), WM_EALIGN);
-  const int ndiag = Vs < Vt ? Vs : Vt;
+  const int ndiag = skip_same ? (Vs < Vt ? Vs : Vt) : 0;
   const int n_terms = Vs * Vt - ndiag;
   WM_REQUIRE(n_terms > 0, WM_EINVAL);
   const float w = 1.f / ((float)n_terms * (float)B);
   dino_loss_kernel<<<Vs * B, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
-      static_cast<const uint16_t*>(student), probs, Vs, Vt, B, D, 1.f / temp_s, w, loss,
+      static_cast<const uint16_t*>(student), probs, Vs, Vt, B, D, 1.f / temp_s, w, skip_same, loss,
       static_cast<uint16_t*>(dstudent));
   WM_LAUNCH_CHECK();
   return WM_OK;
+}
+
+extern "C" int wm_dino_loss_fwd_bwd(const void* student, const float* probs, int Vs, int Vt, int B, int D,
+                                    float temp_s, float* loss, void* dstudent, void* stream) {
+  return dino_loss_impl(student, probs, Vs, Vt, B, D, temp_s, 1, loss, dstudent, stream);
+}
+
+extern "C" int wm_soft_cross_entropy_fwd_bwd(const void* student, const float* probs, int Vs, int B, int D, float temp_s,
+                                             float* loss, void* dstudent, void* stream) {
+  return dino_loss_impl(student, probs, Vs, 1, B, D, temp_s, 0, loss, dstudent, stream);
 }
 
 extern "C" int wm_dino_center_update(const void* teacher, long long rows, int D, float momentum, float* center,
@@ -881,6 +1003,24 @@ extern "C" int wm_standardize(const void* x, int dtype, long long rows, int C, c
   else
     standardize_kernel<uint16_t><<<blocks, TF_THREADS, 0, st>>>(static_cast<const uint16_t*>(x), rows, C, mean,
                                                                 inv_scale, out);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_mean_entropy_reg_fwd_bwd(const void* logits, const float* log_prior, int N, int K, float temperature,
+                                           float* loss, float* dlogits, float* mean_ws, void* stream) {
+  WM_REQUIRE(logits && loss && dlogits && mean_ws, WM_EINVAL);
+  WM_REQUIRE(N > 0 && K > 0 && K % 8 == 0 && temperature > 0.f, WM_EINVAL);
+  WM_REQUIRE(K <= TF_THREADS * 8 * DL_MAXV, WM_EUNSUPPORTED);
+  WM_REQUIRE(al16(logits), WM_EALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  zero_f32<<<ew_blocks(K), TF_THREADS, 0, st>>>(mean_ws, K);
+  WM_LAUNCH_CHECK();
+  memax_mean_kernel<<<N, TF_THREADS, 0, st>>>(static_cast<const uint16_t*>(logits), K, 1.f / temperature, 1.f / (float)N,
+                                             mean_ws);
+  WM_LAUNCH_CHECK();
+  memax_grad_kernel<<<N, TF_THREADS, 0, st>>>(static_cast<const uint16_t*>(logits), mean_ws, log_prior, K,
+                                             1.f / temperature, 1.f / (float)N, loss, dlogits);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

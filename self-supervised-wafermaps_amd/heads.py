@@ -76,6 +76,16 @@ class MoCoProjectionHead(ProjectionHead):
         super().__init__([(input_dim, hidden_dim, None, hnn.ReLU()), (hidden_dim, output_dim, None, None)])
 
 
+class MSNProjectionHead(ProjectionHead):
+    """lightly MSNProjectionHead(input_dim=768, hidden_dim=2048, output_dim=256): (Linear-BN-GELU) x2, Linear(+bias)
+    (reference: MSNProjectionHead(384), scripts/WM811k_benchmark.py:678)."""
+
+    def __init__(self, input_dim: int = 768, hidden_dim: int = 2048, output_dim: int = 256):
+        super().__init__([(input_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.GELU()),
+                          (hidden_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.GELU()),
+                          (hidden_dim, output_dim, None, None)])
+
+
 class SwaVProjectionHead(ProjectionHead):
     """lightly SwaVProjectionHead: Linear-BN-ReLU, Linear(+bias)  (reference: (512, 2048, 128), :830)."""
 

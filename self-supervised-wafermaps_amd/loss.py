@@ -475,6 +475,67 @@ class SwaVLoss(nn.Module):
         return vit_ops.dino_loss(student, probs, len(high) + len(low), len(high), b, self.temperature)
 
 
+class MSNLoss(nn.Module):
+    """lightly.loss.MSNLoss (Masked Siamese Networks; the reference's MSN, scripts/WM811k_benchmark.py:684,705):
+    anchors [V*B, D] (view-major), targets [B, D], prototypes [K, D].  Targets: softmax of the prototype
+    cosines / T, sharpened (power 1 / target_sharpen_temperature) and balanced by Sinkhorn; loss = mean
+    cross-entropy of the anchors' prototype distribution against them + regularization_weight * sum m log m
+    (mean-entropy maximisation) with m the mean anchor distribution.  Gradients reach the anchors only,
+    through every term (the reference passes `prototypes.data`)."""
+
+    def __init__(self, temperature: float = 0.1, sinkhorn_iterations: int = 3, regularization_weight: float = 1.0,
+                 gather_distributed: bool = False):
+        super().__init__()
+        if gather_distributed and _world() > 1:
+            raise NotImplementedError("MSNLoss(gather_distributed=True) is not built")
+        self.temperature = temperature
+        self.sinkhorn_iterations = sinkhorn_iterations
+        self.regularization_weight = regularization_weight
+
+    def _log_prior(self, k: int, device):
+        return None
+
+    def forward(self, anchors: torch.Tensor, targets: torch.Tensor, prototypes: torch.Tensor,
+                target_sharpen_temperature: float = 0.25) -> torch.Tensor:
+        from . import ops, vit_ops
+
+        b, k = targets.shape[0], prototypes.shape[0]
+        views = anchors.shape[0] // b
+        if anchors.shape[0] != views * b or anchors.shape[1] != targets.shape[1] != prototypes.shape[1]:
+            raise ValueError("MSNLoss: anchors [V*B, D], targets [B, D], prototypes [K, D]")
+        protos = F_hip.l2_normalize(prototypes.detach().float().contiguous())
+        a = F_hip.l2_normalize(anchors.float().contiguous())
+        with torch.no_grad():
+            t = F_hip.l2_normalize(targets.detach().float().contiguous())
+            t_cos = ops.linear(t, protos)  # [B, K] cosines (bf16)
+            # sharpen(softmax(cos / T), Ts) = softmax(cos / (T Ts)); Sinkhorn works on it up to row factors
+            if self.sinkhorn_iterations > 0:
+                q = sinkhorn(t_cos.float() / (self.temperature * target_sharpen_temperature), self.sinkhorn_iterations, 1.0)
+            else:
+                q = vit_ops.dino_teacher_probs(t_cos, torch.zeros(k, device=t.device),
+                                               self.temperature * target_sharpen_temperature)
+        a_cos = ops.linear(a, protos)   # [V*B, K], gradient to the anchors through the GEMM's dgrad
+        loss = vit_ops.soft_cross_entropy(a_cos, q, views, b, self.temperature)
+        if self.regularization_weight > 0:
+            loss = loss + self.regularization_weight * vit_ops.mean_entropy_reg(a_cos, self.temperature,
+                                                                                self._log_prior(k, a.device))
+        return loss
+
+
+class PMSNLoss(MSNLoss):
+    """lightly.loss.PMSNLoss: the regulariser is the KL divergence of the mean anchor distribution to a
+    power-law prior over the prototypes, prior_k proportional to 1 / k^power_law_exponent (k = 1..K)."""
+
+    def __init__(self, temperature: float = 0.1, sinkhorn_iterations: int = 3, regularization_weight: float = 1.0,
+                 power_law_exponent: float = 0.25, gather_distributed: bool = False):
+        super().__init__(temperature, sinkhorn_iterations, regularization_weight, gather_distributed)
+        self.power_law_exponent = power_law_exponent
+
+    def _log_prior(self, k: int, device):
+        prior = 1.0 / torch.arange(1, k + 1, dtype=torch.float64) ** self.power_law_exponent
+        return torch.log(prior / prior.sum()).float().to(device)
+
+
 class DINOLoss(nn.Module):
     """lightly.loss.DINOLoss as the reference calls it (scripts/WM811k_benchmark.py:564,586:
     `DINOLoss(output_dim=2048)`, `criterion(teacher_out, student_out, epoch=...)`).

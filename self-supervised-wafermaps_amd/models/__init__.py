@@ -11,3 +11,4 @@ from .dclw import DCLW  # noqa: F401
 from .barlow import BarlowTwins  # noqa: F401
 from .vicreg import VICReg  # noqa: F401
 from .swav import SwaV  # noqa: F401
+from .msn import MSN, PMSN  # noqa: F401

@@ -107,13 +107,36 @@ class MAEBackbone(nn.Module):
     def from_vit(cls, vit) -> "MAEBackbone":
         return cls(vit.image_size, vit.patch_size, vit.num_layers, vit.num_heads, vit.hidden_dim, vit.mlp_dim)
 
+    def _pos_for(self, g_new: int) -> torch.Tensor:
+        """Positional embedding for a g_new x g_new patch grid (lightly's MAEEncoder.interpolate_pos_encoding:
+        the same bicubic resize as dino's; MSN's 96^2 focal crops need it)."""
+        import math
+
+        pos = self.encoder.pos_embedding
+        n = pos.shape[1] - 1
+        if g_new * g_new == n:
+            return pos
+        g = int(math.sqrt(n))
+        key = (g, g_new)
+        cache = self.__dict__.setdefault("_interp", {})
+        m = cache.get(key)
+        if m is None or m.device != pos.device:
+            basis = torch.eye(n, dtype=torch.float32).reshape(1, g, g, n).permute(0, 3, 1, 2)
+            sf = (g_new + 0.1) / g
+            out = nn.functional.interpolate(basis, scale_factor=(sf, sf), mode="bicubic")
+            m = out.permute(0, 2, 3, 1).reshape(g_new * g_new, n).contiguous().to(pos.device)
+            cache[key] = m
+        return torch.cat([pos[:, :1], (m @ pos[0, 1:]).unsqueeze(0)], dim=1)
+
     def images_to_tokens(self, images, add_pos: bool = True):
         """[B,3,S,S] -> bf16 [B*seq, D] rows: class token prepended; the positional embedding is added here
         (add_pos) or later by `encode_tokens` (lightly's encoder adds it: SimMIM masks tokens before that)."""
-        n = images.shape[0]
+        n, g = images.shape[0], images.shape[-1] // self.patch_size
         patches = self.conv_proj(images)
-        pos = self.encoder.pos_embedding if add_pos else torch.zeros_like(self.encoder.pos_embedding)
-        return vit_ops.tokens_assemble(patches, self.class_token, pos, n, self.seq_length - 1)
+        pos = self._pos_for(g)
+        if not add_pos:
+            pos = torch.zeros_like(pos)
+        return vit_ops.tokens_assemble(patches, self.class_token, pos, n, g * g)
 
     def encode_tokens(self, tokens, batch: int):
         """lightly MAEEncoder.forward(tokens): + positional embedding, encoder blocks, final LayerNorm."""
@@ -126,7 +149,7 @@ class MAEBackbone(nn.Module):
         """All kept tokens after the encoder: [B, K, D] (lightly MAEBackbone.encode)."""
         n = images.shape[0]
         tok = self.images_to_tokens(images)
-        seq = self.seq_length
+        seq = (images.shape[-1] // self.patch_size) ** 2 + 1
         if idx_keep is not None:
             tok = vit_ops.gather_rows(tok, idx_keep, n, seq)
             seq = idx_keep.shape[1]

@@ -434,3 +434,54 @@ def dino_center_update(center: torch.Tensor, teacher: torch.Tensor, momentum: fl
     rows, d = teacher.shape
     check(_lib.load().wm_dino_center_update(ptr(teacher), rows, d, float(momentum), ptr(center), stream_ptr()),
           "wm_dino_center_update")
+
+
+class _SoftCE(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, student, probs, views, b, temp_s):
+        _need_cuda(student, "soft_cross_entropy")
+        student = _bf16_rows(student)
+        d = student.shape[1]
+        if student.shape[0] != views * b or tuple(probs.shape) != (b, d) or probs.dtype != torch.float32:
+            raise ValueError(f"soft_cross_entropy: student {tuple(student.shape)}, probs {tuple(probs.shape)} {probs.dtype}")
+        loss = torch.zeros(1, dtype=torch.float32, device=student.device)
+        ds = torch.empty_like(student)
+        check(_lib.load().wm_soft_cross_entropy_fwd_bwd(ptr(student), ptr(probs.contiguous()), views, b, d, temp_s, ptr(loss),
+                                                        ptr(ds), stream_ptr()), "wm_soft_cross_entropy_fwd_bwd")
+        ctx.save_for_backward(ds)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (ds,) = ctx.saved_tensors
+        return (ds.float() * g).to(torch.bfloat16), None, None, None, None
+
+
+def soft_cross_entropy(student: torch.Tensor, probs: torch.Tensor, views: int, batch: int, temperature: float) -> torch.Tensor:
+    """mean over (view, sample) of -<probs_b, log_softmax(student_vb / T)>; student bf16 [views*B, D] view-major."""
+    return _SoftCE.apply(student, probs, int(views), int(batch), float(temperature))
+
+
+class _MeanEntropyReg(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, log_prior, temperature):
+        _need_cuda(logits, "mean_entropy_reg")
+        logits = _bf16_rows(logits)
+        n, k = logits.shape
+        loss = torch.zeros(1, dtype=torch.float32, device=logits.device)
+        dl = torch.empty((n, k), dtype=torch.float32, device=logits.device)
+        ws = torch.empty(k, dtype=torch.float32, device=logits.device)
+        check(_lib.load().wm_mean_entropy_reg_fwd_bwd(ptr(logits), ptr(log_prior), n, k, temperature, ptr(loss), ptr(dl),
+                                                      ptr(ws), stream_ptr()), "wm_mean_entropy_reg_fwd_bwd")
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (dl,) = ctx.saved_tensors
+        return (dl * g).to(torch.bfloat16), None, None
+
+
+def mean_entropy_reg(logits: torch.Tensor, temperature: float, log_prior: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """sum_k m_k (log m_k - log prior_k) with m the batch mean of softmax(logits / T)."""
+    return _MeanEntropyReg.apply(logits, log_prior, float(temperature))

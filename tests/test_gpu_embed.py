@@ -546,3 +546,25 @@ def test_adam_with_l2_weight_decay_matches_torch():
         topt.step()
     for p, r in zip(ps, ref):
         torch.testing.assert_close(p.detach(), r.detach(), rtol=2e-5, atol=2e-6)
+
+
+@pytest.mark.parametrize("pmsn", [False, True])
+def test_msn_losses_match_oracle(pmsn):
+    from ssl_wafermap_amd.loss import MSNLoss, PMSNLoss
+
+    g = torch.Generator().manual_seed(29)
+    b, v, d, k = 24, 3, 256, 1024
+    targets = torch.randn(b, d, generator=g)
+    anchors = (targets.repeat(v, 1) + 0.8 * torch.randn(v * b, d, generator=g))
+    protos = torch.randn(k, d, generator=g)
+    ar = anchors.clone().requires_grad_(True)
+    ref = on.msn_loss(ar, targets, protos, power_law_exponent=0.25 if pmsn else None)
+    ref.backward()
+    ad = anchors.to("cuda:0").requires_grad_(True)
+    crit = (PMSNLoss() if pmsn else MSNLoss()).to("cuda:0")
+    loss = crit(ad, targets.to("cuda:0"), protos.to("cuda:0"))
+    loss.backward()
+    # the prototype cosines pass through bf16 before the softmax at T = 0.1 (targets: T * 0.25 = 0.025)
+    assert abs(float(loss.detach()) - float(ref.detach())) <= 3e-2 * abs(float(ref.detach())) + 2e-2, (float(loss), float(ref))
+    c = torch.nn.functional.cosine_similarity(ad.grad.float().cpu().flatten(), ar.grad.flatten(), dim=0)
+    assert float(c) > 0.97, float(c)

@@ -483,3 +483,42 @@ def test_simmim_step_matches_oracle():
     top = max(float(r.norm() / math.sqrt(r.numel())) for _, _, r in pairs)
     cos = [(_cos(a, r), k) for k, a, r in pairs if float(r.norm() / math.sqrt(r.numel())) > 1e-3 * top]
     assert min(cos)[0] > 0.85 and float(np.median([c for c, _ in cos])) > 0.97, (min(cos), len(cos))
+
+
+@pytest.mark.parametrize("name", ["msn", "pmsn"])
+def test_msn_training_step_runs_and_learns(name):
+    """MSN / PMSN (reference :663-822) with a 2-block ViT-S/16: target network by EMA, masked anchors of two crop
+    sizes (positional embedding resized for 96^2), prototypes; finite loss, gradients everywhere they should be."""
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models import MSN, PMSN
+    from ssl_wafermap_amd.models.mae import MAEBackbone
+
+    torch.manual_seed(0)
+    model = (MSN if name == "msn" else PMSN)(None, 9, batch_size=8, log_rep_std=False)
+    model.backbone = MAEBackbone(224, 16, 2, 6, 384, 1536)
+    model.anchor_backbone = copy.deepcopy(model.backbone)
+    for p_ in model.backbone.parameters():
+        p_.requires_grad = False
+    model = model.to(DEV).train()
+    (opt,), _ = model.configure_optimizers()
+    b = 8
+    g = torch.Generator().manual_seed(2)
+    views = [_bf(torch.randn(b, 3, 224, 224, generator=g)) for _ in range(2)] + \
+            [_bf(torch.randn(b, 3, 96, 96, generator=g)) for _ in range(2)]
+    batch = ([ops.to_nhwc_bf16(v.to(DEV)) for v in views], None)
+    gen = torch.Generator(device=DEV).manual_seed(1)
+    losses = []
+    for i in range(5):
+        opt.zero_grad()
+        loss = model.training_step(batch, i, generator=gen)
+        loss.backward()
+        if i == 0:
+            assert model.prototypes.grad is None or float(model.prototypes.grad.abs().max()) == 0.0  # `.data` in the reference
+            gsum = sum(float(p_.grad.abs().sum()) for p_ in model.anchor_backbone.parameters())
+            assert math.isfinite(gsum) and gsum > 0
+            assert all(p_.grad is None for p_ in model.backbone.parameters())
+        for grp in opt.param_groups:
+            grp["lr"] = 5e-4
+        opt.step()
+        losses.append(float(loss.detach()))
+    assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
