@@ -32,6 +32,24 @@ def knn_topk(query: torch.Tensor, bank: torch.Tensor, k: int, index_base: int = 
     nq, d = query.shape
     n = bank.shape[0]
     lib = _lib.load()
+    rowbytes = d * query.element_size()
+    streaming_ok = rowbytes % 256 == 0 and rowbytes <= (2048 if query.dtype == torch.float32 else 1024) and \
+        (k <= 8 or rowbytes <= 1024)
+    if not streaming_ok:
+        # shapes the streaming kernel does not take (e.g. 768 ViT-B features): the general float32 kernel
+        q32, b32 = query.float().contiguous(), bank.float().contiguous()
+        if d % 4:
+            q32 = torch.nn.functional.pad(q32, (0, 4 - d % 4)).contiguous()
+            b32 = torch.nn.functional.pad(b32, (0, 4 - d % 4)).contiguous()
+        need = lib.wm_knn_topk_general_workspace_bytes(nq, n, q32.shape[1], k)
+        if need == 0:
+            raise ValueError(f"knn_topk: unsupported sizes nq={nq} n={n} d={d} k={k} (k <= 16)")
+        ws = torch.empty(need, dtype=torch.uint8, device=query.device)
+        sim = torch.empty((nq, k), dtype=torch.float32, device=query.device)
+        idx = torch.empty((nq, k), dtype=torch.int32, device=query.device)
+        check(lib.wm_knn_topk_general(ptr(q32), ptr(b32), 0, nq, n, q32.shape[1], k, index_base, ptr(sim), ptr(idx),
+                                      ptr(ws), need, stream_ptr()), "wm_knn_topk_general")
+        return sim, idx
     need = lib.wm_knn_topk_workspace_bytes(nq, n, d, k)
     if need == 0:
         raise ValueError(f"knn_topk: unsupported sizes nq={nq} n={n} d={d} k={k}")

@@ -240,7 +240,8 @@ class MAE(KNNBenchmarkModule):
 
     def training_step(self, batch, batch_idx, generator: torch.Generator = None):
         images = batch[0]
-        images = images[0]  # one view
+        if not (torch.is_tensor(images) and images.dim() == 4):
+            images = images[0]  # the list of views of a one-view transform (the reference's form)
         batch_size = images.shape[0]
         idx_keep, idx_mask = model_utils.random_token_mask(size=(batch_size, self.sequence_length),
                                                            mask_ratio=self.mask_ratio, device=images.device,
@@ -291,7 +292,9 @@ class SimMIM(KNNBenchmarkModule):
         return self.decoder(x_encoded.reshape(b * k, c)).view(b, k, -1)
 
     def training_step(self, batch, batch_idx, generator: torch.Generator = None):
-        images = batch[0][0]
+        images = batch[0]
+        if not (torch.is_tensor(images) and images.dim() == 4):
+            images = images[0]
         batch_size = images.shape[0]
         _, idx_mask = model_utils.random_token_mask(size=(batch_size, self.sequence_length), mask_ratio=self.mask_ratio,
                                                     device=images.device, generator=generator)

@@ -340,3 +340,60 @@ def test_swav_step_runs_and_matches_oracle_loss():
     assert abs(float(loss.detach()) - float(ref)) <= 5e-2 * abs(float(ref)), (float(loss), float(ref))
     norms = model.prototypes.layers.weight.detach().norm(dim=1)
     assert norms.shape == (3000,)
+
+
+ZOO = ["SupervisedR18", "SimCLR", "DCLW", "MoCo", "BarlowTwins", "VICReg", "BYOL", "DINO", "DINOViT", "SimSiam", "FastSiam",
+       "MSN", "PMSN", "SwaV", "MAE", "SimMIM"]
+
+
+@pytest.mark.parametrize("name", ZOO)
+def test_every_benchmark_model_trains_and_validates_through_the_trainer(name):
+    """The reference's main() loop (scripts/WM811k_benchmark.py:1033-1150) for every model class of the script:
+    its transform, one short epoch through Trainer.fit, kNN validation on the backbone features."""
+    import ssl_wafermap_amd.models as zoo
+    from ssl_wafermap_amd.data import WaferLoader, WaferMapDataset
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.trainer import Trainer
+    from ssl_wafermap_amd.transforms import BaseViewTransform, InferenceTransform, MultiCropTransform
+
+    wafers, labels = synthetic_wafers(48, seed=7)
+    multi = name in ("DINO", "DINOViT", "SwaV", "MSN", "PMSN")
+    one_view = name in ("MAE", "SimMIM", "SupervisedR18")
+    if multi:
+        tf = MultiCropTransform(n_local_views=2)
+    elif name == "FastSiam":
+        tf = BaseViewTransform(n_views=4)
+    else:
+        tf = BaseViewTransform(n_views=1 if one_view else 2)
+    ds_ssl = WaferMapDataset(wafers[:32], labels[:32], transform=tf, device=DEV)
+    ds_knn = WaferMapDataset(wafers[:32], labels[:32], transform=InferenceTransform(), device=DEV)
+    ds_val = WaferMapDataset(wafers[32:], labels[32:], transform=InferenceTransform(), device=DEV)
+    torch.manual_seed(0)
+    cls = getattr(zoo, name)
+    model = cls(WaferLoader(ds_knn, 16), 9, knn_k=5, knn_t=0.1, batch_size=8, max_epochs=2).to(DEV)
+    if name in ("DINOViT", "MSN", "PMSN", "MAE", "SimMIM"):  # shrink the transformers: this is a plumbing test
+        from ssl_wafermap_amd.models.mae import MAEBackbone
+        from ssl_wafermap_amd.models.vit import VisionTransformer
+        import copy as _copy
+
+        if name == "DINOViT":
+            model.backbone = VisionTransformer(patch_size=16, embed_dim=384, depth=1, num_heads=6).to(DEV)
+            model.teacher_backbone = _copy.deepcopy(model.backbone)
+            for p_ in model.teacher_backbone.parameters():
+                p_.requires_grad = False
+        elif name in ("MSN", "PMSN"):
+            model.backbone = MAEBackbone(224, 16, 1, 6, 384, 1536).to(DEV)
+            model.anchor_backbone = _copy.deepcopy(model.backbone)
+            for p_ in model.backbone.parameters():
+                p_.requires_grad = False
+        else:
+            model.backbone = MAEBackbone(224, 32, 1, 12, 768, 3072).to(DEV)
+    if name == "SupervisedR18":
+        train = WaferLoader(ds_ssl, 8, shuffle=True, drop_last=True, seed=0)
+    else:
+        train = WaferLoader(ds_ssl, 8, shuffle=True, drop_last=True, seed=0)
+    hist = Trainer(max_epochs=1, limit_train_batches=2, verbose=False).fit(model, train, WaferLoader(ds_val, 16))
+    assert len(hist) == 1
+    key = "train_loss" if name == "SupervisedR18" else "train_loss_ssl"
+    assert np.isfinite(float(model.logged[key]))
+    assert 0.0 <= hist[-1]["knn_accuracy"] <= 1.0
