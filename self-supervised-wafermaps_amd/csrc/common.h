@@ -87,4 +87,9 @@ __device__ __forceinline__ void glds16_at(const void* gsrc, uint32_t lds_byte_ad
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc), "s"(base) : "memory", "m0");
 }
 
+__device__ __forceinline__ void glds16_nt_at(const void* gsrc, uint32_t lds_byte_addr) {
+  const uint32_t base = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gsrc), "s"(base) : "memory", "m0");
+}
+
 static inline int wm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }

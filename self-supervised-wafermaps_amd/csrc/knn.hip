@@ -112,24 +112,30 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
     soff[i] = (dpc ^ (row & 15)) * 16;  // logical chunk that lands at physical slot dpc
     srcp[i] = bank + ((size_t)slice * KNN_ROWS + row) * rowbytes + soff[i];
   }
-  int issued = 0;  // next (chunk, slab) pair to issue, in order
+  // issue() is called for it = 0, 1, 2, ... in order: (chunk, slab) advance by a carry instead of a division,
+  // the ring slot by a wrap-around counter; LDS addresses are plain integers (no pointer cast per piece)
+  int issued = 0, it_slab = 0, it_chunk = slice, it_slot = 0;
+  const uint32_t ring_base = lds_addr(ring);
   auto issue = [&](int it) {
-    const int crel = it / nslab, slab = it - crel * nslab;
-    const int chunk = slice + crel * nslices;
-    const int nb = chunk * KNN_ROWS;
+    (void)it;
+    const int slab = it_slab;
+    const int nb = it_chunk * KNN_ROWS;
     const bool tail = nb + KNN_ROWS > n;  // block-uniform
-    uint8_t* stage = ring + (it % S) * KNN_BUF;
+    const uint32_t stage = ring_base + (uint32_t)it_slot * KNN_BUF;
 #pragma unroll
     for (int i = 0; i < PER_STAGE; ++i) {
       const int row0 = wave * 32 + i * 4;  // wave-uniform first row of this instruction
       const uint8_t* src = srcp[i] + (size_t)slab * KNN_SLAB;
       if (tail && nb + row0 + drow >= n) src = knn_zero_page + soff[i];
-      glds16_nt(src, lds_addr(stage + row0 * KNN_SLAB));
+      glds16_nt_at(src, stage + row0 * KNN_SLAB);
     }
-    if (slab == nslab - 1) {
+    if (++it_slab == nslab) {
+      it_slab = 0;
+      it_chunk += nslices;
 #pragma unroll
       for (int i = 0; i < PER_STAGE; ++i) srcp[i] += chunk_stride_bytes;
     }
+    if (++it_slot == S) it_slot = 0;
     ++issued;
   };
   (void)issued;
