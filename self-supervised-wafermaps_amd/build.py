@@ -31,6 +31,9 @@ FLAGS = [
     "-Wno-unused-function",
     "-Wno-pass-failed",
 ]
+# per-source additions.  knn.hip: MFMA results in VGPRs (the running group maxima read every accumulator
+# register with VALU right after the MFMAs; in AGPR form that is one v_accvgpr_read per register per chunk)
+EXTRA_FLAGS = {"knn.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -42,7 +45,7 @@ def _hipcc() -> str:
 
 def _digest(src: Path, headers: list[Path]) -> str:
     h = hashlib.sha256()
-    h.update(" ".join(FLAGS).encode())
+    h.update(" ".join(FLAGS + EXTRA_FLAGS.get(src.name, [])).encode())
     for p in [src, *headers]:
         h.update(p.read_bytes())
     return h.hexdigest()[:16]
@@ -66,7 +69,7 @@ def build(force: bool = False, jobs: int = 4, verbose: bool = True) -> Path:
 
     def compile_one(item):
         s, obj = item
-        cmd = [hipcc, *FLAGS, "-c", str(s), "-o", str(obj)]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(s.name, []), "-c", str(s), "-o", str(obj)]
         try:
             r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200)
         except subprocess.TimeoutExpired as e:  # a pathological instantiation must fail loudly, not hang

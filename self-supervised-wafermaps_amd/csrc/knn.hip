@@ -56,6 +56,101 @@ __device__ __forceinline__ void topk_insert(float (&v)[K], int (&ix)[K], float n
   }
 }
 
+// (value, id) as one 64-bit key whose unsigned order is the list order (value descending, id ascending):
+// high word = the float's bits mapped monotonically to uint32, low word = ~id.  One v_cmp_gt_u64
+// replaces the three compares of better(); ids are non-negative, values never -0.0 (an MFMA chain
+// starts from +0.0).
+__device__ __forceinline__ unsigned long long knn_key(float v, int id) {
+  uint32_t u = __float_as_uint(v);
+  u ^= (u & 0x80000000u) ? 0xffffffffu : 0x80000000u;
+  return ((unsigned long long)u << 32) | (uint32_t)~id;
+}
+__device__ __forceinline__ void knn_unkey(unsigned long long key, float& v, int& id) {
+  uint32_t u = (uint32_t)(key >> 32);
+  u ^= (u & 0x80000000u) ? 0x80000000u : 0xffffffffu;
+  v = __uint_as_float(u);
+  id = (int)~(uint32_t)key;
+}
+
+// Best K of two best-first key lists by a bitonic merge: max(a[j], b[K-1-j]) keeps the K best of the 2K
+// entries as a bitonic sequence, log2(K) compare-exchange stages sort it (~6x fewer VALU operations than K
+// insertions with topk_insert, same total order).
+template <int K>
+__device__ __forceinline__ void merge_keys(unsigned long long (&a)[K], const unsigned long long (&b)[K]) {
+#pragma unroll
+  for (int j = 0; j < K; ++j) a[j] = b[K - 1 - j] > a[j] ? b[K - 1 - j] : a[j];
+#pragma unroll
+  for (int s = K / 2; s >= 1; s >>= 1) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      if ((j & s) == 0) {
+        const bool c = a[j + s] > a[j];
+        const unsigned long long hi = c ? a[j + s] : a[j], lo = c ? a[j] : a[j + s];
+        a[j] = hi;
+        a[j + s] = lo;
+      }
+    }
+  }
+}
+
+// Block-level tail of the streaming kernels: every lane holds QT best-first lists (query = t*32 + r) for its
+// (wave, half).  Fold the two halves by shuffle, then the four waves through LDS in two levels (waves
+// {0,1} and {2,3} in parallel on different threads, then the two results), and store the block's list.
+template <int QT, int K>
+__device__ __forceinline__ void block_merge_store(float (&lv)[QT][K], int (&li)[QT][K], uint8_t* smem, int tid,
+                                                  int q0, int nslices, int slice, float* __restrict__ part_sim,
+                                                  int* __restrict__ part_idx) {
+  constexpr int QB = QT * 32;
+  const int lane = tid & 63, wave = tid >> 6, r = lane & 31, h = lane >> 5;
+  unsigned long long* mk = reinterpret_cast<unsigned long long*>(smem);  // [4][K][QB], the query fastest
+  unsigned long long* m2 = mk + 4 * K * QB;                              // [2][K][QB]
+#pragma unroll
+  for (int t = 0; t < QT; ++t) {
+    unsigned long long mine[K], other[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      mine[j] = knn_key(lv[t][j], li[t][j]);
+      other[j] = __shfl(mine[j], lane ^ 32, 64);
+    }
+    merge_keys<K>(mine, other);
+    if (h == 0) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) mk[(wave * K + j) * QB + t * 32 + r] = mine[j];
+    }
+  }
+  __syncthreads();
+  const int q = tid % QB, pairid = tid / QB;  // QB <= 128: threads 0 .. 2*QB-1 exist
+  unsigned long long f[K], g[K];
+  if (tid < 2 * QB) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+      f[j] = mk[((2 * pairid) * K + j) * QB + q];
+      g[j] = mk[((2 * pairid + 1) * K + j) * QB + q];
+    }
+    merge_keys<K>(f, g);
+    if (pairid == 1) {
+#pragma unroll
+      for (int j = 0; j < K; ++j) m2[j * QB + q] = f[j];
+    }
+  }
+  __syncthreads();
+  if (tid < QB) {
+#pragma unroll
+    for (int j = 0; j < K; ++j) g[j] = m2[j * QB + q];
+    merge_keys<K>(f, g);
+    float fv[K];
+    int fi[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) knn_unkey(f[j], fv[j], fi[j]);
+    const size_t o = ((size_t)(q0 + tid) * nslices + slice) * K;
+#pragma unroll
+    for (int j = 0; j < K; j += 4) {
+      *reinterpret_cast<float4*>(part_sim + o + j) = make_float4(fv[j], fv[j + 1], fv[j + 2], fv[j + 3]);
+      *reinterpret_cast<int4*>(part_idx + o + j) = make_int4(fi[j], fi[j + 1], fi[j + 2], fi[j + 3]);
+    }
+  }
+}
+
 __device__ __forceinline__ int acc_row(int reg, int half) {
   // C/D map of the 32x32 MFMA family: row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
   return (reg & 3) + 8 * (reg >> 2) + 4 * half;
@@ -289,56 +384,190 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
   }
   __syncthreads();  // ring is free: reuse it for the cross-wave merge
 
-  // ---- merge: (lane, lane+32) by shuffle, then the 4 waves through LDS (bank buffers are free)
+  block_merge_store<QT, K>(lv, li, smem, tid, q0, nslices, slice, part_sim, part_idx);
+}
+
+// bf16 rows of exactly one slab (d = 128, the reference's embedding width): the same stream with the
+// instruction stream cut to the bone.  A wave's 32 rows of a chunk are 8 KB contiguous in HBM, so
+// a stage is ONE asm statement: M0 once, eight global_load_lds_dwordx4 that share a scalar base
+// (advanced by one s_add per chunk) and four loop-invariant per-lane offsets (the XOR swizzle depends
+// on i & 3 only); the instruction's immediate offset moves the global source and the LDS
+// destination together by 1 KiB per instruction.  The ring slot is a compile-time constant (loop
+// unrolled by S), so ds_read addresses are loop-invariant registers + immediates and the query
+// fragments stay in registers.
+#define KNN_GLDS8(POLICY)                                                                              \
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\t"                                                       \
+               "global_load_lds_dwordx4 %1, %5 offset:-4096" POLICY "\n\t"                             \
+               "global_load_lds_dwordx4 %2, %5 offset:-3072" POLICY "\n\t"                             \
+               "global_load_lds_dwordx4 %3, %5 offset:-2048" POLICY "\n\t"                             \
+               "global_load_lds_dwordx4 %4, %5 offset:-1024" POLICY "\n\t"                             \
+               "global_load_lds_dwordx4 %1, %5" POLICY "\n\t"                                          \
+               "global_load_lds_dwordx4 %2, %5 offset:1024" POLICY "\n\t"                              \
+               "global_load_lds_dwordx4 %3, %5 offset:2048" POLICY "\n\t"                              \
+               "global_load_lds_dwordx4 %4, %5 offset:3072" POLICY                                     \
+               :                                                                                       \
+               : "s"(m0v), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "s"(sbase)          \
+               : "memory", "m0")
+
+template <int QT, int K, int S, bool NT>
+__global__ __launch_bounds__(KNN_THREADS) void knn_stream_b128(
+    const uint8_t* __restrict__ query, const uint8_t* __restrict__ bank, int nq, int n, int nslices,
+    int dbg, float* __restrict__ part_sim, int* __restrict__ part_idx) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  constexpr int QB = QT * 32;
+  constexpr int RB = KNN_SLAB;  // bytes per row
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, h = lane >> 5;
+  const int q0 = blockIdx.y * QB;
+  const int slice = blockIdx.x;
+  uint8_t* qbuf = smem + (S - 1) * KNN_BUF;  // query tile staged inside the last ring stage
+  // WM_KNN_DEBUG bit 2: 100 MHz timestamps of the block's phases over query q0's partial similarities (timing only)
+  unsigned long long stamp[4];
+  stamp[0] = __builtin_amdgcn_s_memrealtime();
+
+  const int total_chunks = (n + KNN_ROWS - 1) / KNN_ROWS;
+  const int iters = slice < total_chunks ? (total_chunks - slice + nslices - 1) / nslices : 0;
+
+  const int drow = lane >> 4, dpc = lane & 15;
+  uint32_t voff[4];
 #pragma unroll
-  for (int t = 0; t < QT; ++t) {
-    float pv[K];
-    int pi[K];
+  for (int i = 0; i < 4; ++i) voff[i] = (uint32_t)(drow * RB + ((dpc ^ ((4 * i + drow) & 15)) << 4));
+  const uint64_t chunk_stride_bytes = (uint64_t)nslices * KNN_ROWS * RB;
+  // +4096: the eight immediates are -4096 .. +3072
+  uint64_t sbase = reinterpret_cast<uint64_t>(bank) + ((uint64_t)slice * KNN_ROWS + wave * 32) * RB + 4096;
+  const uint32_t wave_lds = lds_addr(smem) + (uint32_t)wave * 32 * RB;
+  int it_chunk = slice;
+  auto issue = [&](int slot) {  // slot: ring stage, a compile-time constant at every call site
+    const uint32_t m0v = __builtin_amdgcn_readfirstlane(wave_lds + (uint32_t)slot * KNN_BUF + 4096);
+    const int nb = it_chunk * KNN_ROWS;
+    if (nb + KNN_ROWS > n) {
+      // the bank's last chunk: rows past the end are fetched from row n-1 (never beyond the allocation)
+      // and masked out of the maxima below
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        int row = nb + wave * 32 + i * 4 + drow;
+        row = row < n ? row : n - 1;
+        const uint8_t* src = bank + (size_t)row * RB + ((dpc ^ ((4 * i + drow) & 15)) << 4);
+        if constexpr (NT) glds16_nt_at(src, m0v - 4096 + i * 1024);
+        else glds16_at(src, m0v - 4096 + i * 1024);
+      }
+    } else {
+      if constexpr (NT) KNN_GLDS8(" nt");
+      else KNN_GLDS8("");
+    }
+    it_chunk += nslices;
+    sbase += chunk_stride_bytes;
+  };
+
+#pragma unroll
+  for (int p = 0; p < S - 1; ++p)
+    if (p < iters && !(dbg & 2)) issue(p);
+  for (int p = tid; p < QB * 16; p += KNN_THREADS) {
+    const int row = p >> 4, c = p & 15;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (q0 + row < nq) v = *reinterpret_cast<const uint4*>(query + (size_t)(q0 + row) * RB + c * 16);
+    *reinterpret_cast<uint4*>(qbuf + row * RB + ((c ^ (row & 15)) << 4)) = v;
+  }
+
+  float lv[QT][K];
+  int li[QT][K];
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-      pv[j] = __shfl(lv[t][j], lane ^ 32, 64);
-      pi[j] = __shfl(li[t][j], lane ^ 32, 64);
+      lv[t][j] = -INFINITY;
+      li[t][j] = INT_MAX;
     }
-    if (h == 0) {
+  f32x16_t acc[QT];
+  float gmax[QT];
 #pragma unroll
-      for (int j = 0; j < K; ++j)
-        if (better(pv[j], pi[j], lv[t][K - 1], li[t][K - 1])) topk_insert<K>(lv[t], li[t], pv[j], pi[j]);
+  for (int t = 0; t < QT; ++t) gmax[t] = -INFINITY;
+
+  uint32_t aoff[8];  // this lane's eight fragment offsets inside a stage (row wave*32 + r)
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) aoff[s8] = (uint32_t)((wave * 32 + r) * RB + (((2 * s8 + h) ^ (r & 15)) << 4));
+  // the query tile passes through LDS once (coalesced 16-byte loads; per-lane fragment loads straight from
+  // global memory were measured 2 us slower) and then lives in registers
+  uint4 qreg[QT][8];
+  __syncthreads();  // query tile staged
+#pragma unroll
+  for (int t = 0; t < QT; ++t)
+#pragma unroll
+    for (int s8 = 0; s8 < 8; ++s8)
+      qreg[t][s8] = *reinterpret_cast<const uint4*>(qbuf + (t * 32 + r) * RB + (((2 * s8 + h) ^ (r & 15)) << 4));
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();  // every wave has its fragments: the stage may now be overwritten
+  stamp[1] = __builtin_amdgcn_s_memrealtime();
+
+  for (int it0 = 0; it0 < iters; it0 += S) {
+#pragma unroll
+    for (int st = 0; st < S; ++st) {
+      const int it = it0 + st;
+      if (it >= iters) break;
+      const bool more = it + S - 1 < iters;
+      if (more) {
+        if constexpr (S == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+        else if constexpr (S == 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      // no barrier: a wave fetches exactly the rows it multiplies (see knn_stream)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      if (more && !(dbg & 2)) issue((st + S - 1) % S);
+      if (dbg & 1) continue;
+      uint4 a[8];
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) a[s8] = *reinterpret_cast<const uint4*>(smem + st * KNN_BUF + aoff[s8]);
+      __builtin_amdgcn_sched_barrier(0);  // all eight fragment reads in flight before the first MFMA
+#pragma unroll
+      for (int s8 = 0; s8 < 8; ++s8) {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[s8]),
+                                                           __builtin_bit_cast(bf16x8_t, qreg[t][s8]),
+                                                           s8 == 0 ? zero : acc[t], 0, 0, 0);
+        }
+      }
+      const int nb = (slice + it * nslices) * KNN_ROWS + wave * 32;
+      if (nb + 32 <= n) {  // wave-uniform: all 32 rows of this wave's sub-tile exist
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          float m = gmax[t];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) m = fmaxf(m, acc[t][e]);
+          gmax[t] = m;
+        }
+      } else {
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          float m = gmax[t];
+#pragma unroll
+          for (int e = 0; e < 16; ++e) m = fmaxf(m, (nb + acc_row(e, h) < n) ? acc[t][e] : -INFINITY);
+          gmax[t] = m;
+        }
+      }
+      if ((it & 3) == 3 || it == iters - 1) {  // group of 4 chunks complete (or slice ends)
+        const int gid = ((slice + (it & ~3) * nslices) << 3) | (wave << 1) | h;
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+          if (gmax[t] > lv[t][K - 1]) topk_insert<K>(lv[t], li[t], gmax[t], gid);
+          gmax[t] = -INFINITY;
+        }
+      }
     }
   }
-  float* msim = reinterpret_cast<float*>(smem);                  // [QB][4][K]
-  int* midx = reinterpret_cast<int*>(smem + QB * 4 * K * 4);     // [QB][4][K]
-  if (h == 0) {
+  stamp[2] = __builtin_amdgcn_s_memrealtime();
+  __syncthreads();  // ring is free: reuse it for the cross-wave merge
+  block_merge_store<QT, K>(lv, li, smem, tid, q0, nslices, slice, part_sim, part_idx);
+  if ((dbg & 4) && tid == 0) {
+    stamp[3] = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(part_sim + ((size_t)q0 * nslices + slice) * K);
 #pragma unroll
-    for (int t = 0; t < QT; ++t)
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        msim[((t * 32 + r) * 4 + wave) * K + j] = lv[t][j];
-        midx[((t * 32 + r) * 4 + wave) * K + j] = li[t][j];
-      }
-  }
-  __syncthreads();
-  if (tid < QB) {
-    float fv[K];
-    int fi[K];
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      fv[j] = msim[(tid * 4 + 0) * K + j];
-      fi[j] = midx[(tid * 4 + 0) * K + j];
-    }
-    for (int w = 1; w < 4; ++w) {
-#pragma unroll
-      for (int j = 0; j < K; ++j) {
-        const float cv = msim[(tid * 4 + w) * K + j];
-        const int ci = midx[(tid * 4 + w) * K + j];
-        if (better(cv, ci, fv[K - 1], fi[K - 1])) topk_insert<K>(fv, fi, cv, ci);
-      }
-    }
-    const size_t o = ((size_t)(q0 + tid) * nslices + slice) * K;
-#pragma unroll
-    for (int j = 0; j < K; ++j) {
-      part_sim[o + j] = fv[j];
-      part_idx[o + j] = fi[j];
-    }
+    for (int j = 0; j < 4; ++j) o[j] = stamp[j];
   }
 }
 
@@ -425,6 +654,10 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
   float* qf = reinterpret_cast<float*>(ci + K * 64);     // [d]
   const int q = blockIdx.x, tid = threadIdx.x;
   const size_t qbase = (size_t)q * nslices * K;
+  unsigned long long stamp[6];  // WM_KNN_DEBUG bit 2 (kout < 0): phase timestamps, see tools/knn_stamps.py
+  const bool stamps = kout < 0;
+  if (stamps) kout = -kout;
+  stamp[0] = __builtin_amdgcn_s_memrealtime();
 
   for (int c = tid; c < d; c += 256) {
     if constexpr (DT == WM_BF16) qf[c] = bf2f(reinterpret_cast<const uint16_t*>(query + (size_t)q * rowbytes)[c]);
@@ -461,6 +694,7 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
     }
   }
   __syncthreads();
+  stamp[1] = __builtin_amdgcn_s_memrealtime();
   // 2. the K best of the 4*K wave winners -> the K runs that can hold the K best groups
   if (tid < 4 * K) {
     const float v = hv[tid];
@@ -491,6 +725,7 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
   __syncthreads();
   if (tid < K) topg[tid] = selrun[tid];
   __syncthreads();
+  stamp[2] = __builtin_amdgcn_s_memrealtime();
 
   // ---- exact rescoring: 4 lanes per row, 64 rows per pass; a lane's pieces are sub, sub+4, ...
   // All loads of PASSES passes are issued before any arithmetic (the work is pure latency).
@@ -498,7 +733,8 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
   const int pieces = rowbytes >> 4;  // 16-byte pieces per row
   constexpr int EPP = DT == WM_BF16 ? 8 : 4;  // elements per piece
   constexpr int PASSES = K == 8 ? 8 : 4;
-  for (int c0p = 0; c0p < K * 64; c0p += 64 * PASSES) {
+  constexpr int ncand = K * 64;  // 4 chunks x 16 rows per group
+  for (int c0p = 0; c0p < ncand; c0p += 64 * PASSES) {
     int rows[PASSES];
     float accs[PASSES];
 #pragma unroll
@@ -511,7 +747,8 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
         const int c0 = gid >> 3, w = (gid >> 1) & 3, hh = gid & 1;
         const int chunk = c0 + cc * chunk_stride;  // the streaming block's next chunks
         const int rr = chunk * KNN_ROWS + w * 32 + acc_row(e, hh);
-        if (chunk < total_chunks && rr < n) row = rr;
+        // (unsigned: a corrupt group id must not turn into an address)
+        if ((unsigned)chunk < (unsigned)total_chunks && (unsigned)rr < (unsigned)n) row = rr;
       }
       rows[ps] = row;
       accs[ps] = 0.f;
@@ -553,47 +790,54 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
       float a = accs[ps];
       a += __shfl_xor(a, 1, 64);
       a += __shfl_xor(a, 2, 64);
+      const int c = c0p + ps * 64 + slot;
       if (sub == 0) {
-        const int c = c0p + ps * 64 + slot;
         cv[c] = rows[ps] != INT_MAX ? a : -INFINITY;
         ci[c] = rows[ps];
       }
     }
   }
   __syncthreads();
-  if (tid < 64) {  // one wave: kout rounds of arg-best over the candidates
-    const int ncand = K * 64;
+  stamp[3] = __builtin_amdgcn_s_memrealtime();
+  if (tid < 64) {
+    // one wave: every lane keeps its K candidates as 64-bit keys in registers (0 = none); a round is a
+    // lane-local maximum, a 6-step wave maximum and the removal of the winner (bank rows are distinct, so
+    // the key identifies it).  Nothing in the loop waits on memory: the stores of a round are not
+    // waited for (a full s_waitcnt here cost ~1.8 us per round).
+    unsigned long long key[K];
+#pragma unroll
+    for (int i = 0; i < K; ++i) {
+      const int c = tid + 64 * i;
+      const int idx = ci[c];
+      key[i] = idx != INT_MAX ? knn_key(cv[c], idx) : 0ull;
+    }
     for (int t = 0; t < kout; ++t) {
-      float bv = -INFINITY;
-      int bi = INT_MAX, bp = -1;
-      for (int c = tid; c < ncand; c += 64) {
-        const float v = cv[c];
-        const int i = ci[c];
-        if (i != INT_MAX && (bp < 0 || better(v, i, bv, bi))) {
-          bv = v;
-          bi = i;
-          bp = c;
-        }
-      }
+      unsigned long long best = key[0];
+#pragma unroll
+      for (int i = 1; i < K; ++i) best = key[i] > best ? key[i] : best;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        const int op = __shfl_xor(bp, o, 64);
-        if (op >= 0 && (bp < 0 || better(ov, oi, bv, bi))) {
-          bv = ov;
-          bi = oi;
-          bp = op;
-        }
+        const unsigned long long other = __shfl_xor(best, o, 64);
+        best = other > best ? other : best;
       }
+#pragma unroll
+      for (int i = 0; i < K; ++i) key[i] = key[i] == best ? 0ull : key[i];
       if (tid == 0) {
+        float bv = -INFINITY;
+        int bi = -1;
+        if (best != 0ull) {
+          knn_unkey(best, bv, bi);
+          bi += index_base;
+        }
         out_sim[(size_t)q * kout + t] = bv;
-        out_idx[(size_t)q * kout + t] = bp >= 0 ? bi + index_base : -1;
-        if (bp >= 0) ci[bp] = INT_MAX;  // consumed
+        out_idx[(size_t)q * kout + t] = bi;
       }
-      __builtin_amdgcn_s_waitcnt(0);  // lane 0's LDS write lands before the next round's reads
-      __builtin_amdgcn_wave_barrier();
     }
+  }
+  if (stamps && tid == 0) {
+    stamp[4] = __builtin_amdgcn_s_memrealtime();
+    unsigned long long* o = reinterpret_cast<unsigned long long*>(const_cast<float*>(part_sim) + qbase);
+    for (int j = 0; j < 5; ++j) o[j] = stamp[j];
   }
 }
 
@@ -648,6 +892,7 @@ inline KnnPlan make_plan(int nq, int n, int rowbytes, int k) {
   int want = (p.qt == 4 ? 256 : 512) / p.qtiles;  // resident blocks per CU: 1 (128-query tiles) or 2
   if (want < 1) want = 1;
   if (want > 512) want = 512;
+  if (const char* e = getenv("WM_KNN_SLICES")) want = atoi(e);  // experiment knob
   p.nslices = total_chunks < want ? total_chunks : want;
   p.chunks_per_slice = wm_cdiv(total_chunks, p.nslices);
   p.nslices = wm_cdiv(total_chunks, p.chunks_per_slice);
@@ -658,7 +903,7 @@ inline int knn_debug_bits() {
   static int bits = -1;
   if (bits < 0) {
     const char* e = getenv("WM_KNN_DEBUG");
-    bits = e ? atoi(e) & 3 : 0;
+    bits = e ? atoi(e) & 7 : 0;
   }
   return bits;
 }
@@ -682,9 +927,36 @@ int launch_stream(const KnnPlan& p, const void* query, const void* bank, int nq,
   return WM_OK;
 }
 
+template <int QT, int K, int S, bool NT>
+int launch_stream_b128(const KnnPlan& p, const void* query, const void* bank, int nq, int n, float* ps, int* pi,
+                       hipStream_t st) {
+  const size_t lds = (size_t)S * KNN_BUF;
+  static bool attr_set = false;  // idempotent; a race only repeats the call
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream_b128<QT, K, S, NT>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  dim3 grid(p.nslices, p.qtiles);
+  knn_stream_b128<QT, K, S, NT><<<grid, KNN_THREADS, lds, st>>>(
+      static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), nq, n, p.nslices, knn_debug_bits(), ps, pi);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+inline bool knn_nt() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WM_KNN_NT");
+    v = e ? atoi(e) != 0 : 1;
+  }
+  return v != 0;
+}
+
 // Instantiations are kept few (each is a large, fully unrolled kernel): query tiles of 64 or 128
-// (a smaller batch is zero-padded), K = 8 or 16 (16 only with 64-query tiles), register-resident
-// query fragments only for bf16 rows of exactly one slab (d = 128), ring depth 4 there and 3 otherwise.
+// (a smaller batch is zero-padded), K = 8 or 16 (16 only with 64-query tiles); bf16 rows of exactly one
+// slab (d = 128) take the specialised kernel, everything else the general one with a 3-stage ring.
 template <int DT, int QT, int K>
 int launch_block(const KnnPlan& p, const void* query, const void* bank, int nq, int n, int rowbytes,
                  float* ps, int* pi, hipStream_t st) {
@@ -692,8 +964,13 @@ int launch_block(const KnnPlan& p, const void* query, const void* bank, int nq, 
     // 64-query tiles: 2-stage ring, two blocks per CU (2 waves/SIMD overlap issue and waits);
     // 128-query tiles need ~400 registers per lane, i.e. one block per CU: 4-stage ring instead
     if (rowbytes == KNN_SLAB) {
-      if constexpr (QT == 4) return launch_stream<DT, QT, K, 4, true>(p, query, bank, nq, n, rowbytes, ps, pi, st);
-      else return launch_stream<DT, QT, K, 2, true>(p, query, bank, nq, n, rowbytes, ps, pi, st);
+      if constexpr (QT == 4) {
+        return knn_nt() ? launch_stream_b128<QT, K, 4, true>(p, query, bank, nq, n, ps, pi, st)
+                        : launch_stream_b128<QT, K, 4, false>(p, query, bank, nq, n, ps, pi, st);
+      } else {
+        return knn_nt() ? launch_stream_b128<QT, K, 2, true>(p, query, bank, nq, n, ps, pi, st)
+                        : launch_stream_b128<QT, K, 2, false>(p, query, bank, nq, n, ps, pi, st);
+      }
     }
   }
   return launch_stream<DT, QT, K, 3, false>(p, query, bank, nq, n, rowbytes, ps, pi, st);
@@ -719,7 +996,7 @@ int launch_select(const KnnPlan& p, const void* query, const void* bank, int n, 
   const size_t lds = (12 * K + 2 * K * K + K) * 4 + (size_t)K * 64 * 8 + (size_t)d * 4;
   knn_select<DT, K><<<nq, 256, lds, st>>>(static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), n, d,
                                           rowbytes, ps, pi, p.nslices, p.nslices, wm_cdiv(n, KNN_ROWS),
-                                          index_base, kout, out_sim, out_idx);
+                                          index_base, (knn_debug_bits() & 4) ? -kout : kout, out_sim, out_idx);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
