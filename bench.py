@@ -171,7 +171,7 @@ def main():
         try:
             from ssl_wafermap_amd.graph import GraphedTrainStep
 
-            graphed = GraphedTrainStep(model, opt, ds, B).capture(np.arange(B), rng)
+            graphed = GraphedTrainStep(model, opt, ds, B).capture(np.arange(B), rng, sync)
             for i in range(2):
                 step(i)
         except Exception as e:  # capture is an optimisation: report and continue eagerly

@@ -58,8 +58,10 @@ class GraphedTrainStep:
         loss.backward()
         return loss
 
-    def capture(self, sample_idx: np.ndarray, rng: np.random.Generator):
-        """Warm up eagerly on a side stream, then record the graph (torch.cuda.graph)."""
+    def capture(self, sample_idx: np.ndarray, rng: np.random.Generator, sync=None):
+        """Warm up eagerly on a side stream, then record the graph (torch.cuda.graph).  `sync` (a
+        distributed.GradSync) keeps the warm-up steps data-parallel: without the gradient exchange the
+        replicas' weights would drift apart before the first captured step."""
         params = self.tr.sample(self.ds.store, np.asarray(sample_idx), rng)
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
@@ -67,6 +69,9 @@ class GraphedTrainStep:
             self._upload(params)
             for _ in range(self._warmup):
                 self._body()
+                if sync is not None:
+                    sync.start()
+                    sync.wait()
                 self.opt.step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
