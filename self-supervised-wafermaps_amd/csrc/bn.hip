@@ -462,15 +462,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply(const uint16_t* 
                                                                 const float* __restrict__ coef, int N, int C,
                                                                 int imgs_per_group, int remask,
                                                                 uint16_t* __restrict__ dy, const PoolSrc ps) {
-  const int cpr = C >> 3;
-  const int HA = ps.H >> 1, WB = ps.W >> 1;
-  const long long total = (long long)N * HA * WB * cpr;
+  // 32-bit index arithmetic (host-checked range): the kernel is VALU-bound, see pool.hip
+  const uint32_t cpr = (uint32_t)C >> 3;
+  const uint32_t HA = (uint32_t)ps.H >> 1, WB = (uint32_t)ps.W >> 1;
+  const uint32_t total = (uint32_t)N * HA * WB * cpr;
   int cur_g = -1;
   float k[7][8];
-  for (long long t = (long long)blockIdx.x * BN_THREADS + threadIdx.x; t < total;
-       t += (long long)gridDim.x * BN_THREADS) {
+  for (uint32_t t = blockIdx.x * BN_THREADS + threadIdx.x; t < total; t += gridDim.x * BN_THREADS) {
     const int c0 = (int)(t % cpr) * 8;
-    long long u = t / cpr;
+    uint32_t u = t / cpr;
     const int b = (int)(u % WB);
     u /= WB;
     const int a = (int)(u % HA), n = (int)(u / HA);
@@ -917,7 +917,8 @@ static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, in
                                                    dgamma, dbeta, accumulate, coef);
   WM_LAUNCH_CHECK();
   int csh = 0;
-  if (ps.dy != nullptr && !dz && !out_relu && (ps.H & 1) == 0 && (ps.W & 1) == 0 && BN_THREADS % tpr == 0) {
+  if (ps.dy != nullptr && !dz && !out_relu && (ps.H & 1) == 0 && (ps.W & 1) == 0 && BN_THREADS % tpr == 0 &&
+      rows * tpr < (1ll << 31)) {  // (32-bit item indices in the quad kernel)
     const int n_img = (int)(rows / ((long long)ps.H * ps.W));
     bn_pool_bwd_apply<<<stream_grid(rows / 4 * tpr), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), coef, n_img, C, n_img / G, remask ? 1 : 0, static_cast<uint16_t*>(dy), ps);

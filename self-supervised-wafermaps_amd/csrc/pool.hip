@@ -76,15 +76,16 @@ __global__ __launch_bounds__(PL_THREADS) void bn_relu_maxpool_fwd(const uint16_t
                                                                   uint16_t* __restrict__ y,
                                                                   uint8_t* __restrict__ idx,
                                                                   uint16_t* __restrict__ xsel) {
-  const int cpr = C >> 3;
-  const long long total = (long long)N * P * Q * cpr;
-  for (long long t = (long long)blockIdx.x * PL_THREADS + threadIdx.x; t < total;
-       t += (long long)gridDim.x * PL_THREADS) {
+  // 32-bit index arithmetic (the host checks N*P*Q*C/8 < 2^31): the kernel is VALU-bound and 64-bit
+  // divisions by run-time values cost ~150 instructions per item
+  const uint32_t cpr = (uint32_t)C >> 3;
+  const uint32_t total = (uint32_t)N * P * Q * cpr;
+  for (uint32_t t = blockIdx.x * PL_THREADS + threadIdx.x; t < total; t += gridDim.x * PL_THREADS) {
     const int c0 = (int)(t % cpr) * 8;
-    long long pix = t / cpr;
-    const int q = (int)(pix % Q);
-    pix /= Q;
-    const int p = (int)(pix % P), n = (int)(pix / P);
+    uint32_t pix = t / cpr;
+    const int q = (int)(pix % (uint32_t)Q);
+    pix /= (uint32_t)Q;
+    const int p = (int)(pix % (uint32_t)P), n = (int)(pix / (uint32_t)P);
     const int g = n / imgs_per_group;
     float sc[8], sh[8], bx[8];
 #pragma unroll
@@ -240,6 +241,7 @@ extern "C" int wm_bn_relu_maxpool3x3s2_fwd(const void* x, const float* scale, co
   WM_REQUIRE(x && scale && shift && y && idx, WM_EINVAL);
   WM_REQUIRE(N > 0 && H > 1 && W > 1 && C > 0 && G > 0, WM_EINVAL);
   WM_REQUIRE(C % 8 == 0 && N % G == 0, WM_EUNSUPPORTED);
+  WM_REQUIRE((long long)N * H * W * (C / 8) < (1ll << 31), WM_EUNSUPPORTED);  // 32-bit item indices
   const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
   bn_relu_maxpool_fwd<<<grid_for((long long)N * P * Q * (C >> 3)), PL_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
       static_cast<const uint16_t*>(x), scale, shift, N, H, W, C, P, Q, N / G, static_cast<uint16_t*>(y),
