@@ -391,6 +391,173 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   }
 }
 
+// ------------------------------------------------------------- 3x3 / stride 1 on 64 channels (layer1)
+// conv_igemm fetches the pixel operand once per TAP: nine 16-KB tiles per 128 output pixels, each
+// through L2.  On the 64-channel layers (9 k-tiles, 64 output channels per block) that re-read, not
+// MFMA issue, bounds the kernel (~545 TFLOP/s where the 128/256-channel layers reach 850-990).  Here a
+// block owns two 8x8 output tiles and DMAs their 10x10-pixel source patches into LDS ONCE (28 KB
+// instead of 144 KB); the nine taps then only shift the fragment-read address inside the patch, and
+// the loop fetches nothing but the 8-KB weight slice of the next tap (double buffered).
+//   patch layout: [tile][row 0..9][col 0..10][64 ch] = 128-byte pixels, row pitch 11 pixels (col 10 is
+//   padding); 16-byte slot = chunk ^ (col & 7).  A fragment read touches 2 rows x 8 cols: equal cols
+//   of the two rows differ in the parity of the pixel index (pitch 11 is odd), i.e. in the half of the
+//   256-byte bank line, and the 8 cols of a row take 8 distinct slots: conflict free.
+//   The per-lane addresses are 6 loop-invariant registers (3 column shifts x 2 k-steps) + immediates.
+// forward (MODE 0): source pixel of tap (r, s) = (h - 1 + r, w - 1 + s); dgrad (MODE 1, weights
+// [c][r][s][k]): (h + 1 - r, w + 1 - s).  Waves, accumulators and the epilogue (bf16 tile through LDS,
+// fused BatchNorm sums, optional residual) are those of conv_igemm<128, 64>.
+constexpr int PT_PITCH = 11;
+constexpr int PT_PIX = 10 * PT_PITCH;        // pixel slots per patch
+constexpr int PT_SLOTS = 224;                // 2 patches = 220 slots, rounded up to 28 DMA instructions
+constexpr int PT_PATCH_BYTES = PT_SLOTS * CV_ROW;
+constexpr int PT_W_BYTES = 64 * CV_ROW;      // one tap's weights: 64 rows x 64 source channels
+constexpr int PT_LDS = PT_PATCH_BYTES + 2 * PT_W_BYTES;
+
+template <int MODE>
+__global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
+  constexpr bool DGRAD = MODE != 0;
+  extern __shared__ __attribute__((aligned(16))) uint8_t cv_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;  // 8x8 tile of the pair, 32-channel half
+  const int tw_n = a.DW >> 3, tiles_img = (a.DH >> 3) * tw_n;
+  const uint32_t smem_base = lds_addr(cv_smem);
+
+  // ---- patches: 28 instructions x 8 pixel slots; wave w issues instructions w, w + 4, ...
+  {
+    const int sl = lane & 7;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) {
+      const int j = wave + 4 * i;
+      const int gp = 8 * j + (lane >> 3);
+      const int t = gp >= PT_PIX ? 1 : 0;
+      const int pp = gp - t * PT_PIX;
+      const int py = pp / PT_PITCH, px = pp - py * PT_PITCH;
+      const int T = blockIdx.x * 2 + t;
+      const int n = T / tiles_img, tr = T - n * tiles_img;
+      const int th = tr / tw_n, tw = tr - th * tw_n;
+      const int h = th * 8 - 1 + py, w = tw * 8 - 1 + px;
+      const bool ok = gp < 2 * PT_PIX && px < 10 && (unsigned)h < (unsigned)a.SH && (unsigned)w < (unsigned)a.SW;
+      const int chunk = sl ^ (px & 7);
+      const uint16_t* src = ok ? a.src + ((size_t)(n * a.SH + h) * a.SW + w) * 64 + chunk * 8
+                               : conv_zero_page + chunk * 8;
+      glds16_at(src, smem_base + j * 1024);
+    }
+  }
+  // ---- weights of one tap: 8 instructions, two per wave (rows rowl, rowl + 32)
+  const int rowl = tid >> 3;
+  const int wchunk = (tid & 7) ^ (rowl & 7);
+  const size_t wrow = (size_t)9 * 64;
+  const uint16_t* pb0 = a.wt + (size_t)rowl * wrow + wchunk * 8;
+  const uint16_t* pb1 = pb0 + 32 * wrow;
+  auto issue_w = [&](int tap, uint32_t stage) {
+    glds16_at(pb0 + tap * 64, stage + (wave * 8) * CV_ROW);
+    glds16_at(pb1 + tap * 64, stage + (wave * 8 + 32) * CV_ROW);
+  };
+  issue_w(0, smem_base + PT_PATCH_BYTES);
+
+  f32x4_t acc[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int fr = lane & 15, fg = lane >> 4;
+  const int dy = fr >> 3, dx = fr & 7;
+  // pixel-fragment addresses: lane base + (column shift, k-step) variant + immediate row offset
+  uint32_t xoff[3][2];
+#pragma unroll
+  for (int sh = 0; sh < 3; ++sh)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+      xoff[sh][ks] = (uint32_t)((wm * PT_PIX + dy * PT_PITCH + dx + sh) * CV_ROW + (((ks * 4 + fg) ^ ((dx + sh) & 7)) << 4));
+  uint32_t woff[2][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int row = wn * 32 + j * 16 + fr;
+      woff[j][ks] = (uint32_t)(PT_PATCH_BYTES + row * CV_ROW + (((ks * 4 + fg) ^ (row & 7)) << 4));
+    }
+
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces (patch, tap weights) landed
+    __builtin_amdgcn_s_barrier();                     // ... everyone's; and the previous tap's reads are over
+    if (tap + 1 < 9) issue_w(tap + 1, smem_base + PT_PATCH_BYTES + ((tap + 1) & 1) * PT_W_BYTES);
+    const int r = tap / 3, sx = tap % 3;
+    const int prow = DGRAD ? 2 - r : r;      // patch row shift
+    const int pcol = DGRAD ? 2 - sx : sx;    // patch column shift
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t xf[4], wf[2];
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+        xf[i] = *reinterpret_cast<const bf16x8_t*>(cv_smem + xoff[pcol][ks] + (2 * i + prow) * PT_PITCH * CV_ROW);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        wf[j] = *reinterpret_cast<const bf16x8_t*>(cv_smem + woff[j][ks] + (tap & 1) * PT_W_BYTES);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc[j][i], 0, 0, 0);
+    }
+  }
+  __syncthreads();
+
+  // ---- epilogue: accumulators -> bf16 tile in LDS ([pixel][channel], rows padded by 16 B) -> HBM
+  // tile row = wm*64 + ty*8 + tx of 8x8 tile wm
+  constexpr int CS = 64 * 2 + 16;
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int pix = wm * 64 + i * 16 + fr;  // = wm*64 + (2i + dy)*8 + dx
+      const int ch = wn * 32 + j * 16 + fg * 4;
+      const uint2 v = make_uint2(pack_bf2(acc[j][i][0], acc[j][i][1]), pack_bf2(acc[j][i][2], acc[j][i][3]));
+      *reinterpret_cast<uint2*>(cv_smem + pix * CS + ch * 2) = v;
+    }
+  __syncthreads();
+  const int T0 = blockIdx.x * 2;
+  if constexpr (MODE == 0) {
+    if (a.stat != nullptr) {
+      // column sums of the staged tile: 64 channels x 4 row slices; both 8x8 tiles lie in one statistics
+      // group (host-checked: an even number of tiles per group)
+      const int c = tid & 63, part = tid >> 6;
+      float sm = 0.f, sq = 0.f;
+      for (int rr = part * 32; rr < (part + 1) * 32; ++rr) {
+        const float v = bf2f(*reinterpret_cast<const uint16_t*>(cv_smem + rr * CS + c * 2));
+        sm += v;
+        sq = fmaf(v, v, sq);
+      }
+      const int g = (int)(((long long)(T0 / tiles_img) * a.DH * a.DW) / a.stat_rpg);
+      float* base = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 2) * 64 + c;
+      atomicAdd(base, sm);
+      atomicAdd(base + 64, sq);
+    }
+  }
+  for (int p = tid; p < 128 * 8; p += CV_THREADS) {
+    const int row = p >> 3, ch = p & 7;
+    const int T = T0 + (row >> 6);
+    const int n = T / tiles_img, tr = T - n * tiles_img;
+    const int th = tr / tw_n, tw = tr - th * tw_n;
+    const size_t pix = ((size_t)n * a.DH + th * 8 + ((row >> 3) & 7)) * a.DW + tw * 8 + (row & 7);
+    uint4 v = *reinterpret_cast<const uint4*>(cv_smem + row * CS + ch * 16);
+    if (a.res != nullptr) {
+      const uint4 r4 = *reinterpret_cast<const uint4*>(a.res + pix * 64 + ch * 8);
+      const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = pack_bf2(bf2f((uint16_t)(vv[e] & 0xffff)) + bf2f((uint16_t)(rr[e] & 0xffff)),
+                        bf2f((uint16_t)(vv[e] >> 16)) + bf2f((uint16_t)(rr[e] >> 16)));
+      v = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+    *reinterpret_cast<uint4*>(a.dst + pix * 64 + ch * 8) = v;
+  }
+}
+
 // ------------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
   const uint16_t* dy;  // [M][K]
@@ -641,6 +808,44 @@ int launch_igemm(const ConvArgs& a, hipStream_t st) {
   return WM_OK;
 }
 
+// 3x3 / stride 1 / pad 1, 64 -> 64 channels, image sides multiples of 8, an even number of 8x8 tiles
+// (and of tiles per statistics group): the patch-resident kernel.  WM_CONV_PATCH=0 keeps conv_igemm.
+inline bool conv_patch_enabled() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("WM_CONV_PATCH");
+    v = e ? atoi(e) != 0 : 1;
+  }
+  return v != 0;
+}
+
+inline bool conv_patch_ok(const ConvArgs& a) {
+  if (!conv_patch_enabled()) return false;
+  if (a.SC != 64 || a.DC != 64 || a.R != 3 || a.S != 3 || a.stride != 1 || a.pad != 1) return false;
+  if (a.SH != a.DH || a.SW != a.DW || (a.DH & 7) || (a.DW & 7) || a.bias != nullptr) return false;
+  const long long tiles = (long long)a.N * (a.DH >> 3) * (a.DW >> 3);
+  if (tiles & 1) return false;
+  if (a.stat != nullptr) {
+    if (a.stat_rpg % 128 != 0) return false;           // tiles per group even
+    if (a.stat_rpg % (a.DH * a.DW) != 0) return false;  // groups are whole images
+  }
+  return true;
+}
+
+template <int MODE>
+int launch_patch(const ConvArgs& a, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    const int rc = set_lds(&conv3x3_patch<MODE>, PT_LDS);
+    if (rc != WM_OK) return rc;
+    attr = true;
+  }
+  const int blocks = (int)((long long)a.N * (a.DH >> 3) * (a.DW >> 3) / 2);
+  conv3x3_patch<MODE><<<blocks, CV_THREADS, PT_LDS, st>>>(a);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
 template <int BMO, int CPT, int NT, bool BIAS>
 int launch_wgrad_impl(WgradArgs a, hipStream_t st) {
   constexpr int lds = 2 * (WG_PIX * BMO * 2 + NT * WG_PIX * 128);
@@ -747,6 +952,7 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
     return K % 128 == 0 ? launch_igemm<128, 128, 2, 0>(a, st) : launch_igemm<128, 64, 2, 0>(a, st);
   }
   a.nkt = R * S * (C / 64);
+  if (residual == nullptr && conv_patch_ok(a)) return launch_patch<0>(a, st);
   if (bias != nullptr || residual != nullptr)
     return K % 128 == 0 ? launch_igemm<128, 128, 8, 0, true>(a, st) : launch_igemm<128, 64, 8, 0, true>(a, st);
   return K % 128 == 0 ? launch_igemm<128, 128, 8, 0>(a, st) : launch_igemm<128, 64, 8, 0>(a, st);
@@ -786,6 +992,8 @@ static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const v
   a.res = static_cast<const uint16_t*>(residual);
   a.nkt = R * S * (K / 64);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  a.bias = nullptr;
+  if (conv_patch_ok(a)) return launch_patch<1>(a, st);
   // stride 2 with even image sides and class size % 128 == 0: parity-class ordering (no wasted taps)
   const long long cls = (long long)N * (H / 2) * (W / 2);
   if (stride == 2 && H % 2 == 0 && W % 2 == 0) {

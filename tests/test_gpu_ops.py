@@ -53,6 +53,45 @@ def test_conv2d_fwd_bwd(cfg):
     _close(wd.grad, wr.grad, rel=4e-3, what="wgrad")
 
 
+@pytest.mark.parametrize("n,h,w", [(4, 16, 16), (2, 8, 24), (6, 56, 56)])
+def test_conv3x3_patch_kernel(n, h, w):
+    """3x3 / stride 1 / 64 -> 64 channels on 8-multiple image sides runs the patch-resident kernel
+    (csrc/conv.hip conv3x3_patch): forward with fused BatchNorm sums, dgrad with the shortcut gradient
+    added in the epilogue -- against float32 torch and against the statistics of a separate pass."""
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(n + h + w)
+    x = _bf(torch.randn(n, 64, h, w, generator=g))
+    wt = _bf(torch.randn(64, 64, 3, 3, generator=g) * (2.0 / (64 * 9)) ** 0.5)
+    dy = _bf(torch.randn(n, 64, h, w, generator=g))
+    dr = _bf(torch.randn(n, 64, h, w, generator=g))
+    xr = x.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wt, None, 1, 1)
+    yr.backward(dy)
+    xd = ops.to_nhwc_bf16(x.to(DEV)).requires_grad_(True)
+    wd = wt.to(DEV).requires_grad_(True)
+    y, xres = ops.conv2d_passthrough(xd, wd, 1, 1)
+    torch.autograd.backward([y, xres], [ops.to_nhwc_bf16(dy.to(DEV)), ops.to_nhwc_bf16(dr.to(DEV))])
+    _close(y, yr.detach(), what="fwd")
+    _close(xd.grad, xr.grad + dr, what="dgrad + shortcut gradient")
+    # fused statistics == separate pass (two statistics groups = the two halves of the batch)
+    groups = 2
+    if ops.stats_fusable(n * h * w, groups):
+        gamma, beta = (torch.rand(64, generator=g) + 0.5).to(DEV), (torch.randn(64, generator=g) * 0.1).to(DEV)
+        st = torch.zeros(groups, ops.STAT_BUCKETS, 2, 64, device=DEV)
+        rm1, rv1 = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        rm2, rv2 = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+        xin = ops.to_nhwc_bf16(x.to(DEV))
+        y1 = ops.conv2d(xin, wt.to(DEV), 1, 1, stats=st, groups=groups)
+        o1 = ops.batch_norm(y1, gamma, beta, rm1, rv1, True, relu=True, groups=groups, stats=st)
+        y2 = ops.conv2d(xin, wt.to(DEV), 1, 1)
+        o2 = ops.batch_norm(y2, gamma, beta, rm2, rv2, True, relu=True, groups=groups)
+        assert torch.equal(y1, y2)
+        _close(o1, o2.float().cpu(), rel=4e-3, what="fused-stats bn out")
+        torch.testing.assert_close(rm1, rm2, atol=1e-5, rtol=1e-4)
+        torch.testing.assert_close(rv1, rv2, atol=1e-5, rtol=1e-4)
+
+
 def test_conv_weight_cache_follows_updates():
     from ssl_wafermap_amd import ops
 
