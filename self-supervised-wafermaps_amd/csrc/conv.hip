@@ -397,7 +397,11 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
 // MFMA issue, bounds the kernel (~545 TFLOP/s where the 128/256-channel layers reach 850-990).  Here a
 // block owns two 8x8 output tiles and DMAs their 10x10-pixel source patches into LDS ONCE (28 KB
 // instead of 144 KB); the nine taps then only shift the fragment-read address inside the patch, and
-// the loop fetches nothing but the 8-KB weight slice of the next tap (double buffered).
+// the loop fetches nothing but the 8-KB weight slices of the coming taps (3-stage ring, two in flight).
+// (A persistent variant -- one block per CU, all nine taps' weights resident, patches double buffered, no
+// barrier inside a step -- was measured SLOWER, 219 vs 177 us: with one wave per SIMD nothing overlaps a
+// block's fragment reads, epilogue and stores; three independent blocks per CU do.  A 4-stage weight ring
+// (61 KB of LDS, two blocks per CU) was slower as well: 194 vs 168 us.)
 //   patch layout: [tile][row 0..9][col 0..10][64 ch] = 128-byte pixels, row pitch 11 pixels (col 10 is
 //   padding); 16-byte slot = chunk ^ (col & 7).  A fragment read touches 2 rows x 8 cols: equal cols
 //   of the two rows differ in the parity of the pixel index (pitch 11 is odd), i.e. in the half of the
@@ -411,7 +415,8 @@ constexpr int PT_PIX = 10 * PT_PITCH;        // pixel slots per patch
 constexpr int PT_SLOTS = 224;                // 2 patches = 220 slots, rounded up to 28 DMA instructions
 constexpr int PT_PATCH_BYTES = PT_SLOTS * CV_ROW;
 constexpr int PT_W_BYTES = 64 * CV_ROW;      // one tap's weights: 64 rows x 64 source channels
-constexpr int PT_LDS = PT_PATCH_BYTES + 2 * PT_W_BYTES;
+constexpr int PT_WSTAGES = 3;                 // weight ring: two taps in flight ahead of the one being multiplied
+constexpr int PT_LDS = PT_PATCH_BYTES + PT_WSTAGES * PT_W_BYTES;
 
 template <int MODE>
 __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
@@ -455,6 +460,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
     glds16_at(pb1 + tap * 64, stage + (wave * 8 + 32) * CV_ROW);
   };
   issue_w(0, smem_base + PT_PATCH_BYTES);
+  issue_w(1, smem_base + PT_PATCH_BYTES + PT_W_BYTES);
+  if (PT_WSTAGES > 3) issue_w(2, smem_base + PT_PATCH_BYTES + 2 * PT_W_BYTES);
 
   f32x4_t acc[2][4];
 #pragma unroll
@@ -482,9 +489,19 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
 
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's DMA pieces (patch, tap weights) landed
+    // this wave's DMA pieces of tap `tap` (and, at tap 0, of the patches) have landed; the two
+    // instructions of tap + 1 may still be in flight
+    constexpr int AHEAD = PT_WSTAGES - 1;  // taps in flight ahead (incl. the one waited for)
+    if (tap + AHEAD - 1 < 9) {
+      if (AHEAD == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else if (tap + 1 < 9 && AHEAD == 3) {
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     __builtin_amdgcn_s_barrier();                     // ... everyone's; and the previous tap's reads are over
-    if (tap + 1 < 9) issue_w(tap + 1, smem_base + PT_PATCH_BYTES + ((tap + 1) & 1) * PT_W_BYTES);
+    if (tap + AHEAD < 9) issue_w(tap + AHEAD, smem_base + PT_PATCH_BYTES + ((tap + AHEAD) % PT_WSTAGES) * PT_W_BYTES);
     const int r = tap / 3, sx = tap % 3;
     const int prow = DGRAD ? 2 - r : r;      // patch row shift
     const int pcol = DGRAD ? 2 - sx : sx;    // patch column shift
@@ -496,7 +513,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
         xf[i] = *reinterpret_cast<const bf16x8_t*>(cv_smem + xoff[pcol][ks] + (2 * i + prow) * PT_PITCH * CV_ROW);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
-        wf[j] = *reinterpret_cast<const bf16x8_t*>(cv_smem + woff[j][ks] + (tap & 1) * PT_W_BYTES);
+        wf[j] = *reinterpret_cast<const bf16x8_t*>(cv_smem + woff[j][ks] + (tap % PT_WSTAGES) * PT_W_BYTES);
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
