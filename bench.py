@@ -34,9 +34,10 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md chip table
 # HBM-side bytes per conv launch (mean over the 65 implicit-GEMM launches of a step), measured with
 # rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of this same script, FETCH_SIZE doubled per the
 # gfx950 correction (calibrated on sgd_step: 138.1 / 92.0 MB measured vs 138.0 / 92.0 MB algorithmic):
-# profiles/r01_hbm_traffic_simclr_r18.md.  A PMC pass cannot run inside the timed region, so this is the
+# profiles/r01_hbm_traffic_simclr_r18_v2.md.  A PMC pass cannot run inside the timed region, so this is the
 # committed measurement, not a live one.  Algorithmic bytes (every operand once): 230 MB per launch.
-CONV_TRAFFIC_BYTES_PER_LAUNCH = 531.0e6
+# (The counter sits behind L2: repeats served by the 256-MB Infinity Cache are included.)
+CONV_TRAFFIC_BYTES_PER_LAUNCH = 518.0e6
 R18_GFLOP_PER_SAMPLE = 21.76    # ResNet-18 fwd 3.627 GFLOP x 3 (fwd+bwd) x 2 views
 
 
@@ -208,10 +209,10 @@ def main():
             work = sum(v["work"] for v in summ.values())
             ms = sum(v["ms"] for v in summ.values())
             ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "conv_igemm + conv_wgrad (implicit-GEMM, bf16 MFMA)",
+            roof = {"bound": "mfma", "kernel": "conv_igemm + conv3x3_patch + conv_wgrad (implicit-GEMM, bf16 MFMA)",
                     "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": CONV_TRAFFIC_BYTES_PER_LAUNCH,
-                    "traffic_source": "profiles/r01_hbm_traffic_simclr_r18.md (rocprofv3 --pmc, separate passes)",
+                    "traffic_source": "profiles/r01_hbm_traffic_simclr_r18_v2.md (rocprofv3 --pmc, separate passes)",
                     "launches": int(sum(v["launches"] for v in summ.values())),
                     "sampled_steps": timed_steps,
                     "kernel_ms_per_step": round(ms / max(timed_steps, 1), 3),
