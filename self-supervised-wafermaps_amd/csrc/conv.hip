@@ -70,7 +70,7 @@ __device__ __attribute__((aligned(256))) uint16_t conv_zero_page[128];
 // on the fragment reads).  Two stages; the tile for k-step kt+1 is in flight under the MFMAs of kt:
 //   s_waitcnt vmcnt(0) ; s_barrier ; issue(kt+1) ; compute(kt)
 // MODE 0: forward.  MODE 1: dgrad (any stride; stride-2 taps that do not hit a source pixel are
-// fetched as zeros).  MODE 2: dgrad of a stride-2 convolution with the destination pixels ordered by
+// fetched as zeros).  MODE 3: dgrad, stride 1 only (the common case, without the stride-2 address path).  MODE 2: dgrad of a stride-2 convolution with the destination pixels ordered by
 // parity class (h&1, w&1): all 128 rows of a tile then share the set of taps that hit a source
 // pixel (r = r0 + 2 jr, s = s0 + 2 js), so only those k-tiles are executed — 9/4 instead of 9 per
 // pixel for 3x3, and three of four classes of the 1x1 downsample just store zeros.
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
       } else {
         const int th = bh[i] - r, tw = bw[i] - s;
         ok = ok && th >= 0 && tw >= 0;
-        if (a.stride == 2) {
+        if (MODE == 1 && a.stride == 2) {  // MODE 3: stride 1 known at compile time
           ok = ok && (((th | tw) & 1) == 0);
           const int sh = th >> 1, sw = tw >> 1;
           ok = ok && sh < a.SH && sw < a.SW;
@@ -1017,6 +1017,9 @@ static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const v
     if (C % 128 == 0 && cls % 128 == 0) return launch_igemm<128, 128, 8, 2>(a, st);
     if (C % 128 != 0 && cls % 128 == 0) return launch_igemm<128, 64, 8, 2>(a, st);
   }
+  // stride 1: MODE 3 = MODE 1 without the stride-2 address path in the k-loop's issue phase (hipcc
+  // if-converts the run-time branch: its 64-bit address arithmetic was executed on every k-step)
+  if (stride == 1) return C % 128 == 0 ? launch_igemm<128, 128, 8, 3>(a, st) : launch_igemm<128, 64, 8, 3>(a, st);
   return C % 128 == 0 ? launch_igemm<128, 128, 8, 1>(a, st) : launch_igemm<128, 64, 8, 1>(a, st);
 }
 
