@@ -71,10 +71,11 @@ __device__ __forceinline__ NxIds nx_ids(int local_row, int b_local, int b_global
 }
 
 __device__ __forceinline__ void nx_load_rows(const float* __restrict__ src, int first, int count,
-                                             int limit, int d, int stride, float* dst, int tid) {
+                                             int limit, int d, int stride, float* dst, int tid,
+                                             int nthreads = 256) {
   const int d4 = d >> 2;
   const int total = count * d4;
-  for (int p = tid; p < total; p += 256) {
+  for (int p = tid; p < total; p += nthreads) {
     const int row = p / d4, c4 = p - row * d4;
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (first + row < limit) v = *reinterpret_cast<const float4*>(src + (size_t)(first + row) * d + c4 * 4);
@@ -102,7 +103,9 @@ __device__ __forceinline__ void nx_dots(const float* rowt, const float* colt, in
   }
 }
 
-__global__ __launch_bounds__(256) void ntxent_fwd_kernel(const float* __restrict__ zn,
+// WAVES waves per block, 8 local rows per wave
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void ntxent_fwd_kernel(const float* __restrict__ zn,
                                                          const float* __restrict__ zall,
                                                          int b_local, int b_global,
                                                          int rank_offset, int d, float temp,
@@ -111,12 +114,13 @@ __global__ __launch_bounds__(256) void ntxent_fwd_kernel(const float* __restrict
   extern __shared__ __attribute__((aligned(16))) float nx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nlocal = 2 * b_local, nglobal = 2 * b_global;
-  const int row0 = blockIdx.x * NX_RT;
+  constexpr int RT = 8 * WAVES, NTH = 64 * WAVES;
+  const int row0 = blockIdx.x * RT;
   const int cstride = d + NX_PAD;
   float* rowt = nx_smem;                 // [NX_RT][d]
-  float* colt = nx_smem + NX_RT * d;     // [NX_CT][d + pad]
+  float* colt = nx_smem + RT * d;        // [NX_CT][d + pad]
 
-  nx_load_rows(zn, row0, NX_RT, nlocal, d, d, rowt, tid);
+  nx_load_rows(zn, row0, RT, nlocal, d, d, rowt, tid, NTH);
 
   float m[8], l[8], pos[8];
   int self_g[8], pos_g[8];
@@ -133,7 +137,7 @@ __global__ __launch_bounds__(256) void ntxent_fwd_kernel(const float* __restrict
 
   for (int j0 = 0; j0 < nglobal; j0 += NX_CT) {
     __syncthreads();  // previous tile fully consumed (and rowt visible on the first pass)
-    nx_load_rows(zall, j0, NX_CT, nglobal, d, cstride, colt, tid);
+    nx_load_rows(zall, j0, NX_CT, nglobal, d, cstride, colt, tid, NTH);
     __syncthreads();
     float acc[8];
     nx_dots(rowt, colt, d, cstride, wave, lane, acc);
@@ -164,10 +168,13 @@ __global__ __launch_bounds__(256) void ntxent_fwd_kernel(const float* __restrict
   }
 }
 
+// blockIdx.y = column split (tiles_per_split column tiles each): with one block per 32 local rows the
+// 512 x 512 problem of the headline configuration ran on 16 CUs for 160 us.  Split blocks add their
+// partial row gradients into a zeroed dzn with f32 atomics (nsplit == 1: plain stores, deterministic).
 __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
     const float* __restrict__ zn, const float* __restrict__ zall,
     const float* __restrict__ lse_all, int b_local, int b_global, int rank_offset, int d,
-    float temp, float grad_scale, float* __restrict__ dzn) {
+    float temp, float grad_scale, int tiles_per_split, int nsplit, float* __restrict__ dzn) {
   extern __shared__ __attribute__((aligned(16))) float nx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nlocal = 2 * b_local, nglobal = 2 * b_global;
@@ -198,7 +205,9 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
 #pragma unroll
   for (int u = 0; u < 8; ++u) out[u] = make_float4(0.f, 0.f, 0.f, 0.f);
 
-  for (int j0 = 0; j0 < nglobal; j0 += NX_CT) {
+  const int jbegin = blockIdx.y * tiles_per_split * NX_CT;
+  const int jend = min(nglobal, jbegin + tiles_per_split * NX_CT);
+  for (int j0 = jbegin; j0 < jend; j0 += NX_CT) {
     __syncthreads();
     nx_load_rows(zall, j0, NX_CT, nglobal, d, cstride, colt, tid);
     __syncthreads();
@@ -240,7 +249,15 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
       if (u < nu) {
         float4 o = out[u];
         o.x *= sc; o.y *= sc; o.z *= sc; o.w *= sc;
-        *reinterpret_cast<float4*>(dzn + (size_t)lr * d + gsel * 4 + u * 32) = o;
+        float* dst = dzn + (size_t)lr * d + gsel * 4 + u * 32;
+        if (nsplit == 1) {
+          *reinterpret_cast<float4*>(dst) = o;
+        } else {
+          atomicAdd(dst, o.x);
+          atomicAdd(dst + 1, o.y);
+          atomicAdd(dst + 2, o.z);
+          atomicAdd(dst + 3, o.w);
+        }
       }
     }
   }
@@ -291,15 +308,16 @@ extern "C" int wm_ntxent_fwd(const float* zn, const float* zall, int b_local, in
                              float* loss_rows, void* stream) {
   const int rc = nx_check(zn, zall, lse, loss_rows, b_local, b_global, rank_offset, d, temperature);
   if (rc != WM_OK) return rc;
-  const size_t lds = ((size_t)NX_RT * d + (size_t)NX_CT * (d + NX_PAD)) * sizeof(float);
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntxent_fwd_kernel),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntxent_fwd_kernel<4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  ntxent_fwd_kernel<<<wm_cdiv(2 * b_local, NX_RT), 256, lds, static_cast<hipStream_t>(stream)>>>(
+  // (one-wave blocks -- 4x as many -- were slower: 122 vs 73 us; every block streams all of zall through LDS)
+  const size_t lds = ((size_t)NX_RT * d + (size_t)NX_CT * (d + NX_PAD)) * sizeof(float);
+  ntxent_fwd_kernel<4><<<wm_cdiv(2 * b_local, NX_RT), 256, lds, static_cast<hipStream_t>(stream)>>>(
       zn, zall, b_local, b_global, rank_offset, d, temperature, lse, loss_rows);
   WM_LAUNCH_CHECK();
   return WM_OK;
@@ -319,8 +337,19 @@ extern "C" int wm_ntxent_bwd(const float* zn, const float* zall, const float* ls
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  ntxent_bwd_kernel<<<wm_cdiv(2 * b_local, NX_RT), 256, lds, static_cast<hipStream_t>(stream)>>>(
-      zn, zall, lse_all, b_local, b_global, rank_offset, d, temperature, grad_scale, dzn);
+  const int rowtiles = wm_cdiv(2 * b_local, NX_RT), coltiles = wm_cdiv(2 * b_global, NX_CT);
+  int nsplit = 256 / rowtiles;  // about one block per CU
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > coltiles) nsplit = coltiles;
+  const int tiles_per_split = wm_cdiv(coltiles, nsplit);
+  nsplit = wm_cdiv(coltiles, tiles_per_split);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nsplit > 1) {
+    hipError_t e = hipMemsetAsync(dzn, 0, (size_t)2 * b_local * d * sizeof(float), st);
+    if (e != hipSuccess) return (int)e;
+  }
+  ntxent_bwd_kernel<<<dim3(rowtiles, nsplit), 256, lds, st>>>(
+      zn, zall, lse_all, b_local, b_global, rank_offset, d, temperature, grad_scale, tiles_per_split, nsplit, dzn);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
