@@ -568,3 +568,16 @@ def test_msn_losses_match_oracle(pmsn):
     assert abs(float(loss.detach()) - float(ref.detach())) <= 3e-2 * abs(float(ref.detach())) + 2e-2, (float(loss), float(ref))
     c = torch.nn.functional.cosine_similarity(ad.grad.float().cpu().flatten(), ar.grad.flatten(), dim=0)
     assert float(c) > 0.97, float(c)
+
+
+@pytest.mark.gpu
+def test_std_of_l2_normalized_matches_torch():
+    """rep_std (lightly.utils.debug.std_of_l2_normalized): wm_l2_normalize + wm_colstats against torch."""
+    from ssl_wafermap_amd.utils.debug import std_of_l2_normalized
+
+    g = torch.Generator().manual_seed(3)
+    for rows, c in ((256, 512), (37, 96), (2, 8)):
+        z = torch.randn(rows, c, generator=g) * 3 + 0.5
+        ref = torch.std(torch.nn.functional.normalize(z, dim=1), dim=0).mean()
+        got = std_of_l2_normalized(z.to("cuda:0"))
+        assert abs(float(got) - float(ref)) <= 1e-6 + 1e-5 * abs(float(ref)), (rows, c, float(got), float(ref))
