@@ -227,22 +227,24 @@ int wm_cast_f32_bf16(const float* x, long long n, void* y, void* stream);
  * (G = 2 reproduces the reference's two separate forward(x0), forward(x1) calls on the
  * concatenated batch).  out = relu?(bn(y) (+ residual)).  running_* are updated once per group in
  * order (torch momentum convention, unbiased variance); save_mean/save_invstd are [G][C].
+ * num_batches_tracked (torch's int64 buffer, may be NULL) is incremented by G inside the finalize kernel.
  * C % 8 == 0, C <= 2048, rows % G == 0. */
 size_t wm_bn_workspace_bytes(long long rows, int C, int G);
 int wm_bn_train_fwd(const void* y, const void* residual, const float* gamma, const float* beta,
-                    float* running_mean, float* running_var, long long rows, int C, int G, float eps,
+                    float* running_mean, float* running_var, long long* num_batches_tracked, long long rows, int C, int G, float eps,
                     float momentum, int relu, float* save_mean, float* save_invstd, void* out,
                     void* workspace, size_t workspace_bytes, void* stream);
 /* Training forward whose statistics were accumulated by wm_conv2d_fwd_stats. */
 int wm_bn_train_fwd_from_stats(const void* y, const void* residual, const float* gamma, const float* beta,
-                               float* running_mean, float* running_var, long long rows, int C, int G,
-                               float eps, float momentum, int relu, float* save_mean, float* save_invstd,
+                               float* running_mean, float* running_var, long long* num_batches_tracked,
+                               long long rows, int C, int G, float eps, float momentum, int relu, float* save_mean,
+                               float* save_invstd,
                                void* out, float* stat_part, int stat_buckets, void* workspace,
                                size_t workspace_bytes, void* stream);
 /* Statistics only: mean / invstd / running stats and the [G][C] scale, shift of the normalisation, for a
  * consumer that applies it itself (the fused stem below).  stat_part NULL: computed from y here. */
 int wm_bn_train_stats(const void* y, const float* gamma, const float* beta, float* running_mean,
-                      float* running_var, long long rows, int C, int G, float eps, float momentum,
+                      float* running_var, long long* num_batches_tracked, long long rows, int C, int G, float eps, float momentum,
                       float* save_mean, float* save_invstd, float* scale, float* shift, float* stat_part,
                       int stat_buckets, void* workspace, size_t workspace_bytes, void* stream);
 int wm_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,

@@ -94,17 +94,17 @@ SIGNATURES = {
     "wm_bn_workspace_bytes": (c_size_t, [c_longlong, c_int, c_int]),
     "wm_bn_train_fwd": (
         c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_float,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_float,
          c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "wm_bn_train_fwd_from_stats": (
         c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_float,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_float,
          c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
     ),
     "wm_bn_train_stats": (
         c_int,
-        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_float, c_void_p,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_float, c_void_p,
          c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
     ),
     "wm_bn_eval_scale_shift": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_float, c_void_p, c_void_p, c_void_p]),

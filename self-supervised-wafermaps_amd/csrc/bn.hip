@@ -249,9 +249,11 @@ __device__ __forceinline__ void finalize_sums(float* __restrict__ part, int nblk
 __global__ __launch_bounds__(1024) void bn_fwd_finalize(
     float* __restrict__ part, int nblk, int G, int C, int rows_per_group, int clear,
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
-    float* __restrict__ running_mean, float* __restrict__ running_var, float* __restrict__ mean,
-    float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
+    float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ num_batches_tracked,
+    float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
   __shared__ double red[2][32][33];
+  // torch's num_batches_tracked += 1 per forward call; the G groups are G calls (one lane of the launch)
+  if (num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += G;
   const int bl = threadIdx.x >> 5, cl = threadIdx.x & 31;
   const int c = blockIdx.x * 32 + cl;
   const bool owner = bl == 0 && c < C;
@@ -601,11 +603,13 @@ constexpr int BN_WIDE_MAX_C = 16384;
 
 __global__ __launch_bounds__(BN_THREADS) void bn_col_fwd(const uint16_t* __restrict__ y, const uint16_t* __restrict__ res,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                         float* __restrict__ rmean, float* __restrict__ rvar, int rpg,
+                                                         float* __restrict__ rmean, float* __restrict__ rvar,
+                                                         long long* __restrict__ num_batches_tracked, int rpg,
                                                          int C, int G, float eps, float momentum, int relu, int training,
                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                          uint16_t* __restrict__ out) {
   const int c = blockIdx.x * BN_THREADS + threadIdx.x;
+  if (training && num_batches_tracked != nullptr && c == 0) *num_batches_tracked += G;
   if (c >= C) return;
   const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   for (int g = 0; g < G; ++g) {
@@ -707,7 +711,7 @@ extern "C" size_t wm_bn_workspace_bytes(long long rows, int C, int G) {
 
 extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float* gamma,
                                const float* beta, float* running_mean, float* running_var,
-                               long long rows, int C, int G, float eps, float momentum, int relu,
+                               long long* num_batches_tracked, long long rows, int C, int G, float eps, float momentum, int relu,
                                float* save_mean, float* save_invstd, void* out, void* workspace,
                                size_t workspace_bytes, void* stream) {
   WM_REQUIRE(y && out && save_mean && save_invstd && workspace, WM_EINVAL);
@@ -719,7 +723,7 @@ extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float*
   if (bn_wide(rows, C, G)) {
     bn_col_fwd<<<wm_cdiv(C, BN_THREADS), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(residual), gamma, beta, running_mean, running_var,
-        rpg, C, G, eps, momentum, relu, 1, save_mean, save_invstd, static_cast<uint16_t*>(out));
+        num_batches_tracked, rpg, C, G, eps, momentum, relu, 1, save_mean, save_invstd, static_cast<uint16_t*>(out));
     WM_LAUNCH_CHECK();
     return WM_OK;
   }
@@ -733,7 +737,7 @@ extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float*
                                                        nullptr, nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk), part, PoolSrc{});
   WM_LAUNCH_CHECK();
   bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, 0, gamma, beta, eps, momentum, running_mean,
-                                                   running_var, save_mean, save_invstd, scale, shift);
+                                                   running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   WM_LAUNCH_CHECK();
   launch_bn_apply(y, residual, scale, shift, rows, C, rpg, relu, out, st);
   WM_LAUNCH_CHECK();
@@ -744,7 +748,8 @@ extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float*
 // (wm_conv2d_fwd_stats): finalize (and clear) stat_part [G][stat_buckets][2][C], then apply.
 extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, const float* gamma,
                                           const float* beta, float* running_mean, float* running_var,
-                                          long long rows, int C, int G, float eps, float momentum, int relu,
+                                          long long* num_batches_tracked, long long rows, int C, int G, float eps,
+                                          float momentum, int relu,
                                           float* save_mean, float* save_invstd, void* out, float* stat_part,
                                           int stat_buckets, void* workspace, size_t workspace_bytes,
                                           void* stream) {
@@ -758,7 +763,7 @@ extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, c
   float* scale = static_cast<float*>(workspace);
   float* shift = scale + (size_t)G * C;
   bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(stat_part, stat_buckets, G, C, rpg, 1, gamma, beta, eps, momentum,
-                                                   running_mean, running_var, save_mean, save_invstd, scale, shift);
+                                                   running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   WM_LAUNCH_CHECK();
   launch_bn_apply(y, residual, scale, shift, rows, C, rpg, relu, out, st);
   WM_LAUNCH_CHECK();
@@ -769,7 +774,7 @@ extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, c
 // [G][C] each, for a consumer that applies the normalisation itself (wm_bn_relu_maxpool3x3s2_fwd).
 // stat_part non-NULL: statistics were fused into the producing convolution; else they are computed here.
 extern "C" int wm_bn_train_stats(const void* y, const float* gamma, const float* beta, float* running_mean,
-                                 float* running_var, long long rows, int C, int G, float eps, float momentum,
+                                 float* running_var, long long* num_batches_tracked, long long rows, int C, int G, float eps, float momentum,
                                  float* save_mean, float* save_invstd, float* scale, float* shift, float* stat_part,
                                  int stat_buckets, void* workspace, size_t workspace_bytes, void* stream) {
   WM_REQUIRE(y && save_mean && save_invstd && scale && shift && workspace, WM_EINVAL);
@@ -780,7 +785,7 @@ extern "C" int wm_bn_train_stats(const void* y, const float* gamma, const float*
   if (stat_part) {
     WM_REQUIRE(stat_buckets > 0, WM_EINVAL);
     bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(stat_part, stat_buckets, G, C, rpg, 1, gamma, beta, eps, momentum,
-                                                     running_mean, running_var, save_mean, save_invstd, scale, shift);
+                                                     running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   } else {
     WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
     const int nblk = reduce_blocks(rpg, C);
@@ -791,7 +796,7 @@ extern "C" int wm_bn_train_stats(const void* y, const float* gamma, const float*
                                                          nullptr, nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk), part, PoolSrc{});
     WM_LAUNCH_CHECK();
     bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, 0, gamma, beta, eps, momentum, running_mean,
-                                                     running_var, save_mean, save_invstd, scale, shift);
+                                                     running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   }
   WM_LAUNCH_CHECK();
   return WM_OK;
@@ -820,7 +825,7 @@ extern "C" int wm_bn_eval_fwd(const void* y, const void* residual, const float* 
   if (bn_wide(rows, C, 1)) {
     bn_col_fwd<<<wm_cdiv(C, BN_THREADS), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(residual), gamma, beta,
-        const_cast<float*>(running_mean), const_cast<float*>(running_var), (int)rows, C, 1, eps, 0.f, relu, 0, nullptr,
+        const_cast<float*>(running_mean), const_cast<float*>(running_var), nullptr, (int)rows, C, 1, eps, 0.f, relu, 0, nullptr,
         nullptr, static_cast<uint16_t*>(out));
     WM_LAUNCH_CHECK();
     return WM_OK;

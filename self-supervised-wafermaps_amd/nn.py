@@ -60,19 +60,19 @@ class _BatchNorm(nn.Module):
         return buf
 
     def forward(self, x, residual=None, relu=False, stats=None):
-        if self.training:
-            self.num_batches_tracked += ops.current_bn_groups()
+        # num_batches_tracked (+1 per forward call = + the number of statistics groups) is incremented inside
+        # the statistics kernel: 22 one-block torch kernels per ResNet-18 step otherwise
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                              residual=residual, relu=relu, eps=self.eps, momentum=self.momentum, stats=stats)
+                              residual=residual, relu=relu, eps=self.eps, momentum=self.momentum, stats=stats,
+                              num_batches_tracked=self.num_batches_tracked)
 
 
 class BatchNorm2d(_BatchNorm):
     def forward_relu_maxpool(self, x, stats=None):
         """maxpool3x3s2(relu(self(x))) fused (ResNet stem)."""
-        if self.training:
-            self.num_batches_tracked += ops.current_bn_groups()
         return ops.bn_relu_maxpool(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                   eps=self.eps, momentum=self.momentum, stats=stats)
+                                   eps=self.eps, momentum=self.momentum, stats=stats,
+                                   num_batches_tracked=self.num_batches_tracked)
 
 
 class BatchNorm1d(_BatchNorm):

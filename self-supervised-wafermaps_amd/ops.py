@@ -347,7 +347,7 @@ def _as_act(x: torch.Tensor) -> torch.Tensor:
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, residual, gamma, beta, running_mean, running_var, training, groups, eps, momentum, relu,
-                stats=None):
+                stats=None, counter=None):
         _need_cuda(y, "batch_norm")
         y = _as_act(y)
         if residual is not None:
@@ -365,14 +365,15 @@ class _BatchNorm(torch.autograd.Function):
             invstd = torch.empty_like(mean)
             if stats is not None and stats_fusable(rows, groups):
                 check(lib.wm_bn_train_fwd_from_stats(y.data_ptr(), ptr(residual) if residual is not None else 0,
-                                                     ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), rows, c,
+                                                     ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                                     ptr(counter), rows, c,
                                                      groups, eps, momentum, int(relu), ptr(mean), ptr(invstd),
                                                      out.data_ptr(), ptr(stats), STAT_BUCKETS, ptr(ws), ws.numel(),
                                                      stream_ptr()), "wm_bn_train_fwd_from_stats")
             else:
                 check(lib.wm_bn_train_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma),
-                                          ptr(beta), ptr(running_mean), ptr(running_var), rows, c, groups, eps, momentum,
-                                          int(relu), ptr(mean), ptr(invstd), out.data_ptr(), ptr(ws), ws.numel(),
+                                          ptr(beta), ptr(running_mean), ptr(running_var), ptr(counter), rows, c, groups, eps,
+                                          momentum, int(relu), ptr(mean), ptr(invstd), out.data_ptr(), ptr(ws), ws.numel(),
                                           stream_ptr()), "wm_bn_train_fwd")
             # a ReLU'd BN without residual recomputes its mask from y in the backward: `out` is not needed
             mask_from_y = relu and residual is None and gamma is not None and beta is not None
@@ -407,24 +408,27 @@ class _BatchNorm(torch.autograd.Function):
                                   ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(), dz.data_ptr() if has_res else 0,
                                   ptr(ws), ws.numel(), stream_ptr()), "wm_bn_train_bwd")
         if direct:
-            return dy, dz, None, None, None, None, None, None, None, None, None, None
-        return dy, dz, dgamma, dbeta, None, None, None, None, None, None, None, None
+            return dy, dz, None, None, None, None, None, None, None, None, None, None, None
+        return dy, dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None
 
 
 def batch_norm(y, gamma, beta, running_mean, running_var, training: bool, residual=None, relu: bool = False,
-               eps: float = 1e-5, momentum: float = 0.1, groups: Optional[int] = None, stats=None):
+               eps: float = 1e-5, momentum: float = 0.1, groups: Optional[int] = None, stats=None,
+               num_batches_tracked=None):
     """out = relu?(BN(y) (+ residual)) on bf16 [N,C,H,W] (NHWC) or [B,C].  `stats`: the buffer the
-    producing conv2d(..., stats=) accumulated into (same `groups`)."""
+    producing conv2d(..., stats=) accumulated into (same `groups`).  `num_batches_tracked` (int64 scalar
+    tensor): incremented by `groups` inside the statistics kernel when training."""
     g = current_bn_groups() if groups is None else groups
     return _BatchNorm.apply(y, residual, gamma, beta, running_mean, running_var, bool(training), int(g), float(eps),
-                            float(momentum), bool(relu), stats)
+                            float(momentum), bool(relu), stats, num_batches_tracked)
 
 
 class _BnReluMaxPool(torch.autograd.Function):
     """ResNet stem tail: maxpool3x3s2(relu(BN(y))) without materialising the normalised activation."""
 
     @staticmethod
-    def forward(ctx, y, gamma, beta, running_mean, running_var, training, groups, eps, momentum, stats=None):
+    def forward(ctx, y, gamma, beta, running_mean, running_var, training, groups, eps, momentum, stats=None,
+                counter=None):
         _need_cuda(y, "bn_relu_maxpool")
         y = _as_nhwc(y)
         n, c, h, w = y.shape
@@ -439,7 +443,8 @@ class _BnReluMaxPool(torch.autograd.Function):
             mean, invstd = torch.empty_like(scale), torch.empty_like(scale)
             ws = _bn_workspace(rows, c, g, y.device)
             fused = stats is not None and stats_fusable(rows, g)
-            check(lib.wm_bn_train_stats(y.data_ptr(), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), rows, c, g,
+            check(lib.wm_bn_train_stats(y.data_ptr(), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                        ptr(counter), rows, c, g,
                                         eps, momentum, ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
                                         ptr(stats) if fused else 0, STAT_BUCKETS, ptr(ws), ws.numel(), stream_ptr()),
                   "wm_bn_train_stats")
@@ -482,16 +487,16 @@ class _BnReluMaxPool(torch.autograd.Function):
                                          ptr(mean), ptr(invstd), g, ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(),
                                          ptr(ws), ws.numel(), stream_ptr()), "wm_bn_relu_maxpool_bwd")
         if direct:
-            return dy, None, None, None, None, None, None, None, None, None
-        return dy, dgamma, dbeta, None, None, None, None, None, None, None
+            return dy, None, None, None, None, None, None, None, None, None, None
+        return dy, dgamma, dbeta, None, None, None, None, None, None, None, None
 
 
 def bn_relu_maxpool(y, gamma, beta, running_mean, running_var, training: bool, eps: float = 1e-5,
-                    momentum: float = 0.1, groups: Optional[int] = None, stats=None):
+                    momentum: float = 0.1, groups: Optional[int] = None, stats=None, num_batches_tracked=None):
     """max_pool3x3s2(relu(batch_norm(y))) in one pass over y (ResNet stem)."""
     g = current_bn_groups() if groups is None else groups
     return _BnReluMaxPool.apply(y, gamma, beta, running_mean, running_var, bool(training), int(g), float(eps),
-                                float(momentum), stats)
+                                float(momentum), stats, num_batches_tracked)
 
 
 class _MaxPool(torch.autograd.Function):

@@ -390,3 +390,29 @@ def test_bn_relu_maxpool_fused_matches_unfused(groups, training, hw):
         d = (b[1].float().cpu() - yr.grad).abs()
         assert (d <= 1e-2 * yr.grad.abs().max()).float().mean() > 0.995
         torch.testing.assert_close(b[4], a[4]); torch.testing.assert_close(b[5], a[5])
+
+
+@pytest.mark.gpu
+def test_batchnorm_module_counts_batches_in_the_statistics_kernel():
+    """num_batches_tracked += 1 per reference forward call = + the number of statistics groups, done by the
+    finalize kernel (fused-statistics path, plain path, wide path and the fused stem tail); eval leaves it."""
+    from ssl_wafermap_amd import nn as wnn
+    from ssl_wafermap_amd import ops
+
+    g = torch.Generator().manual_seed(0)
+    bn = wnn.BatchNorm2d(64).to(DEV).train()
+    x = ops.to_nhwc_bf16(torch.randn(4, 64, 8, 8, generator=g).to(DEV))
+    with ops.bn_groups(2):
+        bn(x)
+    assert int(bn.num_batches_tracked) == 2
+    bn(x)
+    assert int(bn.num_batches_tracked) == 3
+    with ops.bn_groups(2):
+        bn.forward_relu_maxpool(x)
+    assert int(bn.num_batches_tracked) == 5
+    bn.eval()
+    bn(x)
+    assert int(bn.num_batches_tracked) == 5
+    wide = wnn.BatchNorm1d(4096).to(DEV).train()
+    wide(torch.randn(16, 4096, generator=g).to(DEV).bfloat16())
+    assert int(wide.num_batches_tracked) == 1
