@@ -5,7 +5,8 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 One step = one pass of the hot path over one batch: fused two-view augmentation of 256 wafers per
-GPU -> ResNet-18 forward/backward on 2 x 256 images (3 x 224 x 224, bf16, BN statistics per view) ->
+GPU (written in the stem's space-to-depth layout) -> ResNet-18 forward/backward on 2 x 256 images
+(3 x 224 x 224, bf16, BN statistics per view) ->
 SimCLR projection head -> NT-Xent (in-batch negatives) -> (N > 1: flat RCCL all-reduce of the
 gradient arena) -> fused SGD.  All device work runs in the hand-written HIP kernels of
 libwafer_hip.so; inputs (the ragged uint8 wafer store) are resident in HBM before the timed region.
@@ -141,10 +142,12 @@ def main():
     (opt,), _ = model.configure_optimizers()
     sync = wdist.GradSync(opt)
     rng = np.random.default_rng(rank)
+    # the augmentation kernel writes the 2x2 space-to-depth layout the stem convolution consumes (no layout pass)
+    FMT = "s2d_bf16"
 
     def eager_step(i):
         idx = (np.arange(B) + i * B) % len(ds)
-        batch = ds.get_batch(idx, rng)
+        batch = ds.get_batch(idx, rng, fmt=FMT)
         opt.zero_grad()
         loss = model.training_step(batch, i)
         loss.backward()
@@ -172,7 +175,7 @@ def main():
         try:
             from ssl_wafermap_amd.graph import GraphedTrainStep
 
-            graphed = GraphedTrainStep(model, opt, ds, B).capture(np.arange(B), rng, sync)
+            graphed = GraphedTrainStep(model, opt, ds, B, fmt=FMT).capture(np.arange(B), rng, sync)
             for i in range(2):
                 step(i)
         except Exception as e:  # capture is an optimisation: report and continue eagerly

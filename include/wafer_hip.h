@@ -63,6 +63,8 @@ const char* wm_error_string(int code);
 #define WM_IMG_NCHW_F32 0  /* [n][3][S][S] float32 (the reference's tensor layout)            */
 #define WM_IMG_NHWC_BF16 1 /* [n][S][S][3] bf16     (channels_last, feeds the conv kernels)   */
 #define WM_IMG_HW_U8 2     /* [n][S][S]    uint8    (pre-ToTensor grey image, for parity checks) */
+#define WM_IMG_S2D_BF16 3  /* [n][S/2][S/2][16] bf16: 2x2 space-to-depth of the NHWC image, channel = dh*6 + dw*3 + c,
+                              12..15 zero -- the layout the stem convolution consumes (wm_image_to_s2d's output) */
 
 typedef struct WmViewParams {
   int32_t sample;      /* index into the wafer store                                         */

@@ -16,7 +16,7 @@ LIB_PATH = _HERE / "libwafer_hip.so"
 
 WM_F32, WM_BF16 = 0, 1
 WM_AUG_NONE, WM_AUG_DIENOISE, WM_AUG_DPW, WM_AUG_MEDIAN3 = 0, 1, 2, 3
-WM_IMG_NCHW_F32, WM_IMG_NHWC_BF16, WM_IMG_HW_U8 = 0, 1, 2
+WM_IMG_NCHW_F32, WM_IMG_NHWC_BF16, WM_IMG_HW_U8, WM_IMG_S2D_BF16 = 0, 1, 2, 3
 
 
 class WaferHipError(RuntimeError):

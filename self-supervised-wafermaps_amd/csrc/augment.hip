@@ -217,6 +217,24 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_kernel(
       o4[0] = make_uint4(w[0], w[1], w[2], w[3]);
       o4[1] = make_uint4(w[4], w[5], w[6], w[7]);
       o4[2] = make_uint4(w[8], w[9], w[10], w[11]);
+    } else if (fmt == WM_IMG_S2D_BF16) {
+      // 2x2 space-to-depth: image row oy -> s2d row oy/2, channels dh*6 + dw*3 + c of the pixel pair's s2d
+      // pixel; the three channels of a wafer image are equal.  Row dh = 0 writes channels 0..5 (12 bytes),
+      // dh = 1 channels 6..11 and the zero padding 12..15 (20 bytes): the pair covers the 32-byte pixel.
+      const int O2 = O >> 1, dh = oy & 1;
+      uint16_t* o = static_cast<uint16_t*>(out) + ((slot * O2 + (size_t)(oy >> 1)) * O2 + g * 4) * 16 + dh * 6;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint32_t a = f2bf(lut[px[2 * q]]), b = f2bf(lut[px[2 * q + 1]]);
+        uint32_t* o32 = reinterpret_cast<uint32_t*>(o + q * 16);
+        o32[0] = a | (a << 16);
+        o32[1] = a | (b << 16);
+        o32[2] = b | (b << 16);
+        if (dh) {
+          o32[3] = 0u;
+          o32[4] = 0u;
+        }
+      }
     } else {
       uint8_t* o = static_cast<uint8_t*>(out) + slot * O * O + (size_t)oy * O + g * 8;
       uint32_t lo = px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24);
@@ -241,7 +259,7 @@ extern "C" int wm_augment_views(const uint8_t* wafers, const int64_t* offsets,
   WM_REQUIRE(img_size <= AUG_MAX_SIDE && out_size <= AUG_MAX_SIDE && out_size % 8 == 0,
              WM_EUNSUPPORTED);
   WM_REQUIRE(out_format == WM_IMG_NCHW_F32 || out_format == WM_IMG_NHWC_BF16 ||
-                 out_format == WM_IMG_HW_U8,
+                 out_format == WM_IMG_HW_U8 || out_format == WM_IMG_S2D_BF16,
              WM_EUNSUPPORTED);
   WM_REQUIRE(std != 0.f || !normalize, WM_EINVAL);
   WM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, WM_EALIGN);

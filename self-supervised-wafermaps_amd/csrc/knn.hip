@@ -892,7 +892,11 @@ inline KnnPlan make_plan(int nq, int n, int rowbytes, int k) {
   int want = (p.qt == 4 ? 256 : 512) / p.qtiles;  // resident blocks per CU: 1 (128-query tiles) or 2
   if (want < 1) want = 1;
   if (want > 512) want = 512;
-  if (const char* e = getenv("WM_KNN_SLICES")) want = atoi(e);  // experiment knob
+  static const int forced = [] {  // experiment knob, read once
+    const char* e = getenv("WM_KNN_SLICES");
+    return e ? atoi(e) : 0;
+  }();
+  if (forced > 0) want = forced;
   p.nslices = total_chunks < want ? total_chunks : want;
   p.chunks_per_slice = wm_cdiv(total_chunks, p.nslices);
   p.nslices = wm_cdiv(total_chunks, p.chunks_per_slice);

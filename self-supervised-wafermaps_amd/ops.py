@@ -264,19 +264,25 @@ class _StemConv(torch.autograd.Function):
         _need_cuda(x, "stem_conv")
         n, c, h, w = x.shape
         k = weight.shape[0]
-        if c != 3 or tuple(weight.shape[1:]) != (3, 7, 7) or h % 2 or w % 2:
-            raise ValueError("stem_conv: expects [N,3,even,even] input and [K,3,7,7] weights")
+        s2d_input = c == 16 and x.dtype == torch.bfloat16  # already space-to-depth (augment_views fmt "s2d_bf16")
+        if (c != 3 and not s2d_input) or tuple(weight.shape[1:]) != (3, 7, 7) or (not s2d_input and (h % 2 or w % 2)):
+            raise ValueError("stem_conv: expects [N,3,even,even] (or space-to-depth [N,16,H/2,W/2] bf16) input and "
+                             "[K,3,7,7] weights")
         if x.requires_grad:
             raise NotImplementedError("stem_conv: no input gradient (images are data)")
         lib = _lib.load()
-        if x.dtype == torch.float32 and x.is_contiguous():
-            fmt = _lib.WM_IMG_NCHW_F32
+        if s2d_input:
+            h2, w2 = h, w
+            xs = _as_nhwc(x)  # memory [N][H/2][W/2][16]
         else:
-            x = _as_nhwc(x)
-            fmt = _lib.WM_IMG_NHWC_BF16
-        h2, w2 = h // 2, w // 2
-        xs = torch.empty((n, h2, w2, 16), dtype=torch.bfloat16, device=x.device)
-        check(lib.wm_image_to_s2d(x.data_ptr(), fmt, n, h, w, ptr(xs), stream_ptr()), "wm_image_to_s2d")
+            if x.dtype == torch.float32 and x.is_contiguous():
+                fmt = _lib.WM_IMG_NCHW_F32
+            else:
+                x = _as_nhwc(x)
+                fmt = _lib.WM_IMG_NHWC_BF16
+            h2, w2 = h // 2, w // 2
+            xs = torch.empty((n, h2, w2, 16), dtype=torch.bfloat16, device=x.device)
+            check(lib.wm_image_to_s2d(x.data_ptr(), fmt, n, h, w, ptr(xs), stream_ptr()), "wm_image_to_s2d")
         ws2d, _ = _WCACHE.get(weight, kind="stem")
         y = _empty_nhwc(n, k, h2, w2, x.device)
         if stats is not None and stats_fusable(n * h2 * w2, groups):

@@ -255,7 +255,8 @@ def validate_params(params: np.ndarray, store: WaferStore, img_size: int, n_slot
             raise ValueError("crop box outside the resized image")
 
 
-_FMT = {"nchw_f32": _lib.WM_IMG_NCHW_F32, "nhwc_bf16": _lib.WM_IMG_NHWC_BF16, "u8": _lib.WM_IMG_HW_U8}
+_FMT = {"nchw_f32": _lib.WM_IMG_NCHW_F32, "nhwc_bf16": _lib.WM_IMG_NHWC_BF16, "u8": _lib.WM_IMG_HW_U8,
+        "s2d_bf16": _lib.WM_IMG_S2D_BF16}
 
 
 def augment_views(store: WaferStore, params: np.ndarray, img_size: int = 224, out_size: int = 224,
@@ -266,7 +267,9 @@ def augment_views(store: WaferStore, params: np.ndarray, img_size: int = 224, ou
 
     fmt "nchw_f32": float32 [n,3,O,O] (the reference's batch tensor);
         "nhwc_bf16": bfloat16 [n,3,O,O] in channels_last memory format (feeds the conv kernels);
-        "u8": uint8 [n,O,O] (the grey image before ToTensor; parity checks)."""
+        "u8": uint8 [n,O,O] (the grey image before ToTensor; parity checks);
+        "s2d_bf16": bfloat16 [n,16,O/2,O/2] channels_last = the 2x2 space-to-depth image the ResNet stem
+        convolution runs on (ops.stem_conv takes it as is: no separate layout pass)."""
     if store.device is None or store.device.type != "cuda":
         raise _lib.WaferHipError("WaferStore must live on the GPU (store.to('cuda')); there is no CPU path")
     n = len(params)
@@ -282,6 +285,9 @@ def augment_views(store: WaferStore, params: np.ndarray, img_size: int = 224, ou
             out = torch.empty((n_slots, out_size, out_size, 3), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2)
         elif fmt == "u8":
             out = torch.empty((n_slots, out_size, out_size), dtype=torch.uint8, device=dev)
+        elif fmt == "s2d_bf16":
+            out = torch.empty((n_slots, out_size // 2, out_size // 2, 16), dtype=torch.bfloat16,
+                              device=dev).permute(0, 3, 1, 2)
         else:
             raise ValueError(f"unknown fmt {fmt}")
     if params_dev is not None:

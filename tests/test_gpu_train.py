@@ -397,3 +397,35 @@ def test_every_benchmark_model_trains_and_validates_through_the_trainer(name):
     key = "train_loss" if name == "SupervisedR18" else "train_loss_ssl"
     assert np.isfinite(float(model.logged[key]))
     assert 0.0 <= hist[-1]["knn_accuracy"] <= 1.0
+
+
+@pytest.mark.gpu
+def test_augmentation_writes_the_stem_layout_directly():
+    """fmt "s2d_bf16" of the augmentation kernel == wm_image_to_s2d of its "nhwc_bf16" output, bit for bit, and
+    a SimCLR step on it gives the same loss (the ResNet stem takes the space-to-depth tensor as is)."""
+    import numpy as np
+
+    from ssl_wafermap_amd import _lib, ops
+    from ssl_wafermap_amd._lib import check, ptr, stream_ptr
+    from ssl_wafermap_amd.data import WaferMapDataset
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.models import SimCLR
+    from ssl_wafermap_amd.transforms import BaseViewTransform
+
+    dev = torch.device("cuda:0")
+    wafers, labels = synthetic_wafers(32, seed=5)
+    ds = WaferMapDataset(wafers, labels, transform=BaseViewTransform(), device=dev)
+    idx = np.arange(8)
+    (a0, a1), _ = ds.get_batch(idx, np.random.default_rng(3), fmt="nhwc_bf16")
+    (s0, s1), _ = ds.get_batch(idx, np.random.default_rng(3), fmt="s2d_bf16")
+    assert s0.shape == (8, 16, 112, 112) and s0.dtype == torch.bfloat16
+    for a, s in ((a0, s0), (a1, s1)):
+        ref = torch.empty((8, 112, 112, 16), dtype=torch.bfloat16, device=dev)
+        check(_lib.load().wm_image_to_s2d(a.data_ptr(), _lib.WM_IMG_NHWC_BF16, 8, 224, 224, ptr(ref), stream_ptr()),
+              "wm_image_to_s2d")
+        assert torch.equal(s.permute(0, 2, 3, 1).contiguous(), ref)
+    torch.manual_seed(0)
+    model = SimCLR(None, 9, batch_size=8, log_rep_std=False).to(dev).train()
+    l_nhwc = float(model.training_step(((a0, a1), None), 0))
+    l_s2d = float(model.training_step(((s0, s1), None), 0))
+    assert l_nhwc == l_s2d
