@@ -17,7 +17,8 @@ Prints ONE JSON line (rank 0): metric imgs/sec = wafers (not views) per second, 
                  recorded INSIDE the timed region on the launch stream, on the LAST timed step only
                  (or every `--timer-every`-th): a timing event is a barrier packet on ROCm and
                  bracketing all ~60 conv launches of every step costs ~20 % throughput, so the
-                 bracketed step runs eagerly and the others replay the captured hipGraph.
+                 bracketed step runs eagerly (about twice a graph replay's time: with the default 100
+                 timed steps it costs ~1 % of `value`) and the others replay the captured hipGraph.
   cpu_baseline : the torch-CPU oracle (oracle/) running BASELINE configs[0] (bs 32, fp32) on the
                  host cores for a bounded number of steps (rank 0, N = 1 only).
 """
@@ -105,8 +106,8 @@ def cpu_baseline(seconds_budget: float = 25.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--batch", type=int, default=256, help="wafers per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timer", action="store_true")
