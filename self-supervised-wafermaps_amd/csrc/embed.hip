@@ -83,17 +83,18 @@ __device__ __forceinline__ void nx_load_rows(const float* __restrict__ src, int 
   }
 }
 
-// dots of this wave's 8 rows against column `lane` of the staged tile
+// dots of this wave's R rows against column `lane` of the staged tile
+template <int R>
 __device__ __forceinline__ void nx_dots(const float* rowt, const float* colt, int d, int cstride,
-                                        int wave, int lane, float (&acc)[8]) {
+                                        int wave, int lane, float (&acc)[R]) {
 #pragma unroll
-  for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+  for (int r = 0; r < R; ++r) acc[r] = 0.f;
   const float* cp = colt + (size_t)lane * cstride;
-  const float* rp = rowt + (size_t)(wave * 8) * d;
+  const float* rp = rowt + (size_t)(wave * R) * d;
   for (int kk = 0; kk < d; kk += 4) {
     const float4 c = *reinterpret_cast<const float4*>(cp + kk);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < R; ++r) {
       const float4 a = *reinterpret_cast<const float4*>(rp + (size_t)r * d + kk);
       acc[r] = fmaf(a.x, c.x, acc[r]);
       acc[r] = fmaf(a.y, c.y, acc[r]);
@@ -103,9 +104,10 @@ __device__ __forceinline__ void nx_dots(const float* rowt, const float* colt, in
   }
 }
 
-// WAVES waves per block, 8 local rows per wave
-template <int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void ntxent_fwd_kernel(const float* __restrict__ zn,
+// four waves per block, RPW local rows per wave: RPW = 2 gives 4x the blocks of RPW = 8 for small batches (the
+// 512-row problem of the headline configuration ran on 16 CUs)
+template <int RPW>
+__global__ __launch_bounds__(256) void ntxent_fwd_kernel(const float* __restrict__ zn,
                                                          const float* __restrict__ zall,
                                                          int b_local, int b_global,
                                                          int rank_offset, int d, float temp,
@@ -114,7 +116,7 @@ __global__ __launch_bounds__(64 * WAVES) void ntxent_fwd_kernel(const float* __r
   extern __shared__ __attribute__((aligned(16))) float nx_smem[];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int nlocal = 2 * b_local, nglobal = 2 * b_global;
-  constexpr int RT = 8 * WAVES, NTH = 64 * WAVES;
+  constexpr int RT = 4 * RPW, NTH = 256;
   const int row0 = blockIdx.x * RT;
   const int cstride = d + NX_PAD;
   float* rowt = nx_smem;                 // [NX_RT][d]
@@ -122,14 +124,14 @@ __global__ __launch_bounds__(64 * WAVES) void ntxent_fwd_kernel(const float* __r
 
   nx_load_rows(zn, row0, RT, nlocal, d, d, rowt, tid, NTH);
 
-  float m[8], l[8], pos[8];
-  int self_g[8], pos_g[8];
+  float m[RPW], l[RPW], pos[RPW];
+  int self_g[RPW], pos_g[RPW];
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
+  for (int r = 0; r < RPW; ++r) {
     m[r] = -INFINITY;
     l[r] = 0.f;
     pos[r] = 0.f;
-    const int lr = row0 + wave * 8 + r;
+    const int lr = row0 + wave * RPW + r;
     const NxIds ids = nx_ids(lr < nlocal ? lr : 0, b_local, b_global, rank_offset);
     self_g[r] = ids.self_g;
     pos_g[r] = ids.pos_g;
@@ -139,11 +141,11 @@ __global__ __launch_bounds__(64 * WAVES) void ntxent_fwd_kernel(const float* __r
     __syncthreads();  // previous tile fully consumed (and rowt visible on the first pass)
     nx_load_rows(zall, j0, NX_CT, nglobal, d, cstride, colt, tid, NTH);
     __syncthreads();
-    float acc[8];
-    nx_dots(rowt, colt, d, cstride, wave, lane, acc);
+    float acc[RPW];
+    nx_dots<RPW>(rowt, colt, d, cstride, wave, lane, acc);
     const int g = j0 + lane;
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
+    for (int r = 0; r < RPW; ++r) {
       const float s = acc[r] / temp;
       if (g == pos_g[r]) pos[r] = s;
       if (g < nglobal && g != self_g[r]) {
@@ -154,12 +156,12 @@ __global__ __launch_bounds__(64 * WAVES) void ntxent_fwd_kernel(const float* __r
     }
   }
 #pragma unroll
-  for (int r = 0; r < 8; ++r) {
+  for (int r = 0; r < RPW; ++r) {
     const float mm = wave_max(m[r]);
     const float part = (m[r] == -INFINITY) ? 0.f : l[r] * expf(m[r] - mm);
     const float ll = wave_sum(part);
     const float pp = wave_sum(pos[r]);
-    const int lr = row0 + wave * 8 + r;
+    const int lr = row0 + wave * RPW + r;
     if (lane == 0 && lr < nlocal) {
       const float lse = mm + logf(ll);
       lse_out[lr] = lse;
@@ -212,7 +214,7 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
     nx_load_rows(zall, j0, NX_CT, nglobal, d, cstride, colt, tid);
     __syncthreads();
     float acc[8];
-    nx_dots(rowt, colt, d, cstride, wave, lane, acc);
+    nx_dots<8>(rowt, colt, d, cstride, wave, lane, acc);
     const int g = j0 + lane;
     const float lse_j = g < nglobal ? lse_all[g] : 0.f;
 #pragma unroll
@@ -310,15 +312,24 @@ extern "C" int wm_ntxent_fwd(const float* zn, const float* zall, int b_local, in
   if (rc != WM_OK) return rc;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntxent_fwd_kernel<4>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntxent_fwd_kernel<8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&ntxent_fwd_kernel<2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 131072);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  // (one-wave blocks -- 4x as many -- were slower: 122 vs 73 us; every block streams all of zall through LDS)
-  const size_t lds = ((size_t)NX_RT * d + (size_t)NX_CT * (d + NX_PAD)) * sizeof(float);
-  ntxent_fwd_kernel<4><<<wm_cdiv(2 * b_local, NX_RT), 256, lds, static_cast<hipStream_t>(stream)>>>(
-      zn, zall, b_local, b_global, rank_offset, d, temperature, lse, loss_rows);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (2 * b_local <= 2048) {  // few rows: 8-row blocks (2 per wave) so that the grid covers more of the chip
+    const size_t lds = ((size_t)8 * d + (size_t)NX_CT * (d + NX_PAD)) * sizeof(float);
+    ntxent_fwd_kernel<2><<<wm_cdiv(2 * b_local, 8), 256, lds, st>>>(zn, zall, b_local, b_global, rank_offset, d,
+                                                                    temperature, lse, loss_rows);
+  } else {
+    const size_t lds = ((size_t)NX_RT * d + (size_t)NX_CT * (d + NX_PAD)) * sizeof(float);
+    ntxent_fwd_kernel<8><<<wm_cdiv(2 * b_local, NX_RT), 256, lds, st>>>(zn, zall, b_local, b_global, rank_offset, d,
+                                                                        temperature, lse, loss_rows);
+  }
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
