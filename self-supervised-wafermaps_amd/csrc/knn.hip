@@ -164,7 +164,7 @@ __device__ __attribute__((aligned(256))) uint8_t knn_zero_page[256];
 // behind a counted s_waitcnt vmcnt (cdna_hip_programming.md "Pipelining across barriers"); every
 // wave fetches its own 32 rows, so the loop needs no barrier.  LDS rows are 256 B; the DMA destination is lane-linear, so the XOR swizzle is
 // applied to the per-lane SOURCE chunk and again on the fragment reads.
-template <int DT, int QT, int K, int S, bool QREG>
+template <int DT, int QT, int K, int S>
 __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
     const uint8_t* __restrict__ query, const uint8_t* __restrict__ bank, int nq, int n,
     int rowbytes, int chunks_per_slice, int nslices, float* __restrict__ part_sim,
@@ -182,9 +182,8 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
   const int slice = blockIdx.x;
 
   uint8_t* ring = smem;                  // S x KNN_BUF
-  // register-resident query fragments: the tile is only staged through LDS once, inside the last
-  // ring stage (first written by the DMA of iteration 0, after the fragments were read)
-  uint8_t* qbuf = QREG ? smem + (S - 1) * KNN_BUF : smem + S * KNN_BUF;  // QB x rowbytes
+  uint8_t* qbuf = smem + S * KNN_BUF;    // QB x rowbytes: the query tile, read from LDS throughout
+  // (bf16 rows of exactly one slab take knn_stream_b128 below: query fragments in registers)
 
   // Block b owns chunks b, b + nslices, b + 2*nslices, ...: at any instant the resident blocks read
   // a contiguous window of the bank, which spreads over all HBM channels (contiguous per-block
@@ -266,22 +265,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
 #pragma unroll
   for (int t = 0; t < QT; ++t) gmax[t] = -INFINITY;
 
-  // With one wave per SIMD nothing hides an LDS round trip between dependent ds_read -> MFMA
-  // pairs, so when a row is a single 256-byte slab the query fragments live in registers for the
-  // whole kernel and the 8 bank fragments of an iteration are fetched up front.
-  uint4 qreg[QREG ? QT : 1][8];
-  if constexpr (!QREG) __syncthreads();  // query tile staged (read from LDS throughout)
-  if constexpr (QREG) {
-    __syncthreads();  // query tile staged
-#pragma unroll
-    for (int t = 0; t < QT; ++t)
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8)
-        qreg[t][s8] = *reinterpret_cast<const uint4*>(qbuf + (size_t)(t * 32 + r) * rowbytes +
-                                                      (((2 * s8 + h) ^ (r & 15)) << 4));
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __syncthreads();  // every wave has its fragments: the stage may now be overwritten
-  }
+  __syncthreads();  // query tile staged
 
   for (int it = 0; it < iters; ++it) {
     // stage `it` must have landed: in steady state S-2 younger stages may still be in flight
@@ -300,37 +284,15 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     if (it + S - 1 < iters && !(dbg & 2)) issue(it + S - 1);  // reuses the stage consumed in iteration it-1
     if (dbg & 1) continue;
-    const int slab = QREG ? 0 : it % nslab;
-    if (!QREG && slab == 0) {
+    const int slab = it % nslab;
+    if (slab == 0) {
 #pragma unroll
       for (int t = 0; t < QT; ++t)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
     }
     const uint8_t* abuf = ring + (it % S) * KNN_BUF + (wave * 32 + r) * KNN_SLAB;
-    if constexpr (QREG) {
-      uint4 a[8];
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) a[s8] = *reinterpret_cast<const uint4*>(abuf + (((2 * s8 + h) ^ (r & 15)) << 4));
-#pragma unroll
-      for (int s8 = 0; s8 < 8; ++s8) {
-#pragma unroll
-        for (int t = 0; t < QT; ++t) {
-          if constexpr (DT == WM_BF16) {
-            const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-            acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[s8]),
-                                                             __builtin_bit_cast(bf16x8_t, qreg[t][s8]),
-                                                             s8 == 0 ? zero : acc[t], 0, 0, 0);
-          } else {
-            const f32x4_t af = __builtin_bit_cast(f32x4_t, a[s8]);
-            const f32x4_t bf = __builtin_bit_cast(f32x4_t, qreg[t][s8]);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc[t], 0, 0, 0);
-          }
-        }
-      }
-    } else {
+    {
       const uint8_t* qrow = qbuf + (size_t)r * rowbytes + slab * KNN_SLAB;
 #pragma unroll
       for (int s = 0; s < 8; ++s) {
@@ -352,7 +314,7 @@ __global__ __launch_bounds__(KNN_THREADS) void knn_stream(
         }
       }
     }
-    if (QREG || slab == nslab - 1) {
+    if (slab == nslab - 1) {
       const int crel = it / nslab;  // chunk index inside this slice
       const int nb = (slice + crel * nslices) * KNN_ROWS + wave * 32;
       if (nb + 32 <= n) {  // wave-uniform: every row of this wave's sub-tile is a real bank row
@@ -912,19 +874,19 @@ inline int knn_debug_bits() {
   return bits;
 }
 
-template <int DT, int QT, int K, int S, bool QREG>
+template <int DT, int QT, int K, int S>
 int launch_stream(const KnnPlan& p, const void* query, const void* bank, int nq, int n, int rowbytes,
                   float* ps, int* pi, hipStream_t st) {
-  const size_t lds = QREG ? (size_t)S * KNN_BUF : (size_t)S * KNN_BUF + (size_t)QT * 32 * rowbytes;
+  const size_t lds = (size_t)S * KNN_BUF + (size_t)QT * 32 * rowbytes;
   static bool attr_set = false;  // idempotent; a race only repeats the call
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream<DT, QT, K, S, QREG>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&knn_stream<DT, QT, K, S>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, 163840);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
   dim3 grid(p.nslices, p.qtiles);
-  knn_stream<DT, QT, K, S, QREG><<<grid, KNN_THREADS, lds, st>>>(
+  knn_stream<DT, QT, K, S><<<grid, KNN_THREADS, lds, st>>>(
       static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), nq, n, rowbytes,
       p.chunks_per_slice | (knn_debug_bits() << 24), p.nslices, ps, pi);
   WM_LAUNCH_CHECK();
@@ -977,7 +939,7 @@ int launch_block(const KnnPlan& p, const void* query, const void* bank, int nq, 
       }
     }
   }
-  return launch_stream<DT, QT, K, 3, false>(p, query, bank, nq, n, rowbytes, ps, pi, st);
+  return launch_stream<DT, QT, K, 3>(p, query, bank, nq, n, rowbytes, ps, pi, st);
 }
 
 template <int DT, int K>
