@@ -119,6 +119,13 @@ size_t wm_knn_topk_general_workspace_bytes(int nq, int n, int d, int k);
 int wm_knn_topk_general(const float* query, const float* bank, const float* bias, int nq, int n, int d, int k,
                         int bank_index_base, float* out_sim, int32_t* out_idx, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* The next page: top-k among the rows strictly AFTER the cursor (after_sim[q], after_idx[q]) in the list order
+ * (score descending, index ascending; after_idx in the output index space, i.e. including bank_index_base).
+ * Calling it with the last entry of the previous page walks a top-K of any length in pages of <= 16
+ * (lightly's knn_predict default knn_k = 200; the reference itself uses 5).  NULL cursors = the first page. */
+int wm_knn_topk_general_after(const float* query, const float* bank, const float* bias, int nq, int n, int d, int k,
+                              int bank_index_base, const float* after_sim, const int32_t* after_idx, float* out_sim,
+                              int32_t* out_idx, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Merge `parts` candidate lists per query ([parts][nq][k], e.g. all-gathered shard results)
  * into the global top-k.  in_* and out_* may not alias. */

@@ -172,6 +172,8 @@ SIGNATURES = {
     "wm_knn_topk_general_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
     "wm_knn_topk_general": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p,
                                     c_void_p, c_size_t, c_void_p]),
+    "wm_knn_topk_general_after": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p,
+                                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "wm_colstats": (c_int, [c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "wm_standardize": (c_int, [c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wm_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),

@@ -22,7 +22,9 @@ constexpr int KG_K = 16;
 
 __global__ __launch_bounds__(KG_THREADS) void knn_general(const float* __restrict__ query, const float* __restrict__ bank,
                                                           const float* __restrict__ bias, int nq, int n, int d, int k,
-                                                          int rows_per_slice, int index_base, float* __restrict__ ps,
+                                                          int rows_per_slice, int index_base,
+                                                          const float* __restrict__ after_sim,
+                                                          const int* __restrict__ after_idx, float* __restrict__ ps,
                                                           int* __restrict__ pi) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int q0 = blockIdx.y * KG_Q;
@@ -42,6 +44,14 @@ __global__ __launch_bounds__(KG_THREADS) void knn_general(const float* __restric
   for (int j = 0; j < KG_K; ++j) {
     best[j] = -INFINITY;
     bidx[j] = 0x7fffffff;
+  }
+  // optional cursor: only rows strictly AFTER (after_sim[q], after_idx[q]) in the list order (score descending,
+  // index ascending) compete -- the next page of a top-k that is longer than KG_K
+  float cur_v = INFINITY;
+  int cur_i = -1;
+  if (after_sim != nullptr && lane < KG_Q && q0 + lane < nq) {
+    cur_v = after_sim[q0 + lane];
+    cur_i = after_idx[q0 + lane] - index_base;
   }
   const int r0 = blockIdx.x * rows_per_slice;
   int r1 = r0 + rows_per_slice;
@@ -69,7 +79,8 @@ __global__ __launch_bounds__(KG_THREADS) void knn_general(const float* __restric
       if (lane == q) mine = s;
     }
     // sorted insertion (descending; ties: lower index first) by the lane that owns the query
-    if (lane < KG_Q && (mine > best[KG_K - 1] || (mine == best[KG_K - 1] && r < bidx[KG_K - 1]))) {
+    const bool after_cursor = mine < cur_v || (mine == cur_v && r > cur_i);
+    if (lane < KG_Q && after_cursor && (mine > best[KG_K - 1] || (mine == best[KG_K - 1] && r < bidx[KG_K - 1]))) {
       float v = mine;
       int vi = r;
 #pragma unroll
@@ -106,6 +117,11 @@ inline int kg_slices(int n) {
 
 }  // namespace
 
+extern "C" int wm_knn_topk_general_after(const float* query, const float* bank, const float* bias, int nq, int n, int d,
+                                         int k, int bank_index_base, const float* after_sim, const int32_t* after_idx,
+                                         float* out_sim, int32_t* out_idx, void* workspace, size_t workspace_bytes,
+                                         void* stream);
+
 extern "C" size_t wm_knn_topk_general_workspace_bytes(int nq, int n, int d, int k) {
   if (nq <= 0 || n <= 0 || d <= 0 || k <= 0 || k > KG_K) return 0;
   return (size_t)kg_slices(n) * 4 * nq * k * 8 + 256;
@@ -114,7 +130,16 @@ extern "C" size_t wm_knn_topk_general_workspace_bytes(int nq, int n, int d, int 
 extern "C" int wm_knn_topk_general(const float* query, const float* bank, const float* bias, int nq, int n, int d,
                                    int k, int bank_index_base, float* out_sim, int32_t* out_idx, void* workspace,
                                    size_t workspace_bytes, void* stream) {
+  return wm_knn_topk_general_after(query, bank, bias, nq, n, d, k, bank_index_base, nullptr, nullptr, out_sim, out_idx,
+                                   workspace, workspace_bytes, stream);
+}
+
+extern "C" int wm_knn_topk_general_after(const float* query, const float* bank, const float* bias, int nq, int n, int d,
+                                         int k, int bank_index_base, const float* after_sim, const int32_t* after_idx,
+                                         float* out_sim, int32_t* out_idx, void* workspace, size_t workspace_bytes,
+                                         void* stream) {
   WM_REQUIRE(query && bank && out_sim && out_idx && workspace, WM_EINVAL);
+  WM_REQUIRE((after_sim == nullptr) == (after_idx == nullptr), WM_EINVAL);
   WM_REQUIRE(nq > 0 && n > 0 && d > 0 && k > 0 && k <= n, WM_EINVAL);
   WM_REQUIRE(k <= KG_K && d % 4 == 0 && d <= 64 * 4 * KG_MAXC, WM_EUNSUPPORTED);
   WM_REQUIRE((reinterpret_cast<uintptr_t>(query) & 15) == 0 && (reinterpret_cast<uintptr_t>(bank) & 15) == 0 &&
@@ -127,7 +152,8 @@ extern "C" int wm_knn_topk_general(const float* query, const float* bank, const 
   int* pi = reinterpret_cast<int*>(ps + cand);
   hipStream_t st = static_cast<hipStream_t>(stream);
   dim3 grid(slices, wm_cdiv(nq, KG_Q));
-  knn_general<<<grid, KG_THREADS, 0, st>>>(query, bank, bias, nq, n, d, k, wm_cdiv(n, slices), bank_index_base, ps, pi);
+  knn_general<<<grid, KG_THREADS, 0, st>>>(query, bank, bias, nq, n, d, k, wm_cdiv(n, slices), bank_index_base, after_sim,
+                                           after_idx, ps, pi);
   WM_LAUNCH_CHECK();
   return wm_knn_merge(ps, pi, slices * 4, nq, k, out_sim, out_idx, stream);
 }

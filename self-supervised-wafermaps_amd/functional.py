@@ -32,6 +32,8 @@ def knn_topk(query: torch.Tensor, bank: torch.Tensor, k: int, index_base: int = 
     nq, d = query.shape
     n = bank.shape[0]
     lib = _lib.load()
+    if k > 16:
+        return _knn_topk_paged(query, bank, k, index_base)
     rowbytes = d * query.element_size()
     streaming_ok = rowbytes % 256 == 0 and rowbytes <= (2048 if query.dtype == torch.float32 else 1024) and \
         (k <= 8 or rowbytes <= 1024)
@@ -60,6 +62,41 @@ def knn_topk(query: torch.Tensor, bank: torch.Tensor, k: int, index_base: int = 
     check(lib.wm_knn_topk(ptr(query), ptr(bank), nq, n, d, dtype_code(query), k, index_base, ptr(sim),
                           ptr(idx), ptr(workspace), workspace.numel() * workspace.element_size(),
                           stream_ptr()), "wm_knn_topk")
+    return sim, idx
+
+
+def _knn_topk_paged(query: torch.Tensor, bank: torch.Tensor, k: int, index_base: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """k > 16 (lightly's knn_predict default is 200; the reference uses 5): pages of 16 from the general float32
+    kernel, each page starting strictly after the last entry of the previous one in the list order (score
+    descending, index ascending) -- exact, ceil(k / 16) passes over the bank."""
+    nq, d = query.shape
+    n = bank.shape[0]
+    if k > n:
+        raise ValueError(f"knn_topk: k={k} exceeds the bank size {n}")
+    if d > 1024:
+        raise ValueError(f"knn_topk: k > 16 needs d <= 1024 (got {d})")
+    lib = _lib.load()
+    q32, b32 = query.float().contiguous(), bank.float().contiguous()
+    if d % 4:
+        q32 = torch.nn.functional.pad(q32, (0, 4 - d % 4)).contiguous()
+        b32 = torch.nn.functional.pad(b32, (0, 4 - d % 4)).contiguous()
+    need = lib.wm_knn_topk_general_workspace_bytes(nq, n, q32.shape[1], 16)
+    ws = torch.empty(need, dtype=torch.uint8, device=query.device)
+    sim = torch.empty((nq, k), dtype=torch.float32, device=query.device)
+    idx = torch.empty((nq, k), dtype=torch.int32, device=query.device)
+    cur_s = cur_i = None
+    done = 0
+    while done < k:
+        kk = min(16, k - done)
+        ps = torch.empty((nq, kk), dtype=torch.float32, device=query.device)
+        pi = torch.empty((nq, kk), dtype=torch.int32, device=query.device)
+        check(lib.wm_knn_topk_general_after(ptr(q32), ptr(b32), 0, nq, n, q32.shape[1], kk, index_base, ptr(cur_s),
+                                            ptr(cur_i), ptr(ps), ptr(pi), ptr(ws), need, stream_ptr()),
+              "wm_knn_topk_general_after")
+        sim[:, done:done + kk] = ps
+        idx[:, done:done + kk] = pi
+        cur_s, cur_i = ps[:, -1].contiguous(), pi[:, -1].contiguous()
+        done += kk
     return sim, idx
 
 

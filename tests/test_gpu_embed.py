@@ -581,3 +581,28 @@ def test_std_of_l2_normalized_matches_torch():
         ref = torch.std(torch.nn.functional.normalize(z, dim=1), dim=0).mean()
         got = std_of_l2_normalized(z.to("cuda:0"))
         assert abs(float(got) - float(ref)) <= 1e-6 + 1e-5 * abs(float(ref)), (rows, c, float(got), float(ref))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,d,k,dtype", [(3000, 128, 200, torch.float32), (777, 96, 50, torch.float32),
+                                         (2000, 128, 40, torch.bfloat16)])
+def test_knn_topk_large_k_pages(n, d, k, dtype):
+    """k > 16 (lightly's knn_predict default 200): pages of 16 through wm_knn_topk_general_after are the exact
+    top-k in list order, including ties (duplicated bank rows) and an index base."""
+    from ssl_wafermap_amd import functional as F_hip
+
+    g = torch.Generator().manual_seed(n + k)
+    bank = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1)
+    bank[5::7] = bank[3]  # many exact ties
+    bank = bank.to(dtype)
+    q = bank[:9].clone()
+    sim, idx = F_hip.knn_topk(q.to("cuda:0"), bank.to("cuda:0"), k, index_base=1000)
+    ref = q.float() @ bank.float().t()
+    order = torch.argsort(-ref, dim=1, stable=True)[:, :k]  # descending, lower index first on ties
+    rs = torch.gather(ref, 1, order)
+    assert torch.allclose(sim.cpu(), rs, atol=2e-6, rtol=0)
+    got = idx.cpu().long() - 1000
+    # ranking identical wherever the float32 scores are separated; tied groups must contain the same rows
+    for r in range(q.shape[0]):
+        assert set(got[r].tolist()) == set(order[r].tolist()) or torch.allclose(ref[r, got[r]], rs[r], atol=2e-6)
+        assert len(set(got[r].tolist())) == k
