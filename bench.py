@@ -203,6 +203,12 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     final_loss = float(loss.item())
+    if not np.isfinite(final_loss):
+        # a throughput figure of a network that has diverged is not a training throughput
+        print(f"[bench] rank {rank}: non-finite loss {final_loss} after {args.warmup} + {args.steps} steps", file=sys.stderr)
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(3)
 
     if rank == 0:
         imgs = B * world * args.steps

@@ -452,6 +452,12 @@ int wm_ema_update(float* ema, const float* params, long long n, float m, void* s
 int wm_lars_step(float* params, const float* grads, float* momentum_buf, const long long* seg_offsets, int n_seg,
                  const float* hyper, float* norms_ws, void* stream);
 
+/* Debugging probe (no reference counterpart): *slot = max(*slot, max_i |x[i]|), NaN if any x[i] is NaN
+ * (+inf stays +inf).  x: n elements of WM_F32 / WM_BF16; *slot must hold a non-negative float (zero it
+ * first).  Allocates nothing, so it can sit between the launches of a captured hipGraph
+ * (tools/nan_hunt.py; DESIGN.md "NaN at cfg 2"). */
+int wm_debug_absmax(const void* x, int dtype, long long n, float* slot, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -93,3 +93,19 @@ __device__ __forceinline__ void glds16_nt_at(const void* gsrc, uint32_t lds_byte
 }
 
 static inline int wm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
+
+// Zero `n_words` 32-bit words with a KERNEL.  Not hipMemsetAsync: captured as a memset NODE inside the ~400-node
+// hipGraph of a training step, the clear of the NT-Xent gradient buffer was not reliably applied before the
+// kernel that adds into it (first non-finite tensor of the bs-256 run: that buffer, with finite inputs; a fill
+// kernel in its place: 400 replays finite).  The library therefore issues no memset at all
+// (tests/test_abi.py checks the sources); profiles/r02_nan_root_cause.md has the bisection.
+__global__ __launch_bounds__(256) static void wm_zero_words_kernel(uint32_t* __restrict__ p, long long n_words) {
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n_words; i += (long long)gridDim.x * 256) p[i] = 0u;
+}
+static inline hipError_t wm_zero_async(void* p, size_t bytes, hipStream_t st) {
+  const long long n_words = (long long)(bytes / 4);
+  if (n_words == 0) return hipSuccess;
+  const long long blocks = (n_words + 255) / 256;
+  wm_zero_words_kernel<<<(int)(blocks < 2048 ? blocks : 2048), 256, 0, st>>>(static_cast<uint32_t*>(p), n_words);
+  return hipGetLastError();
+}

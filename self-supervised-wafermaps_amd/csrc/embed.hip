@@ -356,7 +356,9 @@ extern "C" int wm_ntxent_bwd(const float* zn, const float* zall, const float* ls
   nsplit = wm_cdiv(coltiles, tiles_per_split);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (nsplit > 1) {
-    hipError_t e = hipMemsetAsync(dzn, 0, (size_t)2 * b_local * d * sizeof(float), st);
+    // a zero-fill KERNEL, not hipMemsetAsync: as a memset NODE inside the captured training graph this clear
+    // was not reliably applied before the atomics below (profiles/r02_nan_root_cause.md)
+    hipError_t e = wm_zero_async(dzn, (size_t)2 * b_local * d * sizeof(float), st);
     if (e != hipSuccess) return (int)e;
   }
   ntxent_bwd_kernel<<<dim3(rowtiles, nsplit), 256, lds, st>>>(

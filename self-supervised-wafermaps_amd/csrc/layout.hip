@@ -259,7 +259,7 @@ extern "C" int wm_lars_step(float* params, const float* grads, float* momentum_b
                             int n_seg, const float* hyper, float* norms_ws, void* stream) {
   WM_REQUIRE(params && grads && momentum_buf && seg_offsets && hyper && norms_ws && n_seg > 0 && n_seg <= 65535, WM_EINVAL);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  hipError_t e = hipMemsetAsync(norms_ws, 0, (size_t)2 * n_seg * sizeof(float), st);
+  hipError_t e = wm_zero_async(norms_ws, (size_t)2 * n_seg * sizeof(float), st);
   if (e != hipSuccess) return (int)e;
   segment_sqnorms<<<dim3(32, n_seg), LT_THREADS, 0, st>>>(params, grads, seg_offsets, hyper, norms_ws);
   WM_LAUNCH_CHECK();

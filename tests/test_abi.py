@@ -92,3 +92,14 @@ def test_missing_library_is_an_error(tmp_path):
 
     with pytest.raises(_lib.WaferHipError):
         _lib.load(tmp_path / "nope.so")
+
+
+def test_library_sources_issue_no_memset():
+    """A hipMemsetAsync captured as a memset node inside the training step's hipGraph was the root cause of the
+    round-1 NaN (profiles/r02_nan_root_cause.md): buffers are cleared by kernels (csrc/common.h wm_zero_async)."""
+    import re
+
+    csrc = ROOT / "self-supervised-wafermaps_amd" / "csrc"
+    for f in sorted(csrc.glob("*.hip")) + sorted(csrc.glob("*.h")):
+        code = re.sub(r"//[^\n]*", "", f.read_text())
+        assert "hipMemset" not in code, f"{f.name} calls hipMemset*"
