@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 1
+#define WM_ABI_VERSION 2
 
 /* error codes */
 #define WM_OK 0
@@ -134,8 +134,10 @@ int wm_knn_merge(const float* in_sim, const int32_t* in_idx, int parts, int nq, 
 
 /* Weighted vote: w = exp(sim/t); score[c] = sum_j w_j [labels[idx_j]==c]; classes sorted by score
  * descending (ties: lower class id first) into pred_labels [nq][num_classes] int64 — the tensor
- * knn_predict returns; scores [nq][num_classes] float32 optional (may be NULL). */
-int wm_knn_vote(const float* sim, const int32_t* idx, const int64_t* bank_labels, int nq, int k,
+ * knn_predict returns; scores [nq][num_classes] float32 optional (may be NULL).  bank_labels holds
+ * n_labels entries; a neighbour index outside [0, n_labels) (the padding of a shard list shorter than k)
+ * casts no vote. */
+int wm_knn_vote(const float* sim, const int32_t* idx, const int64_t* bank_labels, long long n_labels, int nq, int k,
                 int num_classes, float temperature, int64_t* pred_labels, float* scores,
                 void* stream);
 

@@ -806,8 +806,8 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
 constexpr int VOTE_MAX_CLASSES = 64;
 
 __global__ void knn_vote_kernel(const float* __restrict__ sim, const int* __restrict__ idx,
-                                const long long* __restrict__ labels, int nq, int k, int nc,
-                                float t, long long* __restrict__ pred,
+                                const long long* __restrict__ labels, long long n_labels, int nq, int k,
+                                int nc, float t, long long* __restrict__ pred,
                                 float* __restrict__ scores_out) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q >= nq) return;
@@ -815,8 +815,10 @@ __global__ void knn_vote_kernel(const float* __restrict__ sim, const int* __rest
   for (int c = 0; c < nc; ++c) score[c] = 0.f;
   for (int j = 0; j < k; ++j) {
     // reference order of operations: (sim / t).exp(), then a sum over the k neighbours in order
+    const int nb = idx[(size_t)q * k + j];
+    if (nb < 0 || nb >= n_labels) continue;  // padding entry of a short shard list (sim = -inf): no vote
     const float w = expf(sim[(size_t)q * k + j] / t);
-    const int lab = (int)labels[idx[(size_t)q * k + j]];
+    const int lab = (int)labels[nb];
     for (int c = 0; c < nc; ++c) score[c] += (c == lab) ? w : 0.f;
   }
   if (scores_out)
@@ -1029,15 +1031,15 @@ extern "C" int wm_knn_merge(const float* in_sim, const int32_t* in_idx, int part
   return WM_OK;
 }
 
-extern "C" int wm_knn_vote(const float* sim, const int32_t* idx, const int64_t* bank_labels, int nq,
-                           int k, int num_classes, float temperature, int64_t* pred_labels,
+extern "C" int wm_knn_vote(const float* sim, const int32_t* idx, const int64_t* bank_labels, long long n_labels,
+                           int nq, int k, int num_classes, float temperature, int64_t* pred_labels,
                            float* scores, void* stream) {
   WM_REQUIRE(sim && idx && bank_labels && pred_labels, WM_EINVAL);
-  WM_REQUIRE(nq > 0 && k > 0 && num_classes > 0 && temperature > 0.f, WM_EINVAL);
+  WM_REQUIRE(n_labels > 0 && nq > 0 && k > 0 && num_classes > 0 && temperature > 0.f, WM_EINVAL);
   WM_REQUIRE(num_classes <= VOTE_MAX_CLASSES, WM_EUNSUPPORTED);
   hipStream_t st = static_cast<hipStream_t>(stream);
   knn_vote_kernel<<<wm_cdiv(nq, 64), 64, 0, st>>>(sim, idx,
-                                                  reinterpret_cast<const long long*>(bank_labels),
+                                                  reinterpret_cast<const long long*>(bank_labels), n_labels,
                                                   nq, k, num_classes, temperature,
                                                   reinterpret_cast<long long*>(pred_labels), scores);
   WM_LAUNCH_CHECK();

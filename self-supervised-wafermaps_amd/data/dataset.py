@@ -71,18 +71,35 @@ class WaferLoader:
         n = len(self.dataset)
         return n // gb if self.drop_last else (n + gb - 1) // gb
 
+    def iter_indices(self):
+        """(sample indices of this rank's slice, the batch's decision generator) per batch: what a captured
+        training step needs (graph.GraphedTrainStep draws the decisions and produces the images itself).
+        Same order, same slices and same generators as __iter__."""
+        for mine, rng in self._batches():
+            yield mine, rng
+
     def __iter__(self):
-        n = len(self.dataset)
-        gb = self.batch_size * self.world_size
-        order = np.random.default_rng([self.seed, self.epoch]).permutation(n) if self.shuffle else np.arange(n)
-        for b in range(len(self)):
-            glob = order[b * gb:(b + 1) * gb]
-            mine = glob[self.rank * self.batch_size:(self.rank + 1) * self.batch_size]
-            if len(mine) == 0:
-                continue
-            rng = np.random.default_rng([self.seed, self.epoch, b, self.rank])
+        for mine, rng in self._batches():
             views, y = self.dataset.get_batch(mine, rng, fmt=self.fmt)
             if self.unwrap_single and len(views) == 1:
                 yield views[0], y
             else:
                 yield views, y
+
+    def _batches(self):
+        n = len(self.dataset)
+        gb = self.batch_size * self.world_size
+        order = np.random.default_rng([self.seed, self.epoch]).permutation(n) if self.shuffle else np.arange(n)
+        for b in range(len(self)):
+            glob = order[b * gb:(b + 1) * gb]
+            if self.world_size > 1 and len(glob) < gb:
+                # short final global batch (drop_last=False): every rank must still take part in the step and its
+                # collectives, with equally many samples -- pad by wrapping around to the start of the epoch's
+                # order (what torch's DistributedSampler does) and split evenly
+                per = -(-len(glob) // self.world_size)
+                glob = np.concatenate([glob, order[: per * self.world_size - len(glob)]])
+                mine = glob[self.rank * per:(self.rank + 1) * per]
+            else:
+                mine = glob[self.rank * self.batch_size:(self.rank + 1) * self.batch_size]
+            rng = np.random.default_rng([self.seed, self.epoch, b, self.rank])
+            yield mine, rng

@@ -57,6 +57,23 @@ class WaferStore:
         h, w, o = int(self.heights_np[i]), int(self.widths_np[i]), int(self.offsets_np[i])
         return self.bytes_np[o : o + h * w].reshape(h, w)
 
+    def subset(self, indices, device: Optional[torch.device] = None) -> "WaferStore":
+        """A new store holding wafers `indices` in that order (train / validation splits of one file)."""
+        idx = np.asarray(indices, dtype=np.int64)
+        if idx.ndim != 1 or len(idx) == 0 or idx.min() < 0 or idx.max() >= self.n:
+            raise IndexError("WaferStore.subset: indices outside the store")
+        out = WaferStore.__new__(WaferStore)
+        out.heights_np, out.widths_np = self.heights_np[idx].copy(), self.widths_np[idx].copy()
+        sizes = out.heights_np.astype(np.int64) * out.widths_np.astype(np.int64)
+        out.offsets_np = np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64)
+        out.bytes_np = np.concatenate([self.bytes_np[o:o + s] for o, s in zip(self.offsets_np[idx], sizes)])
+        out.max_elems, out.n = int(sizes.max()), len(idx)
+        out.device = None
+        out.bytes = out.offsets = out.heights = out.widths = None
+        if device is not None:
+            out.to(device)
+        return out
+
     def nbytes(self) -> int:
         return int(self.bytes_np.nbytes)
 

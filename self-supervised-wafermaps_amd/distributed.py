@@ -58,14 +58,49 @@ class GradSync:
     def start(self) -> None:
         if world_size() == 1:
             return
-        for arena in self.optimizer.grad_arenas:
-            for o in range(0, arena.numel(), self.bucket_elems):
-                self.handles.append(dist.all_reduce(arena[o:o + self.bucket_elems], op=dist.ReduceOp.SUM, async_op=True))
+        for ai, arena in enumerate(self.optimizer.grad_arenas):
+            self.start_range(0, arena.numel(), ai)
+
+    def start_range(self, lo: int, hi: int, arena_index: int = 0) -> None:
+        """All-reduce elements [lo, hi) of one gradient arena, asynchronously: the collective runs on the
+        process group's own stream once the work enqueued so far on the current stream (the backward stage that
+        produced this range) has finished, and overlaps whatever the caller enqueues next."""
+        if world_size() == 1 or hi <= lo:
+            return
+        arena = self.optimizer.grad_arenas[arena_index]
+        for o in range(lo, hi, self.bucket_elems):
+            self.handles.append(dist.all_reduce(arena[o:min(o + self.bucket_elems, hi)], op=dist.ReduceOp.SUM,
+                                                async_op=True))
 
     def wait(self) -> None:
         for h in self.handles:
             h.wait()
         self.handles.clear()
+
+
+def broadcast_state(module: torch.nn.Module, optimizer=None, src: int = 0) -> None:
+    """Align the replicas before the first step (what DistributedDataParallel's constructor does): rank
+    `src`'s parameters -- the optimiser's flat arenas in one broadcast each, then whatever lives outside them
+    (frozen EMA teachers, momentum encoders) -- and every buffer (BatchNorm statistics, the MoCo bank, DINO
+    centres).  Without it correctness would rest on every rank seeding identically before construction."""
+    if world_size() == 1:
+        return
+    in_arena = set()
+    for arena in getattr(optimizer, "_arenas", []) if optimizer is not None else []:
+        dist.broadcast(arena.params, src=src)
+        lo, hi = arena.params.data_ptr(), arena.params.data_ptr() + arena.params.numel() * 4
+        in_arena.update(id(p) for p in module.parameters() if lo <= p.data_ptr() < hi)
+    with torch.no_grad():
+        for p in module.parameters():
+            if id(p) not in in_arena:
+                dist.broadcast(p.data, src=src)
+        for b in module.buffers():
+            if b.numel():
+                dist.broadcast(b, src=src)
+    if optimizer is not None:
+        from . import ops
+
+        ops.bump_weight_epoch()  # the bf16 kernel layouts of the weights are stale now
 
 
 def sync_bn_buffers(module: torch.nn.Module) -> None:

@@ -123,7 +123,7 @@ def knn_vote(sim: torch.Tensor, idx: torch.Tensor, bank_labels: torch.Tensor, nu
     nq, k = sim.shape
     pred = torch.empty((nq, num_classes), dtype=torch.int64, device=sim.device)
     scores = torch.empty((nq, num_classes), dtype=torch.float32, device=sim.device) if return_scores else None
-    check(_lib.load().wm_knn_vote(ptr(sim), ptr(idx), ptr(bank_labels), nq, k, num_classes, float(knn_t),
+    check(_lib.load().wm_knn_vote(ptr(sim), ptr(idx), ptr(bank_labels), bank_labels.numel(), nq, k, num_classes, float(knn_t),
                                   ptr(pred), ptr(scores), stream_ptr()), "wm_knn_vote")
     return (pred, scores) if return_scores else pred
 

@@ -9,17 +9,32 @@ once, with every input at a static address (the wafer store, a static device buf
 WmViewParams refreshed by an async copy before each replay, the parameter/gradient arenas), and
 replays it per step; the gradient all-reduce (RCCL) and the fused SGD kernel stay eager after the
 replay, so the captured graph contains no collective.
+
+Data parallel (`stages=True`, world > 1): the backward is cut at the boundaries the model marks with
+`ops.cut_point` (ResNet-18: before layer4 and before layer3) and each stage is its own graph in ONE memory pool:
+
+    G0 = zero_grad, augmentation, forward, backward of head + layer4   -> all-reduce arena[layer4:]   (35 MB, async)
+    G1 = backward of layer3                                            -> all-reduce arena[layer3:layer4]  (8 MB)
+    G2 = backward of layer2, layer1, stem                              -> all-reduce arena[:layer3]   (3 MB)
+    wait, fused SGD
+
+Parameters sit in the flat gradient arena in `model.parameters()` order (stem, layer1..4, head), so the gradients a
+stage completes are one contiguous tail range; its all-reduce runs on RCCL's stream under the remaining stages
+(three quarters of the bytes are ready after the first ~15 % of the backward), leaving only the last 3 MB exposed.
 """
 from __future__ import annotations
 
 import numpy as np
 import torch
 
-from .transforms.augmentations import PARAM_DTYPE
+from . import ops
+
+from .transforms.augmentations import PARAM_DTYPE, validate_params
 
 
 class GraphedTrainStep:
-    def __init__(self, model, optimizer, dataset, batch_size: int, warmup: int = 3, fmt: str = "nhwc_bf16"):
+    def __init__(self, model, optimizer, dataset, batch_size: int, warmup: int = 3, fmt: str = "nhwc_bf16",
+                 stages=None):
         self.model, self.opt, self.ds, self.B, self.fmt = model, optimizer, dataset, batch_size, fmt
         tr = dataset.transform
         self.tr = tr
@@ -33,12 +48,19 @@ class GraphedTrainStep:
                        for _ in range(self.RING)]
         self.events = [None] * self.RING
         self.turn = 0
+        self.staged = bool(stages)
+        self.graphs = []          # one graph, or one per backward stage
+        self.bounds = []          # staged: arena element offsets [b_k, ..., b_1]; stage s completes arena[bounds[s]:prev)
         self.graph = None
         self.loss = None
         self._last_params = None
         self._warmup = warmup
 
     def _upload(self, params_per_group):
+        # the replayed kernel indexes the store and the output with these values: bounds-check every upload
+        # on the host (a faulting kernel can reset the GPU), not only the arrays seen at capture time
+        for (i, j), p in zip(self.tr.groups(), params_per_group):
+            validate_params(p, self.ds.store, self.tr.transforms[i].img_size, (j - i) * self.B)
         slot = self.turn % self.RING
         self.turn += 1
         if self.events[slot] is not None:
@@ -51,15 +73,58 @@ class GraphedTrainStep:
         self.events[slot] = ev
         self._last_params = params_per_group
 
-    def _body(self):
+    # ---- the step as a list of stage closures: stage 0 = zero_grad .. backward down to the last cut
+    def _forward(self):
         self.opt.zero_grad()
         views = self.tr.launch(self.ds.store, self._last_params, self.B, self.fmt, params_dev=self.static)
-        loss = self.model.training_step((views, None), 0)
+        if not self.staged:
+            return self.model.training_step((views, None), 0), []
+        with ops.record_cuts() as cuts:
+            loss = self.model.training_step((views, None), 0)
+        return loss, cuts
+
+    def _body(self):
+        """The whole step eagerly (warm-up; also the unstaged graph's body)."""
+        loss, cuts = self._forward()
         loss.backward()
+        for _, x, leaf in reversed(cuts):
+            x.backward(leaf.grad)
         return loss
 
+    def _stage_bounds(self, cuts):
+        """Arena offset of the first parameter of the module that follows each cut (None: not a single flat arena,
+        or the parameter order does not make the stages contiguous tail ranges -> run unstaged)."""
+        arenas = getattr(self.opt, "_arenas", None)
+        if not cuts or arenas is None or len(arenas) != 1:
+            return None
+        arena = arenas[0]
+        ps = [p for g in self.opt.param_groups for p in g["params"] if p.requires_grad]
+        off = {id(p): o for p, o in zip(ps, arena.offsets)}
+        bounds = []
+        for name, _, _ in cuts:
+            first = [off[id(p)] for n, p in self.model.named_parameters()
+                     if p.requires_grad and id(p) in off and (n.startswith(name + ".") or ("." + name + ".") in n)]
+            if not first:
+                return None
+            bounds.append(min(first))
+        return bounds if bounds == sorted(bounds) else None
+
+    def _check_stage_ranges(self, cuts, bounds):
+        """One eager pass: after stage s, every gradient BELOW that stage's boundary must still be exactly zero
+        (otherwise a later stage would add into a range whose all-reduce is already in flight)."""
+        g = self.opt.grad_arenas[0]
+        loss, cuts = self._forward()
+        loss.backward()
+        lows = list(reversed(bounds))
+        ok = float(g[: lows[0]].abs().max()) == 0.0
+        for k, (_, x, leaf) in enumerate(reversed(cuts)):
+            x.backward(leaf.grad)
+            if k + 1 < len(lows):
+                ok = ok and float(g[: lows[k + 1]].abs().max()) == 0.0
+        return ok
+
     def capture(self, sample_idx: np.ndarray, rng: np.random.Generator, sync=None):
-        """Warm up eagerly on a side stream, then record the graph (torch.cuda.graph).  `sync` (a
+        """Warm up eagerly on a side stream, then record the graph(s) (torch.cuda.graph).  `sync` (a
         distributed.GradSync) keeps the warm-up steps data-parallel: without the gradient exchange the
         replicas' weights would drift apart before the first captured step."""
         params = self.tr.sample(self.ds.store, np.asarray(sample_idx), rng)
@@ -67,6 +132,14 @@ class GraphedTrainStep:
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             self._upload(params)
+            if self.staged:
+                _, cuts = self._forward()
+                bounds = self._stage_bounds(cuts)
+                if bounds is None or not self._check_stage_ranges(cuts, bounds):
+                    self.staged = False
+                else:
+                    self.bounds = list(reversed(bounds))   # in backward order: [before layer4, before layer3]
+                del cuts
             for _ in range(self._warmup):
                 self._body()
                 if sync is not None:
@@ -75,20 +148,44 @@ class GraphedTrainStep:
                 self.opt.step()
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
-        g = torch.cuda.CUDAGraph()
         # thread_local: other threads of the process (the RCCL watchdog of torch.distributed polls its
         # events while we record) must not invalidate the capture
-        with torch.cuda.graph(g, capture_error_mode="thread_local"):
-            self.loss = self._body()
-        self.graph = g
+        g0 = torch.cuda.CUDAGraph()
+        if not self.staged:
+            with torch.cuda.graph(g0, capture_error_mode="thread_local"):
+                self.loss = self._body()
+            self.graphs = [g0]
+        else:
+            with torch.cuda.graph(g0, capture_error_mode="thread_local"):
+                self.loss, cuts = self._forward()
+                self.loss.backward()
+            self.graphs = [g0]
+            self._cuts = cuts   # keeps the stage-boundary activations and their gradients alive in the pool
+            for _, x, leaf in reversed(cuts):
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk, pool=g0.pool(), capture_error_mode="thread_local"):
+                    x.backward(leaf.grad)
+                self.graphs.append(gk)
+        self.graph = g0
         return self
 
     def step(self, sample_idx: np.ndarray, rng: np.random.Generator, sync=None):
         """One training step: fresh decisions -> static buffers -> replay -> (all-reduce) -> SGD."""
         self._upload(self.tr.sample(self.ds.store, np.asarray(sample_idx), rng))
-        self.graph.replay()
-        if sync is not None:
-            sync.start()
-            sync.wait()
+        if not self.staged:
+            self.graph.replay()
+            if sync is not None:
+                sync.start()
+                sync.wait()
+        else:
+            hi = self.opt.grad_arenas[0].numel()
+            for k, g in enumerate(self.graphs):
+                g.replay()
+                lo = self.bounds[k] if k < len(self.bounds) else 0
+                if sync is not None:
+                    sync.start_range(lo, hi)   # this stage's gradients: reduced under the next stage's replay
+                hi = lo
+            if sync is not None:
+                sync.wait()
         self.opt.step()
         return self.loss

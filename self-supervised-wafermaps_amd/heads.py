@@ -173,7 +173,10 @@ class DINOProjectionHead(ProjectionHead):
         if current_epoch >= self.freeze_last_layer:
             return
         for p in self.last_layer.parameters():
-            p.grad = None
+            if p.grad is not None:
+                # in place: with the fused optimisers p.grad is a view of the flat gradient arena, and dropping
+                # the view would detach the parameter from the arena-based step and the all-reduce for good
+                p.grad.zero_()
 
     def forward(self, x):
         x = super().forward(x)

@@ -83,8 +83,10 @@ class ResNet18(nn.Module):
             x = self.bn1.forward_relu_maxpool(self.conv1(x))
         x = self.layer1(x)
         x = self.layer2(x)
-        x = self.layer3(x)
-        return self.layer4(x)
+        # stage boundaries of the backward pass (identity unless graph.GraphedTrainStep records them): layer4 + head
+        # hold 3/4 of the gradient bytes and finish first, so their all-reduce hides under layers 3..1
+        x = self.layer3(ops.cut_point(x, "layer3"))
+        return self.layer4(ops.cut_point(x, "layer4"))
 
     def forward(self, x):
         return ops.global_avg_pool(self.forward_features(x))

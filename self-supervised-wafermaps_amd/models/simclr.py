@@ -12,6 +12,10 @@ from .resnet import create_model
 
 
 class SimCLR(KNNBenchmarkModule):
+    graph_safe = True        # training_step has no host-side scalar that changes from step to step
+    stem_takes_s2d = True    # the ResNet stem consumes the augmentation kernel's space-to-depth layout
+    backward_stages = True   # the backbone marks stage boundaries (ops.cut_point) for overlapped gradient exchange
+
     def __init__(self, dataloader_kNN=None, num_classes=9, batch_size: int = 64, max_epochs: int = 150,
                  gather_distributed: bool = False, log_rep_std: bool = True, **kwargs):
         super().__init__(dataloader_kNN, num_classes, **kwargs)

@@ -77,6 +77,34 @@ def current_bn_groups() -> int:
     return _BN_GROUPS
 
 
+_CUTS = None  # a list while graph.GraphedTrainStep records the stage boundaries of a step
+
+
+@contextlib.contextmanager
+def record_cuts():
+    """Record the stage boundaries (`cut_point` calls) of one forward pass: [(name of the module that follows,
+    activation, detached leaf that the rest of the forward consumed)]."""
+    global _CUTS
+    old, _CUTS = _CUTS, []
+    try:
+        yield _CUTS
+    finally:
+        _CUTS = old
+
+
+def cut_point(x: torch.Tensor, next_module: str) -> torch.Tensor:
+    """Stage boundary of the backward pass.  Normally the identity.  While cuts are recorded the forward continues
+    from a detached leaf, so `loss.backward()` stops there (with the leaf's .grad = the activation gradient) and
+    `x.backward(leaf.grad)` runs the next stage: the backward of a step becomes a few separately captured
+    hipGraphs, and the gradient buckets a finished stage has completed are all-reduced on RCCL's stream while
+    the next stage computes (distributed.GradSync.start_range)."""
+    if _CUTS is None or not (torch.is_grad_enabled() and x.requires_grad):
+        return x
+    leaf = x.detach().requires_grad_(True)
+    _CUTS.append((next_module, x, leaf))
+    return leaf
+
+
 def _need_cuda(t: torch.Tensor, what: str) -> None:
     if not t.is_cuda:
         raise _lib.WaferHipError(f"{what}: the HIP path needs a device tensor (no CPU fallback)")

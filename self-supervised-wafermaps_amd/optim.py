@@ -44,7 +44,68 @@ class _Arena:
         self.offsets = offs
 
 
-class SGD(torch.optim.Optimizer):
+class _ArenaStateMixin:
+    """state_dict / load_state_dict in torch.optim's own format (state[i]["momentum_buffer"] for SGD / LARS,
+    state[i]["step" | "exp_avg" | "exp_avg_sq"] for Adam(W)), so that a run resumes with its momentum, moments
+    and bias-correction counters and a torch.optim checkpoint of the same parameter list loads here.  The
+    tensors live in the flat arenas; torch's `self.state` stays empty."""
+
+    _STATE_KEYS = ("momentum_buffer",)   # arena attribute order: momentum[, second]
+
+    def _param_slices(self):
+        """(packed torch index, arena, offset, parameter) for every parameter that owns an arena slot."""
+        idx = 0
+        for group, arena in zip(self.param_groups, self._arenas):
+            offs = iter(arena.offsets)
+            for p in group["params"]:
+                if p.requires_grad:
+                    yield idx, arena, next(offs), p
+                idx += 1
+
+    def state_dict(self):
+        sd = super().state_dict()
+        state = {}
+        steps = getattr(self, "_steps", None)
+        garena = {id(a): gi for gi, a in enumerate(self._arenas)}
+        for idx, arena, off, p in self._param_slices():
+            n = p.numel()
+            ent = {}
+            bufs = (arena.momentum, arena.second)
+            for key, buf in zip(self._STATE_KEYS, bufs):
+                ent[key] = buf[off:off + n].view(p.shape).clone()
+            if steps is not None:
+                ent["step"] = torch.tensor(float(steps[garena[id(arena)]]))
+            state[idx] = ent
+        sd["state"] = state
+        return sd
+
+    def load_state_dict(self, state_dict):
+        super().load_state_dict({"state": {}, "param_groups": state_dict["param_groups"]})
+        state = state_dict.get("state", {})
+        garena = {id(a): gi for gi, a in enumerate(self._arenas)}
+        seen_step = {}
+        with torch.no_grad():
+            for idx, arena, off, p in self._param_slices():
+                ent = state.get(idx, state.get(str(idx)))
+                if ent is None:
+                    continue
+                n = p.numel()
+                for key, buf in zip(self._STATE_KEYS, (arena.momentum, arena.second)):
+                    v = ent.get(key)
+                    if v is not None:
+                        if v.numel() != n:
+                            raise ValueError(f"optimizer state {key} of parameter {idx}: {tuple(v.shape)} vs {tuple(p.shape)}")
+                        buf[off:off + n].copy_(v.reshape(-1).to(buf.device, torch.float32))
+                if "step" in ent:
+                    seen_step.setdefault(garena[id(arena)], int(float(ent["step"])))
+        if hasattr(self, "_steps"):
+            for gi, t in seen_step.items():
+                self._steps[gi] = t
+        if hasattr(self, "_hyper_host"):
+            self._hyper_host = [None] * len(self._hyper_host)  # re-upload lr / momentum / decay at the next step
+
+
+class SGD(_ArenaStateMixin, torch.optim.Optimizer):
     def __init__(self, params, lr: float, momentum: float = 0.0, weight_decay: float = 0.0, grad_scale: float = 1.0):
         if lr < 0 or momentum < 0 or weight_decay < 0:
             raise ValueError("invalid SGD hyper-parameter")
@@ -83,10 +144,12 @@ class SGD(torch.optim.Optimizer):
         return loss
 
 
-class AdamW(torch.optim.Optimizer):
+class AdamW(_ArenaStateMixin, torch.optim.Optimizer):
     """torch.optim.AdamW's update (decoupled weight decay, bias-corrected moments, no amsgrad — what
     the reference's DINOViT and MAE use, scripts/WM811k_benchmark.py:591-598, :956-963) in one launch
     per parameter group over flat float32 arenas."""
+
+    _STATE_KEYS = ("exp_avg", "exp_avg_sq")
 
     def __init__(self, params, lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8, weight_decay: float = 1e-2,
                  grad_scale: float = 1.0):
@@ -129,7 +192,7 @@ class AdamW(torch.optim.Optimizer):
         return loss
 
 
-class LARS(torch.optim.Optimizer):
+class LARS(_ArenaStateMixin, torch.optim.Optimizer):
     """timm.optim.lars.Lars (momentum SGD with a per-parameter trust ratio; the reference's BarlowTwins and
     VICReg optimiser, scripts/WM811k_benchmark.py:383-392): two launches per parameter group over the flat
     arena (per-parameter squared norms, then the update)."""

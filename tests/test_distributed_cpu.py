@@ -163,3 +163,99 @@ def test_loader_rank_slices_partition_the_global_batch():
     nxt = WaferLoader(ds, 8, shuffle=True, drop_last=True, seed=3)
     nxt.set_epoch(1)
     assert not torch.equal(torch.cat([y for _, y in nxt]), seen)
+
+
+def test_loader_short_final_batch_keeps_every_rank_in_step():
+    """drop_last=False with a final global batch shorter than one rank's share (n % (bs * world) < bs): every
+    rank still gets a batch of the same size (wrap-around padding, as torch's DistributedSampler), so no rank
+    skips a step and its collectives."""
+    from ssl_wafermap_amd.data.dataset import WaferLoader
+
+    class FakeDataset:
+        def __len__(self):
+            return 35  # 35 % (8 * 2) = 3 < 8
+
+        def get_batch(self, indices, rng, fmt="nhwc_bf16"):
+            return [torch.as_tensor(indices)], torch.as_tensor(indices)
+
+    parts = [[y for _, y in WaferLoader(FakeDataset(), 8, shuffle=False, drop_last=False, rank=r, world_size=2)]
+             for r in range(2)]
+    assert len(parts[0]) == len(parts[1]) == 3
+    assert [len(y) for y in parts[0]] == [len(y) for y in parts[1]] == [8, 8, 2]
+    seen = torch.cat(parts[0] + parts[1])
+    assert set(seen.tolist()) == set(range(35))          # nothing lost; one sample repeated as padding
+    assert len(seen) == 36
+
+
+def _broadcast_state(rank, world):
+    from ssl_wafermap_amd import distributed as wdist
+
+    torch.manual_seed(rank)  # replicas constructed from DIFFERENT seeds
+    model = torch.nn.Sequential(torch.nn.Linear(8, 8), torch.nn.BatchNorm1d(8), torch.nn.Linear(8, 4))
+    model[1].running_mean.fill_(float(rank + 1))
+    teacher = torch.nn.Linear(8, 8)
+    for p in teacher.parameters():
+        p.requires_grad = False
+    model.add_module("teacher", teacher)
+
+    class Arena:
+        pass
+
+    class FakeOpt:  # the flat-arena layout of optim._Arena on CPU tensors
+        def __init__(self, params):
+            a = Arena()
+            n = sum(p.numel() for p in params)
+            a.params = torch.zeros(n)
+            o = 0
+            for p in params:
+                a.params[o:o + p.numel()].copy_(p.detach().reshape(-1))
+                p.data = a.params[o:o + p.numel()].view(p.shape)
+                o += p.numel()
+            self._arenas = [a]
+
+    opt = FakeOpt([p for p in model.parameters() if p.requires_grad])
+    wdist.broadcast_state(model, opt)
+    flat = torch.cat([p.detach().reshape(-1) for p in model.parameters()] + [b.reshape(-1).float() for b in model.buffers()])
+    both = [torch.empty_like(flat) for _ in range(world)]
+    dist.all_gather(both, flat)
+    assert torch.equal(both[0], both[1])
+    assert float(model[1].running_mean[0]) == 1.0 and model[0].weight.data_ptr() == opt._arenas[0].params.data_ptr()
+
+
+def test_broadcast_state_aligns_replicas_world2():
+    _spawn(_broadcast_state, 2)
+
+
+def _sharded_knn(rank, world):
+    import ssl_wafermap_amd.functional as F_hip
+    from ssl_wafermap_amd import distributed as wdist
+
+    def ref_topk(query, bank, k, index_base=0):
+        sim = query @ bank.t()
+        s, i = sim.topk(k, dim=1)
+        return s, (i + index_base).to(torch.int32)
+
+    def ref_merge(sims, idxs):
+        parts, nq, k = sims.shape
+        s = sims.permute(1, 0, 2).reshape(nq, parts * k)
+        i = idxs.permute(1, 0, 2).reshape(nq, parts * k)
+        top, pos = s.topk(k, dim=1)
+        return top, torch.gather(i, 1, pos)
+
+    F_hip.knn_topk, F_hip.knn_merge = ref_topk, ref_merge  # contract-equivalent stand-ins (no GPU here)
+    g = torch.Generator().manual_seed(0)
+    bank = torch.nn.functional.normalize(torch.randn(101, 16, generator=g), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(7, 16, generator=g), dim=1)
+    cut = [0, 60, 101]                                     # unequal shards
+    sim, idx = wdist.sharded_knn_topk(q, bank[cut[rank]:cut[rank + 1]], 5, cut[rank])
+    want_s, want_i = ref_topk(q, bank, 5)
+    torch.testing.assert_close(sim, want_s)
+    assert torch.equal(idx, want_i)
+    # a shard smaller than k: padded lists (-inf, out-of-range index) must lose the merge
+    cut = [0, 3, 101]
+    sim, idx = wdist.sharded_knn_topk(q, bank[cut[rank]:cut[rank + 1]], 5, cut[rank])
+    assert torch.equal(idx, want_i) and int(idx.max()) < 101
+
+
+def test_sharded_knn_topk_equals_unsharded_world2():
+    _spawn(_sharded_knn, 2)

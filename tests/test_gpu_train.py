@@ -429,3 +429,64 @@ def test_augmentation_writes_the_stem_layout_directly():
     l_nhwc = float(model.training_step(((a0, a1), None), 0))
     l_s2d = float(model.training_step(((s0, s1), None), 0))
     assert l_nhwc == l_s2d
+
+
+@pytest.mark.parametrize("kind", ["sgd", "adamw", "lars"])
+def test_optimizer_state_dict_round_trip_resumes_the_run(kind):
+    """save -> load into a FRESH optimiser over fresh copies of the parameters -> the next steps equal the
+    uninterrupted run bit for bit (momentum / moments / AdamW step counters live in private arenas, not in
+    torch's self.state); SGD and AdamW checkpoints are also interchangeable with torch.optim's."""
+    from ssl_wafermap_amd import optim
+
+    torch.manual_seed(0)
+    shapes = [(64, 3, 7, 7), (64,), (128, 64, 3, 3), (5,)]
+    init = [torch.randn(s) for s in shapes]
+
+    def make(params):
+        if kind == "sgd":
+            return optim.SGD(params, lr=0.06, momentum=0.9, weight_decay=5e-4)
+        if kind == "adamw":
+            return optim.AdamW(params, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05)
+        return optim.LARS(params, lr=0.2, momentum=0.9, weight_decay=1.5e-6)
+
+    def grads(it):
+        return [torch.randn(s, generator=torch.Generator().manual_seed(100 * it + i)) for i, s in enumerate(shapes)]
+
+    def run(opt, params, its):
+        for it in its:
+            opt.zero_grad()
+            for p, g in zip(params, grads(it)):
+                p.grad.add_(g.to(DEV))
+            opt.step()
+
+    pa = [torch.nn.Parameter(t.clone().to(DEV)) for t in init]
+    oa = make(pa)
+    run(oa, pa, range(3))
+    sd = oa.state_dict()
+    weights = [p.detach().clone() for p in pa]
+    assert len(sd["state"]) == len(shapes)
+    run(oa, pa, range(3, 6))
+
+    pb = [torch.nn.Parameter(w.clone()) for w in weights]
+    ob = make(pb)
+    ob.load_state_dict(sd)
+    run(ob, pb, range(3, 6))
+    for a, b in zip(pa, pb):
+        if kind == "lars":  # the per-parameter norms are summed with f32 atomics: last-bit differences run to run
+            torch.testing.assert_close(a.detach(), b.detach(), atol=1e-6, rtol=1e-6)
+        else:
+            assert torch.equal(a.detach(), b.detach())
+
+    if kind in ("sgd", "adamw"):  # the same checkpoint drives torch.optim to the same place
+        pc = [torch.nn.Parameter(w.clone().cpu()) for w in weights]
+        oc = (torch.optim.SGD(pc, lr=0.06, momentum=0.9, weight_decay=5e-4) if kind == "sgd"
+              else torch.optim.AdamW(pc, lr=1e-3, betas=(0.9, 0.95), weight_decay=0.05))
+        oc.load_state_dict({"state": {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in sd["state"].items()},
+                            "param_groups": oc.state_dict()["param_groups"]})
+        for it in range(3, 6):
+            oc.zero_grad()
+            for p, g in zip(pc, grads(it)):
+                p.grad = g.clone()
+            oc.step()
+        for a, c in zip(pa, pc):
+            torch.testing.assert_close(a.detach().cpu(), c.detach(), atol=2e-6, rtol=2e-6)
