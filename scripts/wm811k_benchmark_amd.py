@@ -92,6 +92,7 @@ def main(argv=None):
     ap.add_argument("--out", default=None)
     ap.add_argument("--limit-train-batches", type=int, default=None)
     ap.add_argument("--graph", action="store_true", help="replay the SimCLR-family step from a captured hipGraph")
+    ap.add_argument("--log-every", type=int, default=50, help="Lightning's log_every_n_steps (loss / rep_std rows)")
     args = ap.parse_args(argv)
 
     import pandas as pd
@@ -155,7 +156,8 @@ def main(argv=None):
             log_dir = out_root / (model_name if args.n_runs <= 1 else f"{model_name}/run{seed}")
             if rank == 0:
                 log_dir.mkdir(parents=True, exist_ok=True)
-            trainer = Trainer(max_epochs=max_epochs, limit_train_batches=args.limit_train_batches, use_graph=args.graph)
+            trainer = Trainer(max_epochs=max_epochs, limit_train_batches=args.limit_train_batches, use_graph=args.graph,
+                              log_every_n_steps=args.log_every)
             torch.cuda.reset_peak_memory_stats()
             start = time.time()
             trainer.fit(benchmark_model, train_dataloaders=dataloader_train_ssl, val_dataloaders=dataloader_test)
@@ -179,6 +181,8 @@ def main(argv=None):
                                     confusion_matrix=np.stack(benchmark_model.confusion_matrix))
                 pd.DataFrame(runs).to_csv(log_dir / "results.csv", index=False)
                 pd.DataFrame(trainer.history).to_csv(log_dir / "history.csv", index=False)
+                # the reference logs these scalars to TensorBoard (train_loss_ssl, rep_std at log_every_n_steps)
+                pd.DataFrame(trainer.loss_log, columns=["step", "loss", "rep_std"]).to_csv(log_dir / "loss_log.csv", index=False)
             del benchmark_model, trainer
             torch.cuda.empty_cache()
         bench_results[model_name] = runs

@@ -1,0 +1,121 @@
+"""GPU: the float path on the data the reference checkout itself HOLDS (tests/golden/*.npz, converted once by
+tests/golden/make_reference_data.py -- arrays only).
+
+(a) `knn_predict` on the reference's real SimSiam backbone features (data/interim/model_preds/
+    SimSiam_preds_subset.pkl.xz: 12 449 x 512 float16 + failureCode), split exactly as the reference's dummy mode
+    splits those wafers (scripts/WM811k_benchmark.py:87-97), evaluated as src/ssl_wafermap/models/knn.py:67-133
+    does (L2-normalised bank, k 5, t 0.1, macro accuracy / F1): HIP path vs the CPU oracle.
+(b) SimCLR (scripts/WM811k_benchmark.py:227-255) trained on the reference's real wafers with the reference's
+    hyper-parameters (bs 64, T 0.5, lr 0.06 * 64/256) through the ported driver: the loss, rep_std and kNN accuracy
+    must land in bands around the reference's OWN curves (data/interim/model_logs/**/run-SimCLR-tag-*.csv).  These are
+    soft pins: same data, same recipe, different seeds and bf16 instead of fp16 AMP.
+"""
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN
+from oracle import knn as ok
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _dummy_split(labels):
+    from sklearn.model_selection import train_test_split
+
+    return train_test_split(np.arange(len(labels)), test_size=0.2, random_state=42, stratify=labels)
+
+
+def test_knn_predict_on_the_reference_simsiam_embeddings():
+    from ssl_wafermap_amd import functional as F
+    from ssl_wafermap_amd.models.knn import macro_metrics
+    from ssl_wafermap_amd.utils.benchmarking import knn_predict
+
+    z = np.load(GOLDEN / "simsiam_preds_subset.npz")
+    emb, labels = torch.from_numpy(z["embeddings"].astype(np.float32)), torch.from_numpy(z["labels"].astype(np.int64))
+    assert emb.shape == (12449, 512)
+    i_train, i_val = _dummy_split(labels.numpy())
+    bank_raw, q_raw = emb[i_train], emb[i_val]
+    y_bank, y_val = labels[i_train], labels[i_val]
+
+    # oracle: knn.py:76-80 bank build, :91-98 predict
+    bank = ok.build_bank(bank_raw)                                  # [D, N]
+    q = torch.nn.functional.normalize(q_raw, dim=1)
+    ref = ok.knn_predict(q, bank, y_bank, 9, 5, 0.1)
+    sim_ref, idx_ref = ok.knn_topk(q, bank, 6)
+
+    # HIP: wm_l2_normalize -> wm_knn_topk -> wm_knn_vote, float32 parity preset
+    bank_nd = F.l2_normalize(bank_raw.to(DEV))
+    qd = F.l2_normalize(q_raw.to(DEV))
+    got = knn_predict(qd, bank_nd.t(), y_bank.to(DEV), 9, 5, 0.1).cpu()
+    sim, idx = F.knn_topk(qd, bank_nd, 5)
+    sim, idx = sim.cpu(), idx.cpu().long()
+
+    torch.testing.assert_close(sim, sim_ref[:, :5], atol=3e-6, rtol=0)
+    # neighbour j is decided when it beats neighbour j+1 by a margin; real features contain exact duplicates
+    # (identical wafers), where any order is a correct top-k
+    # (position j is decided when it is separated from BOTH neighbours in the ranking by more than the float32
+    # accumulation-order noise of a 512-term dot product, 8e-6: DESIGN.md section 3)
+    below = (sim_ref[:, :5] - sim_ref[:, 1:6]) > 8e-6
+    above = torch.cat([torch.ones(len(q), 1, dtype=torch.bool), below[:, :4]], dim=1)
+    decided = below & above
+    print(f"{float(decided.float().mean()):.3f} of the top-5 slots are decided by > 8e-6")
+    assert float(decided.float().mean()) > 0.8
+    assert torch.equal(idx[decided], idx_ref[:, :5][decided])
+    # the vote: identical wherever the winning class wins by a margin
+    scores = ok.knn_scores(sim_ref[:, :5], idx_ref[:, :5], y_bank, 9, 0.1)
+    top2 = scores.topk(2, dim=1).values
+    clear = (top2[:, 0] - top2[:, 1]) > 1e-3 * top2[:, 0]
+    assert float(clear.float().mean()) > 0.97
+    assert torch.equal(got[clear, 0], ref[clear, 0])
+    acc, f1, cm = macro_metrics(got[:, 0].to(DEV), y_val.to(DEV), 9)
+    acc_r, f1_r, cm_r = macro_metrics(ref[:, 0], y_val, 9)
+    print(f"real SimSiam features: kNN macro accuracy {acc:.4f} (oracle {acc_r:.4f}), macro F1 {f1:.4f} (oracle {f1_r:.4f}), "
+          f"{int((got[:, 0] != ref[:, 0]).sum())} of {len(ref)} top-1 differ (ties)")
+    assert abs(acc - acc_r) < 2e-3 and abs(f1 - f1_r) < 2e-3
+    assert acc > 0.4   # measured 0.537 on this 80/20 split of the subset (oracle: the same value)
+
+    # bf16 streaming preset: same neighbours wherever float32 decides them by more than bf16 resolution
+    sim_b, idx_b = F.knn_topk(qd.bfloat16(), bank_nd.bfloat16(), 5)
+    assert float((sim_b.cpu() - sim_ref[:, :5]).abs().max()) < 1e-2
+    pred_b = F.knn_vote(sim_b, idx_b, y_bank.to(DEV), 9, 0.1).cpu()
+    acc_b, f1_b, _ = macro_metrics(pred_b[:, 0], y_val, 9)
+    assert abs(acc_b - acc_r) < 1.5e-2, (acc_b, acc_r)
+
+
+def test_simclr_on_the_reference_wafers_lands_in_the_reference_bands(tmp_path):
+    """One epoch of the ported dummy-mode driver (9 959 training wafers -> 155 steps at bs 64) + kNN validation."""
+    import sys
+
+    sys.path.insert(0, str(GOLDEN.parent.parent / "scripts"))
+    import wm811k_benchmark_amd as drv
+
+    curves = np.load(GOLDEN / "simclr_reference_curves.npz")
+    ref_loss = dict(zip(curves["train_loss_ssl_step"].tolist(), curves["train_loss_ssl_value"].tolist()))
+    ref_std = dict(zip(curves["rep_std_step"].tolist(), curves["rep_std_value"].tolist()))
+    assert abs(ref_loss[99] - 3.7336) < 1e-3 and abs(ref_std[99] - 0.01439) < 1e-4
+
+    res = drv.main(["--models", "SimCLR", "--max-epochs", "1", "--batch-size", "64", "--out", str(tmp_path), "--graph",
+                    "--log-every", "50"])
+    run = res["SimCLR"][0]
+    import pandas as pd
+
+    log = pd.read_csv(tmp_path / "SimCLR" / "loss_log.csv")
+    at99 = log[log.step == 99].iloc[0]
+    at149 = log[log.step == 149].iloc[0]
+    print(f"real wafers, bs 64: loss@99 {at99.loss:.4f} (reference 3.7336), loss@149 {at149.loss:.4f}, rep_std@99 "
+          f"{at99.rep_std:.4f} (reference 0.0144); kNN after epoch 1 (155 steps): accuracy {run['max_accuracy']:.4f} "
+          f"F1 {run['max_f1']:.4f} (reference after its first epoch of 583 steps: 0.609 / 0.637)")
+    assert np.isfinite(log.loss).all()
+    # reference 3.7336 at step 99 (3.44 at 299, 3.32 at 499); ln(127) = 4.84 at init.  Measured here: 3.45 -- the HIP
+    # path falls faster than the reference's logged run while tracking the float32 oracle on identical decisions
+    # (test_gpu_stability.py), so the gap is recipe-level (seeds, fp16-AMP loss scaling skipping early steps), not
+    # arithmetic; the band is +-0.5 around the reference value
+    assert abs(at99.loss - ref_loss[99]) < 0.5, at99.loss
+    assert at149.loss < at99.loss + 0.1
+    assert 0.008 < at99.rep_std < 0.035, at99.rep_std        # reference band 0.0144 (step 99) .. 0.027 (end)
+    assert 0.40 < run["max_accuracy"] <= 1.0                 # a quarter of the reference's first epoch
+    assert (tmp_path / "SimCLR" / "results.csv").exists() and (tmp_path / "SimCLR" / "confusion_matrix.npz").exists()
+    cm = np.load(tmp_path / "SimCLR" / "confusion_matrix.npz")["confusion_matrix"]
+    assert cm.shape == (1, 9, 9)
