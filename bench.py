@@ -1,26 +1,37 @@
 #!/usr/bin/env python3
-"""Headline benchmark: SimCLR ResNet-18 training throughput on synthetic wafer maps (BASELINE.json).
+"""Benchmarks of the MI355X hot path (BASELINE.json).  Default = the headline: SimCLR ResNet-18 training throughput
+on synthetic wafer maps.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload simclr_r18]
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
-One step = one pass of the hot path over one batch: fused two-view augmentation of 256 wafers per
-GPU (written in the stem's space-to-depth layout) -> ResNet-18 forward/backward on 2 x 256 images
-(3 x 224 x 224, bf16, BN statistics per view) ->
-SimCLR projection head -> NT-Xent (in-batch negatives) -> (N > 1: flat RCCL all-reduce of the
-gradient arena) -> fused SGD.  All device work runs in the hand-written HIP kernels of
-libwafer_hip.so; inputs (the ragged uint8 wafer store) are resident in HBM before the timed region.
+Workloads (`--workload`; each prints ONE JSON line with the same schema, rank 0):
+  simclr_r18        BASELINE configs[1] (default).  One step = fused two-view augmentation of 256 wafers per GPU
+                    (written in the stem's space-to-depth layout) -> ResNet-18 forward/backward on 2 x 256 images
+                    (3 x 224 x 224, bf16, BN statistics per view) -> SimCLR head -> NT-Xent (in-batch negatives) ->
+                    (N > 1: bucketed RCCL all-reduce of the flat gradient arena, overlapped with the backward stages)
+                    -> fused SGD.  The step replays captured hipGraphs.
+  dino_vit_tiny     BASELINE configs[2]: DINO, ViT-Tiny/16, 2 x 224^2 + 6 x 96^2 crops, 64 wafers per GPU, AdamW.
+  dino_vit_small    the reference's own DINOViT (ViT-S/16), same step.
+  mae_vit_small_16  BASELINE configs[3]: MAE ViT-S/16, 75 % mask, 64 wafers per GPU (MixedWM38-sized 52 x 52 maps).
+  mae_vit_b_32      the reference's own MAE (ViT-B/32).
+  knn_allpairs      BASELINE configs[4]: 811 457 x 128 bf16 embeddings row-sharded over the ranks, ONE all-gather of the
+                    shards, then every rank ranks its own rows against the whole bank (top-8); step = one batch of
+                    1024 queries per rank; metric queries/s.
+All device work runs in the hand-written HIP kernels of libwafer_hip.so; inputs are resident in HBM before the timed
+region.  The timed region holds EXACTLY K steps between two fences (barrier + synchronize), max over ranks.
 
-Prints ONE JSON line (rank 0): metric imgs/sec = wafers (not views) per second, whole job.
-  roofline     : the conv implicit-GEMM kernels (fwd + dgrad + wgrad), algorithmic FLOPs / the summed
-                 HIP-event durations of those launches, vs dense bf16 MFMA peak.  The events are
-                 recorded INSIDE the timed region on the launch stream, on the LAST timed step only
-                 (or every `--timer-every`-th): a timing event is a barrier packet on ROCm and
-                 bracketing all ~60 conv launches of every step costs ~20 % throughput, so the
-                 bracketed step runs eagerly (about twice a graph replay's time: with the default 100
-                 timed steps it costs ~1 % of `value`) and the others replay the captured hipGraph.
-  cpu_baseline : the torch-CPU oracle (oracle/) running BASELINE configs[0] (bs 32, fp32) on the
-                 host cores for a bounded number of steps (rank 0, N = 1 only).
+Extra objects on the line:
+  roofline     : dominant kernels of the workload (conv implicit-GEMM for simclr_r18; Linear GEMMs + attention for
+                 the transformers; the streaming pairwise-dot kernel for knn): algorithmic FLOPs (bytes) / summed
+                 HIP-event durations of those launches on the launch stream, measured live on ONE eager step run
+                 right AFTER the timed region (a timing event is a barrier packet: bracketing ~60 launches inside the
+                 timed steps would cost throughput), against the dense bf16 MFMA peak (HBM peak for knn).
+  cpu_baseline : the torch-CPU oracle (oracle/) on BASELINE configs[0] (bs 32, fp32), bounded sample, rank 0, N = 1:
+                 augmentation and model seconds split; plus the oracle knn_predict on a 100 k x 128 slice.
+  knn, augment : (simclr_r18, N = 1) the two secondary kernels of the north-star, timed with HIP events:
+                 811 457 x 128 top-8 for 64 / 256 / 1024 queries in bf16 and f32 (stream + select, formula-(ii) HBM
+                 fraction and dense-view TFLOP/s), and the fused augmentation kernel (views/s, HBM fraction).
 """
 import argparse
 import json
@@ -33,18 +44,21 @@ ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md chip table
-# HBM-side bytes per conv launch (mean over the 65 implicit-GEMM launches of a step), measured with
-# rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes of this same script, FETCH_SIZE doubled per the
-# gfx950 correction (calibrated on sgd_step: 138.1 / 92.0 MB measured vs 138.0 / 92.0 MB algorithmic):
-# profiles/r01_hbm_traffic_simclr_r18_v2.md.  A PMC pass cannot run inside the timed region, so this is the
-# committed measurement, not a live one.  Algorithmic bytes (every operand once): 230 MB per launch.
-# (The counter sits behind L2: repeats served by the 256-MB Infinity Cache are included.)
+HBM_PEAK_GBS = 8000.0           # HBM3E, same table
+# HBM-side bytes per conv launch (mean over the implicit-GEMM launches of a step), rocprofv3 --pmc FETCH_SIZE and
+# WRITE_SIZE in separate passes of this script, FETCH_SIZE doubled per the gfx950 correction (calibrated on
+# sgd_step).  A PMC pass cannot run inside the timed region: this is the committed measurement of the file named
+# below, not a live one.  Algorithmic bytes (every operand once): 230 MB per launch.
 CONV_TRAFFIC_BYTES_PER_LAUNCH = 518.0e6
-R18_GFLOP_PER_SAMPLE = 21.76    # SURVEY §8d: ResNet-18 fwd 3.627 GFLOP x 3 (fwd+bwd) x 2 views
+CONV_TRAFFIC_SOURCE = "profiles/r01_hbm_traffic_simclr_r18_v2.md (rocprofv3 --pmc, separate passes)"
+R18_GFLOP_PER_SAMPLE = 21.76    # SURVEY 8d: ResNet-18 fwd 3.627 GFLOP x 3 (fwd+bwd) x 2 views
+KNN_N, KNN_D, KNN_K = 811457, 128, 8
 
 
-def cpu_baseline(seconds_budget: float = 25.0):
-    """Oracle SimCLR step (torch CPU float32), BASELINE configs[0]: bs 32, two views, SGD."""
+# --------------------------------------------------------------------------------------------- CPU baselines
+def cpu_baseline(seconds_budget: float = 22.0):
+    """Oracle SimCLR step (torch CPU float32), BASELINE configs[0]: 1 000 synthetic wafers, bs 32, two views, SGD
+    lr 0.06 x 32/256.  Two warm-up steps, then as many timed steps as fit the budget (at most one epoch = 31)."""
     import numpy as np
     import torch
 
@@ -56,7 +70,7 @@ def cpu_baseline(seconds_budget: float = 25.0):
 
     torch.manual_seed(0)
     cores = torch.get_num_threads()
-    wafers, _ = synthetic_wafers(64, seed=1234)
+    wafers, _ = synthetic_wafers(1000, seed=1234)
     backbone, head = create_model("resnet18", num_classes=0), SimCLRProjectionHead(512, 512, 128)
     sd = {"backbone." + k: v.clone() for k, v in backbone.state_dict().items()}
     sd.update({"projection_head." + k: v.clone() for k, v in head.state_dict().items()})
@@ -66,8 +80,11 @@ def cpu_baseline(seconds_budget: float = 25.0):
     bufs = {}
     rng = np.random.default_rng(0)
     bs = 32
+    t_aug = t_model = 0.0
 
-    def step(i):
+    def step(i, timed):
+        nonlocal t_aug, t_model
+        t0 = time.perf_counter()
         idx = (np.arange(bs) + i * bs) % len(wafers)
         views = []
         for _ in range(2):
@@ -80,6 +97,7 @@ def cpu_baseline(seconds_budget: float = 25.0):
                                     rot90=rng.random() < 0.5, vflip=rng.random() < 0.5, hflip=rng.random() < 0.5)
                 imgs.append(oa.augment_view(w, d))
             views.append(torch.from_numpy(np.stack(imgs)))
+        t1 = time.perf_counter()
         for p in params.values():
             p.grad = None
         loss, _ = orn.simclr_loss(views[0], views[1], state, 0.5, True)
@@ -87,20 +105,151 @@ def cpu_baseline(seconds_budget: float = 25.0):
         with torch.no_grad():
             orn.sgd_step({k: p for k, p in params.items()}, {k: p.grad for k, p in params.items()}, bufs,
                          lr=6e-2 * bs / 256)
-        return float(loss)
+        t2 = time.perf_counter()
+        if timed:
+            t_aug += t1 - t0
+            t_model += t2 - t1
+        return float(loss.detach())
 
-    step(0)  # warm-up
+    step(0, False)
+    step(1, False)
     t0 = time.perf_counter()
     n = 0
-    while True:
-        step(n + 1)
+    while n < 31:
+        step(n + 2, True)
         n += 1
-        if time.perf_counter() - t0 > seconds_budget or n >= 8:
+        if time.perf_counter() - t0 > seconds_budget:
             break
     dt = time.perf_counter() - t0
     return {"value": round(bs * n / dt, 3), "unit": "imgs/sec", "cores": cores, "kind": "port",
-            "sample": f"{n} SimCLR ResNet-18 steps at bs {bs} (fp32, torch CPU oracle incl. numpy augmentation), "
-                      f"{dt:.1f} s"}
+            "augment_s": round(t_aug, 2), "model_s": round(t_model, 2),
+            "sample": f"{n} SimCLR ResNet-18 steps at bs {bs} over 1000 synthetic wafers after 2 warm-up steps (fp32 torch "
+                      f"CPU oracle; numpy augmentation in process, {t_aug:.1f} s of {dt:.1f} s)"}
+
+
+def cpu_knn_baseline():
+    """Oracle knn_predict (torch.mm + topk, fp32) on a 100 000 x 128 slice, 256 queries per call, k 8."""
+    import torch
+
+    from oracle import knn as ok
+
+    g = torch.Generator().manual_seed(7)
+    n, d, bq = 100_000, KNN_D, 256
+    bank = torch.nn.functional.normalize(torch.randn(n, d, generator=g), dim=1).t().contiguous()
+    labels = torch.randint(0, 9, (n,), generator=g)
+    q = bank.t()[:bq].contiguous()
+    ok.knn_predict(q, bank, labels, 9, KNN_K, 0.1)
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 50 and time.perf_counter() - t0 < 4.0:
+        ok.knn_predict(q, bank, labels, 9, KNN_K, 0.1)
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    qps = bq / dt
+    return {"value": round(qps, 1), "unit": "queries/sec against 100000 x 128 (fp32)", "cores": torch.get_num_threads(),
+            "kind": "port", "sample": f"{reps} calls of oracle knn_predict, 256 queries x 100 000 rows, k 8",
+            "extrapolated_allpairs_811457_s": round((KNN_N / qps) * (KNN_N / n), 1)}
+
+
+# --------------------------------------------------------------------------------------------- secondary kernels
+def knn_object(dev):
+    """811 457 x 128, top-8: wm_knn_topk (stream + select) for 64 / 256 / 1024 queries, bf16 and f32, HIP events."""
+    import torch
+
+    from ssl_wafermap_amd import functional as F
+
+    g = torch.Generator(device=dev).manual_seed(7)
+    bank32 = torch.nn.functional.normalize(torch.randn(KNN_N, KNN_D, generator=g, device=dev), dim=1)
+    bank16 = bank32.bfloat16()
+    out = {"n": KNN_N, "d": KNN_D, "k": KNN_K, "rows": []}
+    for dtype, bank in (("bf16", bank16), ("f32", bank32)):
+        s = bank.element_size()
+        for bq in (64, 256, 1024):
+            q = bank[1000:1000 + bq].contiguous()
+            for _ in range(3):
+                F.knn_topk(q, bank, KNN_K)
+            reps = 20
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            for _ in range(reps):
+                F.knn_topk(q, bank, KNN_K)
+            b.record()
+            torch.cuda.synchronize()
+            us = a.elapsed_time(b) * 1e3 / reps
+            bytes_ = KNN_N * KNN_D * s + bq * KNN_D * s + bq * KNN_K * 8      # SURVEY 8d formula (ii), one batch
+            out["rows"].append({"dtype": dtype, "queries": bq, "us_per_batch": round(us, 1),
+                                "hbm_GBs": round(bytes_ / us / 1e3, 1), "hbm_frac": round(bytes_ / us / 1e3 / HBM_PEAK_GBS, 3),
+                                "dense_TFLOPs": round(2.0 * bq * KNN_N * KNN_D / us / 1e6, 1),
+                                "allpairs_s": round(us * 1e-6 * (KNN_N / bq), 3)})
+    del bank32, bank16
+    torch.cuda.empty_cache()
+    return out
+
+
+def augment_object(dev, ds, B):
+    """The fused two-view augmentation kernel alone: 2 x B views of 224^2 in the stem's bf16 layout."""
+    import numpy as np
+    import torch
+
+    rng = np.random.default_rng(0)
+    tr = ds.transform
+    params = tr.sample(ds.store, np.arange(B), rng)
+    for _ in range(3):
+        tr.launch(ds.store, params, B, "s2d_bf16")
+    reps = 50
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        tr.launch(ds.store, params, B, "s2d_bf16")
+    b.record()
+    torch.cuda.synchronize()
+    us = a.elapsed_time(b) * 1e3 / reps
+    views = 2 * B
+    hw = float(np.mean(ds.store.heights_np[:B].astype(np.int64) * ds.store.widths_np[:B]))
+    bytes_ = views * (hw + 3 * 224 * 224 * 2)       # SURVEY 8d: read H*W uint8, write 3 x 224 x 224 bf16 per view
+    written = views * 112 * 112 * 16 * 2            # what the s2d layout actually stores (16 channels, 12 used)
+    return {"views": views, "us_per_launch": round(us, 1), "views_per_sec": round(views / us * 1e6, 0),
+            "algorithmic_GBs": round(bytes_ / us / 1e3, 1), "hbm_frac": round(bytes_ / us / 1e3 / HBM_PEAK_GBS, 3),
+            "written_GBs": round(written / us / 1e3, 1), "includes": "host parameter upload (32 KB) + launch, per call"}
+
+
+# --------------------------------------------------------------------------------------------- workloads
+def make_vit_workload(name, dev, B, world):
+    """DINO / MAE steps on synthetic wafers -> (dataset, model, transform format, GFLOP per sample, label)."""
+    from ssl_wafermap_amd.data import WaferMapDataset
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.models import MAE, DINOViT
+    from ssl_wafermap_amd.transforms import BaseViewTransform, MultiCropTransform
+
+    def vit_gflop(d, tokens, layers=12, patch=16, mlp=4):
+        per_layer = 2.0 * (tokens * d * d * (4 + 2 * mlp) + 2 * tokens * tokens * d)
+        return (layers * per_layer + 2.0 * (tokens - 1) * (patch * patch * 3) * d) / 1e9
+
+    if name.startswith("dino"):
+        bb = "vit_tiny" if name.endswith("tiny") else "vit_small"
+        d = 192 if bb == "vit_tiny" else 384
+        wafers, labels = synthetic_wafers(2048, seed=1)
+        ds = WaferMapDataset(wafers, labels, transform=MultiCropTransform(), device=dev)
+        model = DINOViT(None, 9, batch_size=B * world, log_rep_std=False, backbone=bb)
+        g224, g96 = vit_gflop(d, 197), vit_gflop(d, 37)
+        head = 2.0 * (d * 2048 + 2048 * 2048 + 2048 * 256 + 256 * 2048) / 1e9
+        gflop = 2 * (g224 + head) + 3 * (2 * g224 + 6 * g96 + 8 * head)   # teacher: 2 fwd; student: 8 crops fwd + bwd
+        label = f"DINO {'ViT-Tiny' if bb == 'vit_tiny' else 'ViT-S'}/16, {B} wafers/GPU/step, 2x224^2 + 6x96^2 crops, AdamW"
+        cfg = "BASELINE.json configs[2]" if bb == "vit_tiny" else "the reference's DINOViT"
+        return ds, model, gflop, f"{label} ({cfg})"
+    bb = "vit_small_16" if "small" in name else "vit_b_32"
+    fixed = 52 if bb == "vit_small_16" else None                            # MixedWM38 maps are 52 x 52
+    wafers, labels = synthetic_wafers(2048, seed=1, fixed_size=fixed)
+    ds = WaferMapDataset(wafers, labels, transform=BaseViewTransform(n_views=1, denoise=bb == "vit_small_16"), device=dev)
+    model = MAE(None, 9, batch_size=B * world, log_rep_std=False, backbone=bb)
+    d, tokens, patch = (384, 197, 16) if bb == "vit_small_16" else (768, 50, 32)
+    keep = int(tokens * 0.25)
+    enc = vit_gflop(d, keep, patch=patch) + 2.0 * (tokens - 1 - keep) * patch * patch * 3 * d / 1e9
+    dec = vit_gflop(512, tokens, layers=1, patch=1) + 2.0 * (keep * d * 512 + (tokens - keep) * 512 * patch * patch * 3) / 1e9
+    gflop = 3 * (enc + dec)
+    label = f"MAE {'ViT-S/16' if bb == 'vit_small_16' else 'ViT-B/32'}, 75 % mask, {B} wafers/GPU/step, AdamW"
+    cfg = "BASELINE.json configs[3]" if bb == "vit_small_16" else "the reference's MAE"
+    return ds, model, gflop, f"{label} ({cfg})"
 
 
 def main():
@@ -108,12 +257,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--batch", type=int, default=256, help="wafers per GPU per step")
+    ap.add_argument("--workload", default="simclr_r18",
+                    choices=["simclr_r18", "dino_vit_tiny", "dino_vit_small", "mae_vit_small_16", "mae_vit_b_32", "knn_allpairs"])
+    ap.add_argument("--batch", type=int, default=None, help="wafers per GPU per step (default: 256 SimCLR, 64 DINO / MAE)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the knn / augment objects of the default line")
     ap.add_argument("--no-kernel-timer", action="store_true")
-    ap.add_argument("--timer-every", type=int, default=0,
-                    help="bracket the conv launches on every n-th timed step (0: on the last timed step only)")
-    ap.add_argument("--no-graph", action="store_true", help="do not capture the step into a hipGraph")
+    ap.add_argument("--no-graph", action="store_true", help="do not capture the step into hipGraphs")
+    ap.add_argument("--no-overlap", action="store_true", help="N > 1: one graph + one exposed all-reduce (no stages)")
     args = ap.parse_args()
 
     import numpy as np
@@ -122,10 +273,6 @@ def main():
 
     from ssl_wafermap_amd import distributed as wdist
     from ssl_wafermap_amd import ops
-    from ssl_wafermap_amd.data import WaferMapDataset
-    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
-    from ssl_wafermap_amd.models import SimCLR
-    from ssl_wafermap_amd.transforms import BaseViewTransform
 
     rank, world, local = wdist.init_from_env()
     if world != args.gpus:
@@ -135,16 +282,138 @@ def main():
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
-    B = args.batch
-    wafers, labels = synthetic_wafers(4096, seed=1234 + rank)
-    ds = WaferMapDataset(wafers, labels, transform=BaseViewTransform(), device=dev)
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(step_fn, warmup, steps):
+        """W untimed + exactly K timed steps between two fences; -> (wall s max over ranks, GPU-event ms per step,
+        the value step_fn returned last)."""
+        last = None
+        for i in range(warmup):
+            last = step_fn(i)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        fence()
+        t0 = time.perf_counter()
+        ev0.record()
+        for i in range(steps):
+            last = step_fn(warmup + i)
+        ev1.record()
+        fence()
+        dt = time.perf_counter() - t0
+        gpu_ms = ev0.elapsed_time(ev1) / steps
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, gpu_ms, last
+
+    def finish(out):
+        if rank == 0:
+            print(json.dumps(out), flush=True)
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+
+    def check_finite(loss):
+        v = float(loss.detach())
+        if not np.isfinite(v):
+            # a throughput figure of a network that has diverged is not a training throughput
+            print(f"[bench] rank {rank}: non-finite loss {v} after {args.warmup} + {args.steps} steps", file=sys.stderr)
+            if world > 1:
+                dist.destroy_process_group()
+            raise SystemExit(3)
+        return v
+
+    def roofline_from(timer, sampled_steps, kernel_label, traffic=None, traffic_source=None):
+        summ = timer.summary()
+        work = sum(v["work"] for v in summ.values())
+        ms = sum(v["ms"] for v in summ.values())
+        ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        r = {"bound": "mfma", "kernel": kernel_label, "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS,
+             "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic,
+             "launches": int(sum(v["launches"] for v in summ.values())), "sampled_steps": sampled_steps,
+             "kernel_ms_per_step": round(ms / max(sampled_steps, 1), 3),
+             "by_kernel": {k: {"TFLOP/s": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
+                               "ms_per_step": round(v["ms"] / max(sampled_steps, 1), 3)} for k, v in summ.items()}}
+        if traffic_source:
+            r["traffic_source"] = traffic_source
+        return r
+
+    # ------------------------------------------------------------------------------------------ kNN all-pairs
+    if args.workload == "knn_allpairs":
+        from ssl_wafermap_amd import functional as F
+
+        bq = args.batch or 1024
+        per = -(-KNN_N // world)
+        lo, hi = rank * per, min(KNN_N, (rank + 1) * per)
+        g = torch.Generator(device=dev).manual_seed(7 + rank)
+        shard = torch.nn.functional.normalize(torch.randn(hi - lo, KNN_D, generator=g, device=dev), dim=1).bfloat16()
+        if world > 1:   # the one exchange of the path: every rank ends up with the whole 208-MB bank
+            pad = torch.zeros(per, KNN_D, dtype=torch.bfloat16, device=dev)
+            pad[: hi - lo] = shard
+            parts = [torch.empty_like(pad) for _ in range(world)]
+            t0 = time.perf_counter()
+            dist.all_gather(parts, pad)
+            torch.cuda.synchronize()
+            gather_s = time.perf_counter() - t0
+            bank = torch.cat(parts)[:KNN_N].contiguous()
+        else:
+            gather_s, bank = 0.0, shard
+        nq_local = hi - lo
+
+        def step(i):
+            o = lo + (i * bq) % max(nq_local - bq, 1)
+            return F.knn_topk(bank[o:o + bq], bank, KNN_K)
+
+        dt, gpu_ms, (sim, idx) = timed(step, args.warmup, args.steps)
+        ok = bool((sim[:, 0] > 0.99).all()) and bool((sim[:, :-1] >= sim[:, 1:]).all())
+        if not ok:
+            raise SystemExit("knn_allpairs: self-retrieval / sortedness check failed")
+        qps = bq * world * args.steps / dt
+        us = gpu_ms * 1e3
+        bytes_ = KNN_N * KNN_D * 2 + bq * KNN_D * 2 + bq * KNN_K * 8
+        finish({"metric": "queries/sec (all-pairs cosine kNN top-8, 811457 x 128 bf16)", "value": round(qps, 1),
+                "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                "ms_per_step": round(1e3 * dt / args.steps, 4), "gpu_ms_per_step": round(gpu_ms, 4), "higher_is_better": True,
+                "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                "config": {"workload": f"all-pairs kNN top-{KNN_K}, {KNN_N} x {KNN_D} bf16 rows sharded over {world} ranks, one "
+                                       f"all-gather of the shards, {bq} queries per rank per step (BASELINE.json configs[4])",
+                           "queries_per_step_per_gpu": bq, "all_gather_s": round(gather_s, 4),
+                           "allpairs_extrapolated_s": round(KNN_N / qps, 3)},
+                "roofline": {"bound": "hbm" if bq <= 256 else "mfma", "kernel": "knn_stream_b128 + knn_select (wm_knn_topk)",
+                             "achieved": round(bytes_ / us / 1e3, 1) if bq <= 256 else round(2.0 * bq * KNN_N * KNN_D / us / 1e6, 1),
+                             "peak": HBM_PEAK_GBS if bq <= 256 else MFMA_BF16_PEAK_TFLOPS, "unit": "GB/s" if bq <= 256 else "TFLOP/s",
+                             "frac": round((bytes_ / us / 1e3 / HBM_PEAK_GBS) if bq <= 256 else (2.0 * bq * KNN_N * KNN_D / us / 1e6 / MFMA_BF16_PEAK_TFLOPS), 4),
+                             "traffic": None}})
+        return
+
+    # ------------------------------------------------------------------------------------------ training workloads
+    from ssl_wafermap_amd.data import WaferMapDataset
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.graph import GraphedTrainStep
+    from ssl_wafermap_amd.models import SimCLR
+    from ssl_wafermap_amd.transforms import BaseViewTransform
+
+    simclr = args.workload == "simclr_r18"
+    B = args.batch or (256 if simclr else 64)
     torch.manual_seed(0)
-    model = SimCLR(None, 9, batch_size=B * world, max_epochs=150, gather_distributed=False).to(dev).train()
+    if simclr:
+        wafers, labels = synthetic_wafers(4096, seed=1234 + rank)
+        ds = WaferMapDataset(wafers, labels, transform=BaseViewTransform(), device=dev)
+        model = SimCLR(None, 9, batch_size=B * world, max_epochs=150, gather_distributed=False)
+        gflop, label = R18_GFLOP_PER_SAMPLE, ("SimCLR ResNet-18, 256 wafers/GPU/step, two 3x224x224 views, NT-Xent in-batch "
+                                              "negatives, SGD (BASELINE.json configs[1])")
+        FMT, metric = "s2d_bf16", "imgs/sec (SimCLR ResNet18, bs=256, 224^2)"
+    else:
+        ds, model, gflop, label = make_vit_workload(args.workload, dev, B, world)
+        FMT, metric = "nhwc_bf16", f"imgs/sec ({args.workload})"
+    model = model.to(dev).train()
     (opt,), _ = model.configure_optimizers()
     sync = wdist.GradSync(opt)
+    wdist.broadcast_state(model, opt)
     rng = np.random.default_rng(rank)
-    # the augmentation kernel writes the 2x2 space-to-depth layout the stem convolution consumes (no layout pass)
-    FMT = "s2d_bf16"
 
     def eager_step(i):
         idx = (np.arange(B) + i * B) % len(ds)
@@ -158,97 +427,69 @@ def main():
         return loss
 
     graphed = None
-
-    def step(i):
-        # sampled steps (kernel timer on) run eagerly: timing events cannot be captured
-        if graphed is None or ops.TIMER is not None:
-            return eager_step(i)
-        return graphed.step((np.arange(B) + i * B) % len(ds), rng, sync)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for i in range(args.warmup):
-        step(i)
+    for i in range(min(args.warmup, 3)):
+        eager_step(i)
     if not args.no_graph:
         try:
-            from ssl_wafermap_amd.graph import GraphedTrainStep
-
-            graphed = GraphedTrainStep(model, opt, ds, B, fmt=FMT).capture(np.arange(B), rng, sync)
-            for i in range(2):
-                step(i)
+            stages = bool(getattr(model, "backward_stages", False)) and world > 1 and not args.no_overlap
+            graphed = GraphedTrainStep(model, opt, ds, B, fmt=FMT, stages=stages).capture(np.arange(B), rng, sync)
         except Exception as e:  # capture is an optimisation: report and continue eagerly
             print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
             graphed = None
-    timer = None if args.no_kernel_timer else ops.KernelTimer()
-    timed_steps = 0
-    fence()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if args.timer_every > 0:
-            sample = timer is not None and i % args.timer_every == args.timer_every - 1
-        else:
-            sample = timer is not None and i == args.steps - 1
-        ops.TIMER = timer if sample else None
-        timed_steps += int(sample)
-        loss = step(args.warmup + i)
-    ops.TIMER = None
-    host_dt = time.perf_counter() - t0  # time the host needed to enqueue the K steps (no sync yet)
-    fence()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    final_loss = float(loss.item())
-    if not np.isfinite(final_loss):
-        # a throughput figure of a network that has diverged is not a training throughput
-        print(f"[bench] rank {rank}: non-finite loss {final_loss} after {args.warmup} + {args.steps} steps", file=sys.stderr)
-        if world > 1:
-            dist.destroy_process_group()
-        raise SystemExit(3)
 
-    if rank == 0:
-        imgs = B * world * args.steps
-        value = imgs / dt
-        roof = None
-        if timer is not None:
-            summ = timer.summary()
-            work = sum(v["work"] for v in summ.values())
-            ms = sum(v["ms"] for v in summ.values())
-            ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-            roof = {"bound": "mfma", "kernel": "conv_igemm + conv3x3_patch + conv_wgrad (implicit-GEMM, bf16 MFMA)",
-                    "achieved": round(ach, 2), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": CONV_TRAFFIC_BYTES_PER_LAUNCH,
-                    "traffic_source": "profiles/r01_hbm_traffic_simclr_r18_v2.md (rocprofv3 --pmc, separate passes)",
-                    "launches": int(sum(v["launches"] for v in summ.values())),
-                    "sampled_steps": timed_steps,
-                    "kernel_ms_per_step": round(ms / max(timed_steps, 1), 3),
-                    "by_kernel": {k: {"TFLOP/s": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                      "ms_per_step": round(v["ms"] / max(timed_steps, 1), 3)} for k, v in summ.items()}}
-        out = {
-            "metric": "imgs/sec (SimCLR ResNet18, bs=256, 224^2)",
-            "value": round(value, 2), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps,
-            "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "SimCLR ResNet-18, 256 wafers/GPU/step, two 3x224x224 views, NT-Xent in-batch "
-                                   "negatives, SGD (BASELINE.json configs[1])",
-                       "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                       "hip_graph": graphed is not None,
-                       "model_tflop_per_step_per_gpu": round(R18_GFLOP_PER_SAMPLE * B / 1e3, 3),
-                       "model_mfma_frac": round(value / world * R18_GFLOP_PER_SAMPLE / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)},
-            "final_loss": round(final_loss, 4),
-            "host_enqueue_ms_per_step": round(1e3 * host_dt / args.steps, 3),
-            "roofline": roof,
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    def step(i):
+        if graphed is None:
+            return eager_step(i)
+        return graphed.step((np.arange(B) + i * B) % len(ds), rng, sync)
+
+    dt, gpu_ms, loss = timed(step, args.warmup, args.steps)
+    final_loss = check_finite(loss)
+
+    # ---- after the timed region: host-side preparation cost of a step, and ONE eager step with event brackets
+    t0 = time.perf_counter()
+    for i in range(20):
+        p = ds.transform.sample(ds.store, (np.arange(B) + i * B) % len(ds), rng)
+    host_prepare_ms = (time.perf_counter() - t0) / 20 * 1e3
+    roof = None
+    if not args.no_kernel_timer:
+        timer = ops.KernelTimer()
+        ops.TIMER = timer
+        check_finite(eager_step(args.warmup + args.steps))
+        ops.TIMER = None
+        torch.cuda.synchronize()
+        if simclr:
+            roof = roofline_from(timer, 1, "conv_igemm + conv3x3_patch + conv_wgrad (implicit-GEMM, bf16 MFMA)",
+                                 CONV_TRAFFIC_BYTES_PER_LAUNCH, CONV_TRAFFIC_SOURCE)
+        else:
+            roof = roofline_from(timer, 1, "Linear GEMMs (conv_igemm 1x1 fwd / dgrad, conv_wgrad) + attn_fwd / attn_bwd, bf16 MFMA")
+
+    imgs = B * world * args.steps
+    value = imgs / dt
+    out = {
+        "metric": metric, "value": round(value, 2), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": label, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                   "hip_graph": graphed is not None,
+                   "backward_stage_graphs": len(graphed.graphs) if graphed is not None else 0,
+                   "model_tflop_per_step_per_gpu": round(gflop * B / 1e3, 3),
+                   "model_mfma_frac": round(value / world * gflop / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)},
+        "final_loss": round(final_loss, 4),
+        "gpu_ms_per_step": round(gpu_ms, 3),          # HIP events around the K steps on the launch stream
+        "host_prepare_ms_per_step": round(host_prepare_ms, 3),  # drawing + checking the step's augmentation decisions
+        "roofline": roof,
+    }
+    if world == 1 and simclr and not args.no_secondary:
+        del graphed
+        model = opt = None
+        torch.cuda.empty_cache()
+        out["augment"] = augment_object(dev, ds, B)
+        out["knn"] = knn_object(dev)
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+        if simclr and not args.no_secondary:
+            out["knn"]["cpu_baseline"] = cpu_knn_baseline()
+    finish(out)
 
 
 if __name__ == "__main__":

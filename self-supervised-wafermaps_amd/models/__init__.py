@@ -1,7 +1,7 @@
 from .knn import KNNBenchmarkModule, macro_metrics  # noqa: F401
 from .resnet import ResNet18, create_model  # noqa: F401
 from .simclr import SimCLR  # noqa: F401
-from .vit import VisionTransformer, vit_base, vit_small  # noqa: F401
+from .vit import VisionTransformer, vit_base, vit_small, vit_tiny  # noqa: F401
 from .dino import DINO, DINOViT  # noqa: F401
 from .mae import MAE, MAEBackbone, MAEDecoder, SimMIM, masked_autoencoder, vit_b_32  # noqa: F401
 from .moco import MoCo  # noqa: F401

@@ -17,14 +17,19 @@ from .. import heads, ops, optim
 from ..loss import DINOLoss
 from ..utils import debug, model_utils, scheduler
 from .knn import KNNBenchmarkModule
-from .vit import vit_small
+from .vit import vit_base, vit_small, vit_tiny
+
+_BACKBONES = {"vit_small": vit_small, "vit_tiny": vit_tiny, "vit_base": vit_base}
 
 
 class DINOViT(KNNBenchmarkModule):
     def __init__(self, dataloader_kNN=None, num_classes=9, batch_size: int = 64, max_epochs: int = 150,
-                 batch_norm: bool = True, log_rep_std: bool = True, **kwargs):
+                 batch_norm: bool = True, log_rep_std: bool = True, backbone: str = "vit_small", **kwargs):
         super().__init__(dataloader_kNN, num_classes, **kwargs)
-        self.backbone = vit_small(patch_size=16)
+        # "vit_small" = the reference's dino_vits16 (:548-550); "vit_tiny" = BASELINE.json configs[2] (192-d, 3 heads)
+        if backbone not in _BACKBONES:
+            raise ValueError(f"DINOViT: unknown backbone {backbone!r} (have {sorted(_BACKBONES)})")
+        self.backbone = _BACKBONES[backbone](patch_size=16)
         feature_dim = self.backbone.embed_dim
         self.head = heads.DINOProjectionHead(feature_dim, 2048, 256, 2048, batch_norm=batch_norm)
         self.teacher_backbone = copy.deepcopy(self.backbone)

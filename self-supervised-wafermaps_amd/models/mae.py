@@ -94,6 +94,20 @@ def vit_b_32():
                            seq_length=50)
 
 
+def vit_small_16():
+    """ViT-S/16 geometry (384-d, 6 heads, 197 tokens): BASELINE.json configs[3], MAE on MixedWM38."""
+    return SimpleNamespace(image_size=224, patch_size=16, num_layers=12, num_heads=6, hidden_dim=384, mlp_dim=1536,
+                           seq_length=197)
+
+
+def vit_tiny_16():
+    return SimpleNamespace(image_size=224, patch_size=16, num_layers=12, num_heads=3, hidden_dim=192, mlp_dim=768,
+                           seq_length=197)
+
+
+VIT_GEOMETRIES = {"vit_b_32": vit_b_32, "vit_small_16": vit_small_16, "vit_tiny_16": vit_tiny_16}
+
+
 class MAEBackbone(nn.Module):
     def __init__(self, image_size=224, patch_size=32, num_layers=12, num_heads=12, hidden_dim=768, mlp_dim=3072):
         super().__init__()
@@ -203,10 +217,14 @@ masked_autoencoder = SimpleNamespace(MAEBackbone=MAEBackbone, MAEDecoder=MAEDeco
 
 class MAE(KNNBenchmarkModule):
     def __init__(self, dataloader_kNN=None, num_classes=9, batch_size: int = 64, max_epochs: int = 150,
-                 log_rep_std: bool = True, **kwargs):
+                 log_rep_std: bool = True, backbone: str = "vit_b_32", **kwargs):
         super().__init__(dataloader_kNN, num_classes, **kwargs)
         decoder_dim = 512
-        vit = vit_b_32()
+        # "vit_b_32" = the reference's torchvision.models.vit_b_32() (both scripts); "vit_small_16" = BASELINE.json
+        # configs[3]: 197 tokens, 49 kept at mask ratio 0.75, 16 x 16 x 3 = 768 predicted values per masked patch
+        if backbone not in VIT_GEOMETRIES:
+            raise ValueError(f"MAE: unknown backbone {backbone!r} (have {sorted(VIT_GEOMETRIES)})")
+        vit = VIT_GEOMETRIES[backbone]()
         self.warmup_epochs = 40 if max_epochs >= 800 else 20
         self.mask_ratio = 0.75
         self.patch_size = vit.patch_size

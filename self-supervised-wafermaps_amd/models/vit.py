@@ -161,6 +161,13 @@ def vit_small(patch_size: int = 16, **kw) -> VisionTransformer:
                              eps=1e-6, **kw)
 
 
+def vit_tiny(patch_size: int = 16, **kw) -> VisionTransformer:
+    """dino's vit_tiny: dim 192, depth 12, 3 heads (head dim 64), MLP x4 -- the shape the reference notes as the
+    lighter DINO backbone (scripts/WM811k_benchmark.py:668-669) and BASELINE.json configs[2] names."""
+    return VisionTransformer(patch_size=patch_size, embed_dim=192, depth=12, num_heads=3, mlp_ratio=4, qkv_bias=True,
+                             eps=1e-6, **kw)
+
+
 def vit_base(patch_size: int = 16, **kw) -> VisionTransformer:
     return VisionTransformer(patch_size=patch_size, embed_dim=768, depth=12, num_heads=12, mlp_ratio=4, qkv_bias=True,
                              eps=1e-6, **kw)

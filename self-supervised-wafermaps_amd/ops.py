@@ -603,8 +603,8 @@ class _Linear(torch.autograd.Function):
         train = torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad)
         krsc, _ = _WCACHE.get(weight, kind="linear", need_crsk=train and x.requires_grad)
         y = torch.empty((b, k), dtype=torch.bfloat16, device=x.device)
-        check(_lib.load().wm_conv2d_fwd(ptr(x), ptr(krsc), ptr(y), b, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
-              "wm_conv2d_fwd(linear)")
+        check(_run("gemm_fwd", 2.0 * b * c * k, _lib.load().wm_conv2d_fwd, ptr(x), ptr(krsc), ptr(y), b, 1, 1, c, k, 1, 1,
+                   1, 1, 1, 0, stream_ptr()), "wm_conv2d_fwd(linear)")
         ctx.save_for_backward(x)
         ctx.weight = weight
         ctx.geom = (b, c, k)
@@ -621,13 +621,13 @@ class _Linear(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, crsk = _WCACHE.get(weight, kind="linear", need_crsk=True)
             dx = torch.empty((b, c), dtype=torch.bfloat16, device=dy.device)
-            check(lib.wm_conv2d_dgrad(ptr(dy), ptr(crsk), ptr(dx), b, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
-                  "wm_conv2d_dgrad(linear)")
+            check(_run("gemm_dgrad", 2.0 * b * c * k, lib.wm_conv2d_dgrad, ptr(dy), ptr(crsk), ptr(dx), b, 1, 1, c, k, 1, 1,
+                       1, 1, 1, 0, stream_ptr()), "wm_conv2d_dgrad(linear)")
         if ctx.needs_input_grad[1]:
             slot = _arena_grad(weight)  # [K][1][1][C] == [K][C]: the atomics can land in the arena itself
             tgt = slot if slot is not None else torch.zeros((k, c), dtype=torch.float32, device=dy.device)
-            check(lib.wm_conv2d_wgrad(ptr(dy), ptr(x), ptr(tgt), b, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
-                  "wm_conv2d_wgrad(linear)")
+            check(_run("gemm_wgrad", 2.0 * b * c * k, lib.wm_conv2d_wgrad, ptr(dy), ptr(x), ptr(tgt), b, 1, 1, c, k, 1, 1,
+                       1, 1, 1, 0, stream_ptr()), "wm_conv2d_wgrad(linear)")
             dw = None if slot is not None else tgt
         return dx, dw
 

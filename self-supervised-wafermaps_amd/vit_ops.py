@@ -133,8 +133,9 @@ class _LinearBias(torch.autograd.Function):
         if residual is not None:
             residual = _bf16_rows(residual)
         # bias and residual are added in the GEMM kernel's epilogue
-        check(lib.wm_conv2d_fwd_bias_res(ptr(x), ptr(krsc), ptr(bias), ptr(residual), ptr(y), rows, 1, 1, c, k, 1, 1, 1, 1,
-                                         1, 0, stream_ptr()), "wm_conv2d_fwd_bias_res(linear)")
+        check(ops._run("gemm_fwd", 2.0 * rows * c * k, lib.wm_conv2d_fwd_bias_res, ptr(x), ptr(krsc), ptr(bias),
+                       ptr(residual), ptr(y), rows, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
+              "wm_conv2d_fwd_bias_res(linear)")
         ctx.save_for_backward(x)
         ctx.params = (weight, bias)
         ctx.geom = (rows, c, k)
@@ -152,8 +153,8 @@ class _LinearBias(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             _, crsk = ops._WCACHE.get(weight, kind="linear", need_crsk=True)
             dx = torch.empty((rows, c), dtype=torch.bfloat16, device=dout.device)
-            check(lib.wm_conv2d_dgrad(ptr(dout), ptr(crsk), ptr(dx), rows, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()),
-                  "wm_conv2d_dgrad(linear)")
+            check(ops._run("gemm_dgrad", 2.0 * rows * c * k, lib.wm_conv2d_dgrad, ptr(dout), ptr(crsk), ptr(dx), rows, 1, 1,
+                           c, k, 1, 1, 1, 1, 1, 0, stream_ptr()), "wm_conv2d_dgrad(linear)")
         want_b = bias is not None and bias.requires_grad
         if ctx.needs_input_grad[1] or want_b:
             db = None
@@ -161,8 +162,8 @@ class _LinearBias(torch.autograd.Function):
                 db, db_ret = _grad_target(bias)
             slot = _arena_grad(weight)
             tgt = slot if slot is not None else torch.zeros((k, c), dtype=torch.float32, device=dout.device)
-            check(lib.wm_conv2d_wgrad_bias(ptr(dout), ptr(x), ptr(tgt), ptr(db), rows, 1, 1, c, k, 1, 1, 1, 1, 1, 0,
-                                           stream_ptr()), "wm_conv2d_wgrad_bias(linear)")
+            check(ops._run("gemm_wgrad", 2.0 * rows * c * k, lib.wm_conv2d_wgrad_bias, ptr(dout), ptr(x), ptr(tgt), ptr(db),
+                           rows, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()), "wm_conv2d_wgrad_bias(linear)")
             dw = None if slot is not None else tgt
         return dx, dw, db_ret, (dout if ctx.has_res else None)
 
@@ -187,8 +188,8 @@ class _Attention(torch.autograd.Function):
             raise ValueError(f"attention: qkv {tuple(qkv.shape)} vs B={b} S={s} H={h} head_dim={hd}")
         out = torch.empty((b * s, h * hd), dtype=torch.bfloat16, device=qkv.device)
         lse = torch.empty((b, h, s), dtype=torch.float32, device=qkv.device)
-        check(_lib.load().wm_attention_fwd(ptr(qkv), b, s, h, hd, scale, ptr(out), ptr(lse), stream_ptr()),
-              "wm_attention_fwd")
+        check(ops._run("attn_fwd", 4.0 * b * h * s * s * hd, _lib.load().wm_attention_fwd, ptr(qkv), b, s, h, hd, scale,
+                       ptr(out), ptr(lse), stream_ptr()), "wm_attention_fwd")
         ctx.save_for_backward(qkv, out, lse)
         ctx.geom = (b, s, h, hd, scale)
         return out
@@ -199,8 +200,8 @@ class _Attention(torch.autograd.Function):
         b, s, h, hd, scale = ctx.geom
         dout = _bf16_rows(dout)
         dqkv = torch.empty_like(qkv)
-        check(_lib.load().wm_attention_bwd(ptr(qkv), ptr(out), ptr(dout), ptr(lse), b, s, h, hd, scale, ptr(dqkv),
-                                           stream_ptr()), "wm_attention_bwd")
+        check(ops._run("attn_bwd", 8.0 * b * h * s * s * hd, _lib.load().wm_attention_bwd, ptr(qkv), ptr(out), ptr(dout),
+                       ptr(lse), b, s, h, hd, scale, ptr(dqkv), stream_ptr()), "wm_attention_bwd")
         return dqkv, None, None, None, None, None
 
 

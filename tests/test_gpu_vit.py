@@ -315,18 +315,33 @@ def test_dino_head_matches_oracle_with_per_view_batchnorm():
         _close(got, ref, rel=4e-2, what=f"dino head bn={bn}")
 
 
-def test_dino_training_step_matches_oracle_and_learns():
+@pytest.mark.parametrize("preset", ["vit_small_2blocks", "vit_tiny"])
+def test_dino_training_step_matches_oracle_and_learns(preset):
     """Whole step on identical weights: teacher EMA -> teacher fwd -> student fwd on 2 global + 2 local
-    crops -> DINO loss -> backward -> AdamW.  A 2-block ViT keeps the CPU-free oracle quick."""
+    crops -> DINO loss -> backward -> AdamW.  "vit_small_2blocks": the reference's ViT-S/16 cut to 2 blocks (keeps
+    the oracle quick); "vit_tiny": BASELINE.json configs[2] at full depth (DINOViT(backbone="vit_tiny"): 192-d,
+    3 heads, 12 blocks; reference scripts/WM811k_benchmark.py:545-602, :668-669)."""
     from oracle import vit as ov
     from ssl_wafermap_amd import ops
     from ssl_wafermap_amd.models import DINOViT
     from ssl_wafermap_amd.models.vit import VisionTransformer
 
     torch.manual_seed(0)
-    model = DINOViT(None, 9, batch_size=8, max_epochs=10, log_rep_std=False)
-    model.backbone = VisionTransformer(patch_size=16, embed_dim=384, depth=2, num_heads=6)
-    model.teacher_backbone = copy.deepcopy(model.backbone)
+    if preset == "vit_tiny":
+        model = DINOViT(None, 9, batch_size=8, max_epochs=10, log_rep_std=False, backbone="vit_tiny")
+        assert model.backbone.embed_dim == 192 and len(model.backbone.blocks) == 12
+        assert model.head.layers[0].in_features == 192
+        with torch.no_grad():  # break the symmetry of the zero biases / unit LayerNorms
+            for p_ in model.backbone.parameters():
+                if p_.dim() == 1:
+                    p_.add_(torch.randn_like(p_) * 0.05)
+        model.teacher_backbone = copy.deepcopy(model.backbone)
+        nh = 3
+    else:
+        model = DINOViT(None, 9, batch_size=8, max_epochs=10, log_rep_std=False)
+        model.backbone = VisionTransformer(patch_size=16, embed_dim=384, depth=2, num_heads=6)
+        model.teacher_backbone = copy.deepcopy(model.backbone)
+        nh = 6
     for p_ in model.teacher_backbone.parameters():
         p_.requires_grad = False
     model = model.to(DEV).train()
@@ -348,8 +363,8 @@ def test_dino_training_step_matches_oracle_and_learns():
                        {k: v for k, v in t_hd.items() if v.is_floating_point() and "running" not in k and "num_batches" not in k}, 0.99)
     vd = [v.to(DEV) for v in views]
     with torch.no_grad():
-        t_out = [ov.dino_head(ov.vit_features(v, t_bb, 6), t_hd, training=True) for v in vd[:2]]
-    s_out = [ov.dino_head(ov.vit_features(v, s_bb, 6), s_hd, training=True) for v in vd]
+        t_out = [ov.dino_head(ov.vit_features(v, t_bb, nh), t_hd, training=True) for v in vd[:2]]
+    s_out = [ov.dino_head(ov.vit_features(v, s_bb, nh), s_hd, training=True) for v in vd]
     ref_loss, _ = ov.dino_loss(t_out, s_out, torch.zeros(1, 1, 2048, device=DEV), 0.04, 0.1)
     ref_loss.backward()
 
@@ -374,8 +389,10 @@ def test_dino_training_step_matches_oracle_and_learns():
     assert len(cos) >= len(pairs) - 4
     worst = min(cos)
     med = float(np.median([c for c, _ in cos]))
-    # bf16 activations + bf16 probabilities in attention against a float32 oracle
-    assert worst[0] > 0.9 and med > 0.98, (worst, med)
+    # bf16 activations + bf16 probabilities in attention against a float32 oracle; the rounding noise of the
+    # activation gradients accumulates with depth (12 blocks of ViT-Tiny: median 0.96, worst 0.94 measured)
+    lo_worst, lo_med = (0.85, 0.94) if preset == "vit_tiny" else (0.9, 0.98)
+    assert worst[0] > lo_worst and med > lo_med, (worst, med)
     # teacher moved by the EMA
     got_t = dict(model.teacher_backbone.state_dict())
     for k in ("blocks.0.attn.qkv.weight", "pos_embed", "norm.bias"):
@@ -392,9 +409,12 @@ def test_dino_training_step_matches_oracle_and_learns():
     assert math.isfinite(float(loss)) and float(loss) < first, (first, float(loss))
 
 
-def test_mae_training_step_matches_oracle_and_learns():
-    """MAE step (2-block ViT-B/32 encoder to keep it quick, the reference's 1-block 512/16 decoder) on
-    identical weights and token masks: loss, gradients, and a falling loss under AdamW."""
+@pytest.mark.parametrize("preset", ["vit_b_32_2blocks", "vit_small_16"])
+def test_mae_training_step_matches_oracle_and_learns(preset):
+    """MAE step on identical weights and token masks: loss, gradients, and a falling loss under AdamW.
+    "vit_b_32_2blocks": the reference's ViT-B/32 encoder cut to 2 blocks; "vit_small_16": BASELINE.json configs[3]
+    at full depth (MAE(backbone="vit_small_16"): 197 tokens, 49 kept, 768 values per masked patch; reference step
+    scripts/MixedWM38_pretrain.py:257-340).  The decoder is the reference's 1-block 512/16 one in both."""
     from oracle import vit as ov
     from ssl_wafermap_amd import ops
     from ssl_wafermap_amd.models import MAE
@@ -402,8 +422,15 @@ def test_mae_training_step_matches_oracle_and_learns():
     from ssl_wafermap_amd.utils import random_token_mask
 
     torch.manual_seed(0)
-    model = MAE(None, 9, batch_size=8, log_rep_std=False)
-    model.backbone = MAEBackbone(224, 32, 2, 12, 768, 3072)
+    if preset == "vit_small_16":
+        model = MAE(None, 9, batch_size=8, log_rep_std=False, backbone="vit_small_16")
+        assert model.sequence_length == 197 and model.patch_size == 16 and model.backbone.hidden_dim == 384
+        assert model.decoder.decoder_pred.out_features == 768
+        seq, ps, enc_heads, pdim = 197, 16, 6, 768
+    else:
+        model = MAE(None, 9, batch_size=8, log_rep_std=False)
+        model.backbone = MAEBackbone(224, 32, 2, 12, 768, 3072)
+        seq, ps, enc_heads, pdim = 50, 32, 12, 3072
     with torch.no_grad():
         model.mask_token.normal_(std=0.02)
         for p_ in model.parameters():
@@ -413,19 +440,20 @@ def test_mae_training_step_matches_oracle_and_learns():
     b = 8
     g = torch.Generator().manual_seed(4)
     images = _bf(torch.randn(b, 3, 224, 224, generator=g)).to(DEV)
-    keep, mask = random_token_mask((b, 50), 0.75, generator=g)
+    keep, mask = random_token_mask((b, seq), 0.75, generator=g)
+    assert keep.shape[1] == int(seq * 0.25)
     keep, mask = keep.to(DEV), mask.to(DEV)
     sd = {k: v.detach().clone().float().requires_grad_(True) for k, v in model.state_dict().items()}
-    ref = ov.mae_loss(images, sd, keep, mask)
+    ref = ov.mae_loss(images, sd, keep, mask, enc_heads=enc_heads)
     ref.backward()
 
     x_enc = model.forward_encoder(ops.to_nhwc_bf16(images), keep)
     pred = model.forward_decoder(x_enc, keep, mask)
     from ssl_wafermap_amd.utils import get_at_index, patchify
 
-    target = get_at_index(patchify(ops.to_nhwc_bf16(images), 32), mask - 1)
-    torch.testing.assert_close(target.float(), torch.gather(ov.lightly_patchify(images, 32), 1,
-                                                             (mask - 1).unsqueeze(-1).expand(-1, -1, 3072)))
+    target = get_at_index(patchify(ops.to_nhwc_bf16(images), ps), mask - 1)
+    torch.testing.assert_close(target.float(), torch.gather(ov.lightly_patchify(images, ps), 1,
+                                                             (mask - 1).unsqueeze(-1).expand(-1, -1, pdim)))
     loss = model.criterion(pred, target)
     loss.backward()
     assert abs(float(loss.detach()) - float(ref.detach())) <= 5e-3 * abs(float(ref.detach())), (float(loss), float(ref))
