@@ -103,3 +103,29 @@ class WaferLoader:
                 mine = glob[self.rank * self.batch_size:(self.rank + 1) * self.batch_size]
             rng = np.random.default_rng([self.seed, self.epoch, b, self.rank])
             yield mine, rng
+
+
+class WaferCollateLoader:
+    """DataLoader(dataset, batch_size, shuffle, collate_fn=..., drop_last) as scripts/MixedWM38_pretrain.py:117-135
+    builds it: the dataset carries NO transform, the collate function (transforms/collate.py: Wafer*CollateFunction)
+    turns a list of (image, label, filename) items into `(views, labels, fnames)`.  Items here are (store index,
+    label, "index"): the images live in the GPU-resident store the collate function is bound to."""
+
+    def __init__(self, dataset: WaferMapDataset, batch_size: int, collate_fn, shuffle: bool = False,
+                 drop_last: bool = False, seed: int = 0, rank: int = 0, world_size: int = 1, fmt: str = "nhwc_bf16"):
+        self.dataset, self.collate_fn = dataset, collate_fn
+        self._index = WaferLoader(dataset, batch_size, shuffle=shuffle, drop_last=drop_last, seed=seed, rank=rank,
+                                  world_size=world_size, fmt=fmt)
+        self.batch_size, self.drop_last, self.fmt = int(batch_size), drop_last, fmt
+        self._labels = dataset.y.cpu().numpy()
+
+    def set_epoch(self, epoch: int):
+        self._index.set_epoch(epoch)
+
+    def __len__(self):
+        return len(self._index)
+
+    def __iter__(self):
+        for mine, rng in self._index.iter_indices():
+            self.collate_fn.bind(self.dataset.store, rng, fmt=self.fmt)
+            yield self.collate_fn([(int(i), self._labels[i], str(int(i))) for i in mine])

@@ -10,6 +10,7 @@ Inputs (reference checkout)                                        -> fixture (a
       (the file the reference's dummy mode trains on: scripts/WM811k_benchmark.py:87-97)
   data/interim/model_preds/SimSiam_preds_subset.pkl.xz  12 449 x 512 float16 backbone features of the SAME wafers
       (row order and failureCode identical to train_20_split) + failureCode  -> simsiam_preds_subset.npz
+  data/processed/MixedWM38/train_1_split.pkl.xz  381 maps (52 x 52) + failureType codes + 8-bit labels -> mixedwm38_train_1_split.npz
   data/interim/model_logs/{loss,rep_std,accuracy,f1}/run-SimCLR-tag-*.csv  the reference's own SimCLR curves
       (Step, Value columns)                                                  -> simclr_reference_curves.npz
 
@@ -47,7 +48,22 @@ def wafers(name):
     return df
 
 
+def mixed(name):
+    """MixedWM38 split: 52 x 52 maps + the 8-bit multi-label vector; `failureType` strings factorised as the
+    reference does for its (unused) SSL labels (scripts/MixedWM38_pretrain.py:89-91)."""
+    df = pd.read_pickle(REF / "data/processed/MixedWM38" / f"{name}.pkl.xz")
+    maps = [np.ascontiguousarray(w, dtype=np.uint8) for w in df.waferMap]
+    h = np.array([m.shape[0] for m in maps], dtype=np.int32)
+    w = np.array([m.shape[1] for m in maps], dtype=np.int32)
+    sizes = h.astype(np.int64) * w
+    save_npz_lzma(OUT / f"mixedwm38_{name}.npz", bytes=np.concatenate([m.reshape(-1) for m in maps]),
+                  offsets=np.concatenate([[0], np.cumsum(sizes)[:-1]]).astype(np.int64), heights=h, widths=w,
+                  labels=df.failureType.factorize(sort=True)[0].astype(np.int64),
+                  multilabel=np.stack([np.asarray(v) for v in df.label]).astype(np.int8))
+
+
 def main():
+    mixed("train_1_split")
     wafers("train_1_split")
     t20 = wafers("train_20_split")
     preds = pd.read_pickle(REF / "data/interim/model_preds/SimSiam_preds_subset.pkl.xz")

@@ -119,3 +119,24 @@ def test_simclr_on_the_reference_wafers_lands_in_the_reference_bands(tmp_path):
     assert (tmp_path / "SimCLR" / "results.csv").exists() and (tmp_path / "SimCLR" / "confusion_matrix.npz").exists()
     cm = np.load(tmp_path / "SimCLR" / "confusion_matrix.npz")["confusion_matrix"]
     assert cm.shape == (1, 9, 9)
+
+
+def test_mixedwm38_pretrain_driver_runs_on_the_reference_maps(tmp_path):
+    """The ported MixedWM38 pre-training driver (reference scripts/MixedWM38_pretrain.py:566-654) on the 381 real
+    52 x 52 maps of the reference's train_1_split: the collate-function loaders (denoise=True -> the 3 x 3 median
+    path), MAE at BASELINE configs[3] (ViT-S/16) and the BN-free DINOViT, a few steps each, results.csv written."""
+    import sys
+
+    sys.path.insert(0, str(GOLDEN.parent.parent / "scripts"))
+    import mixedwm38_pretrain_amd as drv
+    import pandas as pd
+
+    res = drv.main(["--models", "MAE,DCLW,DINOViT", "--max-epochs", "1", "--batch-size", "32", "--limit-train-batches", "4",
+                    "--mae-backbone", "vit_small_16", "--out", str(tmp_path), "--log-every", "1"])
+    for name in ("MAE", "DCLW", "DINOViT"):
+        run = res[name][0]
+        assert np.isfinite(run["final_train_loss_ssl"]), (name, run)
+        assert (tmp_path / name / "results.csv").exists()
+        log = pd.read_csv(tmp_path / name / "loss_log.csv")
+        assert len(log) == 4 and np.isfinite(log.loss).all()
+    assert 21.0 < res["MAE"][0]["params"] < 30.0      # ViT-S/16 encoder 21.7 M + 512-d decoder
