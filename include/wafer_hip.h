@@ -221,6 +221,23 @@ int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_krsc, float* d
 /* f32 OIHW master weights -> bf16 [K][R][S][C] and/or [C][R][S][K] (either may be NULL). */
 int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int S, void* w_krsc, void* w_crsk,
                        void* stream);
+/* Batched forms of the two layout passes: one launch for every convolution / Linear parameter of a model.
+ * descs (DEVICE, n_desc entries, tile0 ascending): w = f32 OIHW master weights [K][C][RS]; krsc / crsk = bf16
+ * [K][RS][C] / [C][RS][K] kernel layouts (either may be NULL); ws = f32 [K][RS][C] weight-gradient accumulator and
+ * grad = f32 OIHW gradient (wm_wgrad_fold: grad += ws, ws cleared); RS = R*S in {1, 9}; tiles_c = ceil(C / 32);
+ * tile0 = index of the parameter's first 32 x 32 (k, c) tile in the launch; total_tiles = sum over parameters of
+ * ceil(K / 32) * tiles_c.  Replaces 24-100 wm_weights_prepare / 19 wm_wgrad_finalize launches per training step. */
+typedef struct WmLayoutDesc {
+  const float* w;
+  uint16_t* krsc;
+  uint16_t* crsk;
+  float* ws;
+  float* grad;
+  int32_t K, C, RS, tiles_c, tile0, reserved;
+} WmLayoutDesc; /* 64 bytes */
+int wm_layouts_refresh(const WmLayoutDesc* descs_dev, int n_desc, int total_tiles, void* stream);
+int wm_wgrad_fold(const WmLayoutDesc* descs_dev, int n_desc, int total_tiles, void* stream);
+
 /* wgrad accumulator [K][R][S][C] f32 -> OIHW gradient (= or +=); the accumulator is cleared as it
  * is read, so a persistent one needs zeroing only once. */
 int wm_wgrad_finalize(float* dw_krsc, int K, int C, int R, int S, float* grad_oihw,

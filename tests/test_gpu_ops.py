@@ -446,3 +446,39 @@ def test_zz_report_measured_errors():
     with open("gpurun_out/ops_rms_errors.txt", "w") as fh:
         for k, (r, c) in sorted(worst.items()):
             fh.write(f"{k:32s} rel RMS {r:.3e}   1-cos {c:.3e}\n")
+
+
+def test_batched_layout_refresh_and_wgrad_fold_match_the_per_parameter_kernels():
+    """wm_layouts_refresh / wm_wgrad_fold (one launch over a descriptor table, 32 x 32 tiles through LDS) against
+    wm_weights_prepare / wm_wgrad_finalize parameter by parameter: bit-identical, ragged shapes included."""
+    import numpy as np
+
+    from ssl_wafermap_amd import _lib, ops
+    from ssl_wafermap_amd._lib import check, ptr, stream_ptr
+
+    lib = _lib.load()
+    g = torch.Generator().manual_seed(0)
+    shapes = [(64, 64, 3, 3), (128, 64, 1, 1), (512, 256, 3, 3), (192, 576, 1, 1), (40, 72, 3, 3), (33, 31, 1, 1)]
+    rows, refs = [], []
+    keep = []
+    for (k, c, r, s) in shapes:
+        w = torch.randn(k, c, r, s, generator=g).to(DEV)
+        krsc = torch.zeros(k, r, s, c, dtype=torch.bfloat16, device=DEV)
+        crsk = torch.zeros(c, r, s, k, dtype=torch.bfloat16, device=DEV)
+        rk, rc = torch.empty_like(krsc), torch.empty_like(crsk)
+        check(lib.wm_weights_prepare(ptr(w), k, c, r, s, ptr(rk), ptr(rc), stream_ptr()), "prepare")
+        ws = torch.randn(k, r, s, c, generator=g).to(DEV)
+        grad = torch.randn(k, c, r, s, generator=g).to(DEV)
+        ws2, grad2 = ws.clone(), grad.clone()
+        check(lib.wm_wgrad_finalize(ptr(ws2), k, c, r, s, ptr(grad2), 1, stream_ptr()), "finalize")
+        rows.append((w.data_ptr(), krsc.data_ptr(), crsk.data_ptr(), ws.data_ptr(), grad.data_ptr(), k, c, r * s))
+        refs.append((krsc, crsk, rk, rc, ws, grad, ws2, grad2))
+        keep.append(w)
+    tab, n, tiles = ops._desc_table(tuple(rows), torch.device(DEV))
+    check(lib.wm_layouts_refresh(ptr(tab), n, tiles, stream_ptr()), "wm_layouts_refresh")
+    check(lib.wm_wgrad_fold(ptr(tab), n, tiles, stream_ptr()), "wm_wgrad_fold")
+    torch.cuda.synchronize()
+    for (krsc, crsk, rk, rc, ws, grad, ws2, grad2), shp in zip(refs, shapes):
+        assert torch.equal(krsc, rk) and torch.equal(crsk, rc), shp
+        assert torch.equal(grad, grad2), shp
+        assert float(ws.abs().max()) == 0.0 and float(ws2.abs().max()) == 0.0
