@@ -218,6 +218,18 @@ int wm_conv2d_fwd_bias_res(const void* x, const void* w_krsc, const float* bias,
 int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_krsc, float* dbias, int N, int H, int W, int C,
                          int K, int R, int S, int P, int Q, int stride, int pad, void* stream);
 
+/* The two Linear layers around a GELU (ViT MLP: dino vision_transformer.py Mlp, torchvision MLPBlock; reference
+ * call sites scripts/WM811k_benchmark.py:548-550, :881-899) with the activation inside the GEMM epilogues:
+ *   wm_linear_bias_gelu_fwd: pre = x W^T + bias -> pre_out [rows][K] bf16 (kept for the backward pass),
+ *                            gelu(pre) -> y [rows][K]            (x [rows][C], w_krsc [K][C] bf16, bias [K] f32)
+ *   wm_linear_dgrad_gelu:    dx = (dy W) * gelu'(pre)            (dy [rows][K], w_crsk [C][K] bf16; pre, dx [rows][C])
+ * i.e. the input gradient of the layer that FOLLOWS the activation, already taken through the activation.
+ * Replaces a separate bias + GELU pass (forward) and a GELU-gradient + column-sum pass (backward). */
+int wm_linear_bias_gelu_fwd(const void* x, const void* w_krsc, const float* bias, void* pre_out, void* y, int rows,
+                            int C, int K, void* stream);
+int wm_linear_dgrad_gelu(const void* dy, const void* w_crsk, const void* pre, void* dx, int rows, int C, int K,
+                         void* stream);
+
 /* f32 OIHW master weights -> bf16 [K][R][S][C] and/or [C][R][S][K] (either may be NULL). */
 int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int S, void* w_krsc, void* w_crsk,
                        void* stream);

@@ -59,7 +59,18 @@ struct ConvArgs {
   const uint16_t* res;
   // optional per-output-channel bias added in the epilogue (forward only: Linear layers)
   const float* bias;
+  // optional activation in the EPI epilogue (ViT MLP): act 1 = forward GELU: the biased pre-activation goes to
+  // pre_out (saved for the backward pass) and gelu(pre) to dst; act 2 = dgrad: result *= gelu'(pre_in) (the
+  // gradient through the activation that follows the layer whose input gradient this is)
+  const uint16_t* pre_in;
+  uint16_t* pre_out;
+  int act;
 };
+
+__device__ __forceinline__ float cv_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
+__device__ __forceinline__ float cv_gelu_grad(float v) {
+  return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
+}
 
 // 128 zero bytes: the global_load_lds source of padded / out-of-range taps
 __device__ __attribute__((aligned(256))) uint16_t conv_zero_page[128];
@@ -326,6 +337,8 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
       // far as the compiler knows, so it would not hoist them itself)
       rv[it] = make_uint4(0, 0, 0, 0);
       if (a.res != nullptr && m0 + row < a.M) rv[it] = *reinterpret_cast<const uint4*>(a.res + pix * a.DC + n0 + ch * 8);
+      // (act 2 never comes with a residual: the same registers carry the pre-activation chunk)
+      if (a.act == 2 && m0 + row < a.M) rv[it] = *reinterpret_cast<const uint4*>(a.pre_in + pix * a.DC + n0 + ch * 8);
     }
   #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -344,7 +357,24 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
                            pack_bf2(bf2f((uint16_t)(v.w & 0xffff)) + b1.z, bf2f((uint16_t)(v.w >> 16)) + b1.w));
           }
         }
-        if (a.res != nullptr) {
+        if (a.act == 1) {  // v = biased pre-activation (bf16): keep it for the backward pass, emit gelu(v)
+          *reinterpret_cast<uint4*>(a.pre_out + pix * a.DC + n0 + ch * 8) = v;
+          const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+          uint32_t o[4];
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] = pack_bf2(cv_gelu(bf2f((uint16_t)(vv[e] & 0xffff))), cv_gelu(bf2f((uint16_t)(vv[e] >> 16))));
+          v = make_uint4(o[0], o[1], o[2], o[3]);
+        } else if (a.act == 2) {  // v = gradient w.r.t. gelu(pre): times gelu'(pre)
+          const uint4 r4 = rv[it];
+          const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
+          uint32_t o[4];
+  #pragma unroll
+          for (int e = 0; e < 4; ++e)
+            o[e] = pack_bf2(bf2f((uint16_t)(vv[e] & 0xffff)) * cv_gelu_grad(bf2f((uint16_t)(rr[e] & 0xffff))),
+                            bf2f((uint16_t)(vv[e] >> 16)) * cv_gelu_grad(bf2f((uint16_t)(rr[e] >> 16))));
+          v = make_uint4(o[0], o[1], o[2], o[3]);
+        } else if (a.res != nullptr) {
           const uint4 r4 = rv[it];
           const uint32_t vv[4] = {v.x, v.y, v.z, v.w}, rr[4] = {r4.x, r4.y, r4.z, r4.w};
           uint32_t o[4];
@@ -921,7 +951,8 @@ static int conv_check(int N, int H, int W, int C, int K, int R, int S, int P, in
 
 static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int R,
                          int S, int P, int Q, int stride, int pad, float* stat, int stat_nb, int stat_rpg,
-                         void* stream, const float* bias = nullptr, const void* residual = nullptr);
+                         void* stream, const float* bias = nullptr, const void* residual = nullptr,
+                         void* pre_out = nullptr);
 
 extern "C" int wm_conv2d_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C,
                              int K, int R, int S, int P, int Q, int stride, int pad, void* stream) {
@@ -946,7 +977,8 @@ extern "C" int wm_conv2d_fwd_stats(const void* x, const void* w_krsc, void* y, i
 
 static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int R,
                          int S, int P, int Q, int stride, int pad, float* stat, int stat_nb, int stat_rpg,
-                         void* stream, const float* bias, const void* residual) {
+                         void* stream, const float* bias, const void* residual, void* pre_out) {
+  WM_REQUIRE(pre_out == nullptr || (residual == nullptr && R == 1 && S == 1), WM_EUNSUPPORTED);
   WM_REQUIRE(x && w_krsc && y, WM_EINVAL);
   const int rc = conv_check(N, H, W, C, K, R, S, P, Q, stride, pad);
   if (rc != WM_OK) return rc;
@@ -960,6 +992,9 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   a.stat = stat; a.stat_nb = stat_nb; a.stat_rpg = stat_rpg;
   a.res = static_cast<const uint16_t*>(residual);
   a.bias = bias;
+  a.pre_in = nullptr;
+  a.pre_out = static_cast<uint16_t*>(pre_out);
+  a.act = pre_out != nullptr ? 1 : 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (C == 16) {
     WM_REQUIRE(bias == nullptr && residual == nullptr, WM_EUNSUPPORTED);
@@ -970,13 +1005,31 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   }
   a.nkt = R * S * (C / 64);
   if (residual == nullptr && conv_patch_ok(a)) return launch_patch<0>(a, st);
-  if (bias != nullptr || residual != nullptr)
+  if (bias != nullptr || residual != nullptr || pre_out != nullptr)
     return K % 128 == 0 ? launch_igemm<128, 128, 8, 0, true>(a, st) : launch_igemm<128, 64, 8, 0, true>(a, st);
   return K % 128 == 0 ? launch_igemm<128, 128, 8, 0>(a, st) : launch_igemm<128, 64, 8, 0>(a, st);
 }
 
 static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const void* residual, int N, int H,
-                           int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, void* stream);
+                           int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, void* stream,
+                           const void* pre_in = nullptr);
+
+// Linear + bias + GELU in one launch (ViT MLP fc1): pre = x W^T + bias -> pre_out (bf16, saved for the backward
+// pass), gelu(pre) -> y.
+extern "C" int wm_linear_bias_gelu_fwd(const void* x, const void* w_krsc, const float* bias, void* pre_out, void* y,
+                                       int rows, int C, int K, void* stream) {
+  WM_REQUIRE(pre_out && bias, WM_EINVAL);
+  WM_REQUIRE((reinterpret_cast<uintptr_t>(bias) & 15) == 0 && (reinterpret_cast<uintptr_t>(pre_out) & 15) == 0, WM_EALIGN);
+  return conv_fwd_impl(x, w_krsc, y, rows, 1, 1, C, K, 1, 1, 1, 1, 1, 0, nullptr, 0, 0, stream, bias, nullptr, pre_out);
+}
+
+// Input gradient of a Linear whose INPUT was gelu(pre): dx = (dy W) * gelu'(pre)  (ViT MLP fc2 backward): the
+// activation's backward pass rides in the dgrad epilogue.  dy [rows][K], w_crsk [C][K], pre / dx [rows][C].
+extern "C" int wm_linear_dgrad_gelu(const void* dy, const void* w_crsk, const void* pre, void* dx, int rows, int C,
+                                    int K, void* stream) {
+  WM_REQUIRE(pre, WM_EINVAL);
+  return conv_dgrad_impl(dy, w_crsk, dx, nullptr, rows, 1, 1, C, K, 1, 1, 1, 1, 1, 0, stream, pre);
+}
 
 extern "C" int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W,
                                int C, int K, int R, int S, int P, int Q, int stride, int pad,
@@ -993,8 +1046,10 @@ extern "C" int wm_conv2d_dgrad_add(const void* dy, const void* w_crsk, const voi
 }
 
 static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const void* residual, int N, int H,
-                           int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, void* stream) {
+                           int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, void* stream,
+                           const void* pre_in) {
   WM_REQUIRE(dy && w_crsk && dx, WM_EINVAL);
+  WM_REQUIRE(pre_in == nullptr || (residual == nullptr && R == 1 && S == 1 && stride == 1 && aligned16(pre_in)), WM_EUNSUPPORTED);
   const int rc = conv_check(N, H, W, C, K, R, S, P, Q, stride, pad);
   if (rc != WM_OK) return rc;
   WM_REQUIRE(C % 64 == 0, WM_EUNSUPPORTED);  // the stem needs no input gradient
@@ -1010,6 +1065,11 @@ static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const v
   a.nkt = R * S * (K / 64);
   hipStream_t st = static_cast<hipStream_t>(stream);
   a.bias = nullptr;
+  a.pre_in = static_cast<const uint16_t*>(pre_in);
+  a.pre_out = nullptr;
+  a.act = pre_in != nullptr ? 2 : 0;
+  if (pre_in != nullptr)
+    return C % 128 == 0 ? launch_igemm<128, 128, 8, 3, true>(a, st) : launch_igemm<128, 64, 8, 3, true>(a, st);
   if (conv_patch_ok(a)) return launch_patch<1>(a, st);
   // stride 2 with even image sides and class size % 128 == 0: parity-class ordering (no wasted taps)
   const long long cls = (long long)N * (H / 2) * (W / 2);

@@ -142,35 +142,64 @@ __device__ __forceinline__ int lb_find(const WmLayoutDesc* __restrict__ d, int n
   return lo;
 }
 
+template <int RS>
+__device__ __forceinline__ void refresh_tile(const WmLayoutDesc& d, int k0, int c0, uint16_t (*tile)[LB_T][LB_T + 2]) {
+  const int K = d.K, C = d.C;
+  const int nk = min(LB_T, K - k0), nc = min(LB_T, C - c0);
+  // load: for each k row the (c, rs) block is nc * RS contiguous floats of the OIHW tensor; 8 rows per pass
+  // (thread = (row in pass, position in row): no division by a run-time value anywhere)
+  const int rowl = threadIdx.x >> 5, pos = threadIdx.x & 31;
+  for (int k = rowl; k < nk; k += LT_THREADS / 32) {
+    const float* src = d.w + ((size_t)(k0 + k) * C + c0) * RS;
+    for (int j = pos; j < nc * RS; j += 32) {
+      const int c = j / RS, rs = j - c * RS;  // RS is a compile-time constant
+      tile[rs][k][c] = f2bf(src[j]);
+    }
+  }
+  __syncthreads();
+  if (d.krsc != nullptr) {  // [K][RS][C]: runs of nc channels
+    for (int u = rowl; u < nk * RS; u += LT_THREADS / 32) {
+      const int k = u / RS, rs = u - k * RS;
+      if (pos < nc) d.krsc[((size_t)(k0 + k) * RS + rs) * C + c0 + pos] = tile[rs][k][pos];
+    }
+  }
+  if (d.crsk != nullptr) {  // [C][RS][K]: runs of nk output channels
+    for (int u = rowl; u < nc * RS; u += LT_THREADS / 32) {
+      const int c = u / RS, rs = u - c * RS;
+      if (pos < nk) d.crsk[((size_t)(c0 + c) * RS + rs) * K + k0 + pos] = tile[rs][pos][c];
+    }
+  }
+}
+
 __global__ __launch_bounds__(LT_THREADS) void layouts_refresh_batched(const WmLayoutDesc* __restrict__ descs, int n_desc) {
   __shared__ uint16_t tile[LB_MAX_RS][LB_T][LB_T + 2];  // [rs][k][c], +2: the transposed read walks k at fixed c
   const int di = lb_find(descs, n_desc, blockIdx.x);
   const WmLayoutDesc d = descs[di];
   const int t = blockIdx.x - d.tile0;
   const int tk = t / d.tiles_c, tc = t - tk * d.tiles_c;
-  const int k0 = tk * LB_T, c0 = tc * LB_T;
-  const int RS = d.RS, K = d.K, C = d.C;
+  if (d.RS == 9) refresh_tile<9>(d, tk * LB_T, tc * LB_T, tile);
+  else refresh_tile<1>(d, tk * LB_T, tc * LB_T, tile);
+}
+
+template <int RS>
+__device__ __forceinline__ void fold_tile(const WmLayoutDesc& d, int k0, int c0, float (*tile)[LB_T][LB_T + 1]) {
+  const int K = d.K, C = d.C;
   const int nk = min(LB_T, K - k0), nc = min(LB_T, C - c0);
-  // load: for each k row the (c, rs) block is nc * RS contiguous floats of the OIHW tensor
-  const int row_elems = nc * RS;
-  for (int i = threadIdx.x; i < nk * row_elems; i += LT_THREADS) {
-    const int k = i / row_elems, j = i - k * row_elems;
-    const int c = j / RS, rs = j - c * RS;
-    tile[rs][k][c] = f2bf(d.w[((size_t)(k0 + k) * C + c0) * RS + j]);
-  }
-  __syncthreads();
-  if (d.krsc != nullptr) {  // [K][RS][C]: runs of nc channels
-    for (int i = threadIdx.x; i < nk * RS * nc; i += LT_THREADS) {
-      const int c = i % nc, u = i / nc;
-      const int rs = u % RS, k = u / RS;
-      d.krsc[((size_t)(k0 + k) * RS + rs) * C + c0 + c] = tile[rs][k][c];
+  const int rowl = threadIdx.x >> 5, pos = threadIdx.x & 31;
+  for (int u = rowl; u < nk * RS; u += LT_THREADS / 32) {
+    const int k = u / RS, rs = u - k * RS;
+    if (pos < nc) {
+      float* src = d.ws + ((size_t)(k0 + k) * RS + rs) * C + c0 + pos;
+      tile[rs][k][pos] = *src;
+      *src = 0.f;
     }
   }
-  if (d.crsk != nullptr) {  // [C][RS][K]: runs of nk output channels
-    for (int i = threadIdx.x; i < nc * RS * nk; i += LT_THREADS) {
-      const int k = i % nk, u = i / nk;
-      const int rs = u % RS, c = u / RS;
-      d.crsk[((size_t)(c0 + c) * RS + rs) * K + k0 + k] = tile[rs][k][c];
+  __syncthreads();
+  for (int k = rowl; k < nk; k += LT_THREADS / 32) {
+    float* g = d.grad + ((size_t)(k0 + k) * C + c0) * RS;
+    for (int j = pos; j < nc * RS; j += 32) {
+      const int c = j / RS, rs = j - c * RS;
+      g[j] += tile[rs][k][c];
     }
   }
 }
@@ -182,24 +211,8 @@ __global__ __launch_bounds__(LT_THREADS) void wgrad_fold_batched(const WmLayoutD
   const WmLayoutDesc d = descs[di];
   const int t = blockIdx.x - d.tile0;
   const int tk = t / d.tiles_c, tc = t - tk * d.tiles_c;
-  const int k0 = tk * LB_T, c0 = tc * LB_T;
-  const int RS = d.RS, K = d.K, C = d.C;
-  const int nk = min(LB_T, K - k0), nc = min(LB_T, C - c0);
-  for (int i = threadIdx.x; i < nk * RS * nc; i += LT_THREADS) {
-    const int c = i % nc, u = i / nc;
-    const int rs = u % RS, k = u / RS;
-    const size_t wi = ((size_t)(k0 + k) * RS + rs) * C + c0 + c;
-    tile[rs][k][c] = d.ws[wi];
-    d.ws[wi] = 0.f;
-  }
-  __syncthreads();
-  const int row_elems = nc * RS;
-  for (int i = threadIdx.x; i < nk * row_elems; i += LT_THREADS) {
-    const int k = i / row_elems, j = i - k * row_elems;
-    const int c = j / RS, rs = j - c * RS;
-    float* g = d.grad + ((size_t)(k0 + k) * C + c0) * RS + j;
-    *g += tile[rs][k][c];
-  }
+  if (d.RS == 9) fold_tile<9>(d, tk * LB_T, tc * LB_T, tile);
+  else fold_tile<1>(d, tk * LB_T, tc * LB_T, tile);
 }
 
 inline int grid_for(long long items) {

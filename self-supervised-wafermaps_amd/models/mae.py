@@ -69,8 +69,7 @@ class EncoderBlock(nn.Module):
 
     def forward(self, x, batch, seq):
         x = self.self_attention(self.ln_1(x), batch, seq, residual=x)
-        h = self.mlp[0](self.ln_2(x), act=vit_ops.ACT_GELU)
-        return self.mlp[3](h, residual=x)
+        return vit_ops.mlp_gelu(self.ln_2(x), self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight, self.mlp[3].bias, x)
 
 
 class _Encoder(nn.Module):

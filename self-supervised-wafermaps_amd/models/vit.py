@@ -43,7 +43,7 @@ class Mlp(nn.Module):
         self.fc2 = hnn.Linear(hidden, dim, bias=True)
 
     def forward(self, x, residual):
-        return self.fc2(self.fc1(x, act=vit_ops.ACT_GELU), residual=residual)
+        return vit_ops.mlp_gelu(x, self.fc1.weight, self.fc1.bias, self.fc2.weight, self.fc2.bias, residual)
 
 
 class Block(nn.Module):

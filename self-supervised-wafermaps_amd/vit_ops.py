@@ -179,6 +179,78 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return bias_act(y, bias, act, residual)
 
 
+class _MlpGelu(torch.autograd.Function):
+    """y = fc2(gelu(fc1(x))) (+ residual), four GEMM-shaped launches forward + backward each carrying the
+    element-wise work in its epilogue: fc1 + bias + GELU (pre-activation kept), fc2 + bias + residual; backward:
+    wgrad(+bias) of fc2, dgrad of fc2 x gelu'(pre), wgrad(+bias) of fc1, dgrad of fc1."""
+
+    @staticmethod
+    def forward(ctx, x, w1, b1, w2, b2, residual):
+        _need_cuda(x, "mlp")
+        x = _bf16_rows(x)
+        rows, c = x.shape
+        hid, out = w1.shape[0], w2.shape[0]
+        if w1.shape[1] != c or w2.shape[1] != hid or hid % 64 or out % 64 or c % 64:
+            raise ValueError(f"mlp: x {tuple(x.shape)}, fc1 {tuple(w1.shape)}, fc2 {tuple(w2.shape)}")
+        lib = _lib.load()
+        k1, _ = ops._WCACHE.get(w1, kind="linear", need_crsk=True)
+        k2, _ = ops._WCACHE.get(w2, kind="linear", need_crsk=True)
+        pre = torch.empty((rows, hid), dtype=torch.bfloat16, device=x.device)
+        h = torch.empty_like(pre)
+        check(ops._run("gemm_fwd", 2.0 * rows * c * hid, lib.wm_linear_bias_gelu_fwd, ptr(x), ptr(k1), ptr(b1), ptr(pre),
+                       ptr(h), rows, c, hid, stream_ptr()), "wm_linear_bias_gelu_fwd")
+        y = torch.empty((rows, out), dtype=torch.bfloat16, device=x.device)
+        if residual is not None:
+            residual = _bf16_rows(residual)
+        check(ops._run("gemm_fwd", 2.0 * rows * hid * out, lib.wm_conv2d_fwd_bias_res, ptr(h), ptr(k2), ptr(b2),
+                       ptr(residual), ptr(y), rows, 1, 1, hid, out, 1, 1, 1, 1, 1, 0, stream_ptr()),
+              "wm_conv2d_fwd_bias_res(fc2)")
+        ctx.save_for_backward(x, pre, h)
+        ctx.params = (w1, b1, w2, b2)
+        ctx.geom = (rows, c, hid, out)
+        ctx.has_res = residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, pre, h = ctx.saved_tensors
+        w1, b1, w2, b2 = ctx.params
+        rows, c, hid, out = ctx.geom
+        dy = _bf16_rows(dy)
+        lib = _lib.load()
+        rets = {}
+
+        def wgrad(dout, inp, w, b, kk, cc, tag):
+            db = db_ret = None
+            if b.requires_grad:
+                db, db_ret = _grad_target(b)
+            slot = _arena_grad(w)
+            tgt = slot if slot is not None else torch.zeros((kk, cc), dtype=torch.float32, device=dy.device)
+            check(ops._run("gemm_wgrad", 2.0 * rows * cc * kk, lib.wm_conv2d_wgrad_bias, ptr(dout), ptr(inp), ptr(tgt),
+                           ptr(db), rows, 1, 1, cc, kk, 1, 1, 1, 1, 1, 0, stream_ptr()), "wm_conv2d_wgrad_bias(mlp)")
+            rets[tag] = (None if slot is not None else tgt, db_ret)
+
+        wgrad(dy, h, w2, b2, out, hid, "fc2")
+        _, c2 = ops._WCACHE.get(w2, kind="linear", need_crsk=True)
+        dpre = torch.empty_like(pre)
+        check(ops._run("gemm_dgrad", 2.0 * rows * hid * out, lib.wm_linear_dgrad_gelu, ptr(dy), ptr(c2), ptr(pre),
+                       ptr(dpre), rows, hid, out, stream_ptr()), "wm_linear_dgrad_gelu")
+        wgrad(dpre, x, w1, b1, hid, c, "fc1")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            _, c1 = ops._WCACHE.get(w1, kind="linear", need_crsk=True)
+            dx = torch.empty((rows, c), dtype=torch.bfloat16, device=dy.device)
+            check(ops._run("gemm_dgrad", 2.0 * rows * c * hid, lib.wm_conv2d_dgrad, ptr(dpre), ptr(c1), ptr(dx), rows, 1, 1,
+                           c, hid, 1, 1, 1, 1, 1, 0, stream_ptr()), "wm_conv2d_dgrad(fc1)")
+        return dx, rets["fc1"][0], rets["fc1"][1], rets["fc2"][0], rets["fc2"][1], (dy if ctx.has_res else None)
+
+
+def mlp_gelu(x: torch.Tensor, fc1_weight: torch.Tensor, fc1_bias: torch.Tensor, fc2_weight: torch.Tensor,
+             fc2_bias: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """fc2(gelu(fc1(x))) (+ residual) on bf16 [rows, C] with biases: the transformer MLP block."""
+    return _MlpGelu.apply(x, fc1_weight, fc1_bias, fc2_weight, fc2_bias, residual)
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, b, s, h, hd, scale):

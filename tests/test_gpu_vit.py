@@ -550,3 +550,30 @@ def test_msn_training_step_runs_and_learns(name):
         opt.step()
         losses.append(float(loss.detach()))
     assert all(math.isfinite(v) for v in losses) and losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("rows,c,hid", [(25, 192, 768), (394, 384, 1536), (130, 768, 3072)])
+def test_fused_mlp_gelu_matches_torch(rows, c, hid):
+    """fc2(gelu(fc1(x))) + residual with GELU in the fc1 GEMM epilogue and gelu' in the fc2 dgrad epilogue
+    (wm_linear_bias_gelu_fwd / wm_linear_dgrad_gelu) against float32 torch: output, input gradient, both weight and
+    bias gradients."""
+    from ssl_wafermap_amd import vit_ops
+
+    g = torch.Generator().manual_seed(rows)
+    x = _bf(torch.randn(rows, c, generator=g))
+    res = _bf(torch.randn(rows, c, generator=g))
+    w1 = _bf(torch.randn(hid, c, generator=g) * c ** -0.5)
+    w2 = _bf(torch.randn(c, hid, generator=g) * hid ** -0.5)
+    b1, b2 = torch.randn(hid, generator=g) * 0.1, torch.randn(c, generator=g) * 0.1
+    dy = _bf(torch.randn(rows, c, generator=g))
+    ref_in = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2, res)]
+    pre = torch.nn.functional.linear(ref_in[0], ref_in[1], ref_in[2])
+    yr = torch.nn.functional.linear(torch.nn.functional.gelu(_bf(pre.detach()) + (pre - pre.detach())), ref_in[3], ref_in[4]) + ref_in[5]
+    yr.backward(dy)
+    dev_in = [t.to(DEV).requires_grad_(True) for t in (x.bfloat16(), w1, b1, w2, b2, res.bfloat16())]
+    yd = vit_ops.mlp_gelu(*dev_in)
+    yd.backward(dy.to(DEV).bfloat16())
+    _close(yd, yr.detach(), rel=1.5e-2, what="mlp out")
+    for name, a, b in zip(("dx", "dw1", "db1", "dw2", "db2", "dres"), dev_in, ref_in):
+        _close(a.grad, b.grad, rel=2.5e-2, what="mlp " + name)
+        assert _cos(a.grad, b.grad) > 0.999, name
