@@ -5,7 +5,7 @@
 // softmax -> @ v, as run by scripts/WM811k_benchmark.py:566-576) and torch.nn.MultiheadAttention
 // inside torchvision's vit_b_32 encoder blocks (MAE, :903-947), and their autograd backward.
 //
-// One block (8 waves) per (image, head).  Q, K, V (and dO in the backward) of the head sit in LDS as
+// One block (8 waves) per (image, head).  K, V (and Q, dO in the backward) of the head sit in LDS as
 // [token][64] bf16 rows padded to 144 B: a ds_read_b128 fragment read (16 rows x one 16-byte column)
 // then touches 16 distinct 4-bank groups.  A wave owns 16-row strips.
 //
@@ -61,6 +61,15 @@ __device__ __forceinline__ bf16x8_t pack_slots(const f32x4_t a, const f32x4_t b)
   return __builtin_bit_cast(bf16x8_t, v);
 }
 
+// One fragment (row, 32-wide k-slab ks, 16-byte piece fg) of a [token][HD] operand straight from global memory:
+// what frag_rows reads from an LDS image.  Rows >= S read as zeros.  The forward kernel takes a strip's own query rows
+// this way (only that wave uses them): the request is in flight under the K / V staging, and Q needs no LDS.
+__device__ __forceinline__ bf16x8_t frag_global(const uint16_t* base, size_t row_stride, int row, int S, int ks, int fg) {
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (row < S) v = *reinterpret_cast<const uint4*>(base + (size_t)row * row_stride + ks * 32 + fg * 8);
+  return __builtin_bit_cast(bf16x8_t, v);
+}
+
 // rows [0, S) of one [token][64] operand of (image b, head h) -> LDS; rows [S, SP) zero
 template <int HD>
 __device__ __forceinline__ void stage_rows(const uint16_t* src, size_t row_stride, int S, int SP, uint8_t* dst) {
@@ -78,8 +87,7 @@ __global__ __launch_bounds__(AT_FWD_THREADS) void attn_fwd(const uint16_t* __res
                                                        uint16_t* __restrict__ out, float* __restrict__ lse) {
   extern __shared__ __attribute__((aligned(16))) uint8_t at_smem[];
   constexpr int SP = NT * 16;
-  uint8_t* sq = at_smem;
-  uint8_t* sk = sq + SP * AT_ROWB;
+  uint8_t* sk = at_smem;
   uint8_t* sv = sk + SP * AT_ROWB;
   const int b = blockIdx.x / H, h = blockIdx.x - b * H;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -87,16 +95,20 @@ __global__ __launch_bounds__(AT_FWD_THREADS) void attn_fwd(const uint16_t* __res
   constexpr int KS = HD / 32, DJ = HD / 16;
   const size_t rs = (size_t)3 * H * HD;
   const uint16_t* base = qkv + (size_t)b * S * rs + h * HD;
-  stage_rows<HD>(base, rs, S, SP, sq);
+  // this wave's first query strip: requested before the K / V staging so that it is in flight under it
+  bf16x8_t qf[KS];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_global(base, rs, wave * 16 + fr, S, ks, fg);
   stage_rows<HD>(base + (size_t)H * HD, rs, S, SP, sk);
   stage_rows<HD>(base + (size_t)2 * H * HD, rs, S, SP, sv);
   __syncthreads();
 
   for (int qs = wave; qs < NT; qs += AT_FWD_THREADS / 64) {
     const int q = qs * 16 + fr;
-    bf16x8_t qf[KS];
+    if (qs != wave) {
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_rows<HD>(sq, q, ks, fg);
+      for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_global(base, rs, q, S, ks, fg);
+    }
     f32x4_t sc[NT];
     float m = -INFINITY;
 #pragma unroll
@@ -312,7 +324,7 @@ int at_set_lds(K kernel, int bytes) {
 
 template <int NT, int HD>
 int launch_fwd(const void* qkv, int B, int S, int H, float scale, void* out, float* lse, hipStream_t st) {
-  constexpr int lds = 3 * NT * 16 * AT_ROWB;
+  constexpr int lds = 2 * NT * 16 * AT_ROWB;
   static bool attr = false;
   if (!attr) {
     const int rc = at_set_lds(&attn_fwd<NT, HD>, lds);
