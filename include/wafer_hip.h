@@ -127,6 +127,16 @@ int wm_knn_topk_general_after(const float* query, const float* bank, const float
                               int bank_index_base, const float* after_sim, const int32_t* after_idx, float* out_sim,
                               int32_t* out_idx, void* workspace, size_t workspace_bytes, void* stream);
 
+/* wm_knn_topk for nq queries in batches of `batch` rows, batch i (streaming + selection kernel) on
+ * streams[i % n_streams] with slice i % n_streams of `workspaces` (n_streams slices of workspace_bytes_per_lane >=
+ * wm_knn_topk_workspace_bytes(batch, ...) bytes, a multiple of 256), every launch queued by this one call: the
+ * selection kernel of a batch overlaps the streaming kernels queued behind it on the other streams.  The caller
+ * orders the streams against its own (fork before, join after).  (Embedding retrieval over a whole set:
+ * notebooks/3.0-Embeddings-inference.ipynb cell 7; BASELINE configs[4].) */
+int wm_knn_topk_many(const void* query, const void* bank, int nq, int n, int d, int dtype, int k, int bank_index_base,
+                     float* out_sim, int32_t* out_idx, int batch, void* workspaces, size_t workspace_bytes_per_lane,
+                     void* const* streams, int n_streams);
+
 /* Merge `parts` candidate lists per query ([parts][nq][k], e.g. all-gathered shard results)
  * into the global top-k.  in_* and out_* may not alias. */
 int wm_knn_merge(const float* in_sim, const int32_t* in_idx, int parts, int nq, int k,

@@ -61,6 +61,11 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
          c_size_t, c_void_p],
     ),
+    "wm_knn_topk_many": (
+        c_int,
+        [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p, c_size_t,
+         c_void_p, c_int],
+    ),
     "wm_knn_merge": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "wm_knn_vote": (
         c_int,

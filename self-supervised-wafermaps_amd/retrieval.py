@@ -129,7 +129,8 @@ def nearest_neighbors(query: torch.Tensor, bank: torch.Tensor, k: int, metric: s
     dist, idx = [], []
     for s in range(0, q.shape[0], query_block):
         qs = q[s:s + query_block].contiguous()
-        sim, ind = F_hip.knn_topk(qs, b, k) if fast else _topk_general(qs, b, bias, k)
+        # (the fast path pipelines its query batches over several HIP streams: functional.knn_topk_batched)
+        sim, ind = F_hip.knn_topk_batched(qs, b, k, batch=256) if fast else _topk_general(qs, b, bias, k)
         if metric == "cosine":
             dist.append((1.0 - sim).clamp_min_(0.0))
         else:

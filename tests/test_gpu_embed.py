@@ -606,3 +606,19 @@ def test_knn_topk_large_k_pages(n, d, k, dtype):
     for r in range(q.shape[0]):
         assert set(got[r].tolist()) == set(order[r].tolist()) or torch.allclose(ref[r, got[r]], rs[r], atol=2e-6)
         assert len(set(got[r].tolist())) == k
+
+
+def test_knn_topk_batched_pipelined_equals_single_calls():
+    """functional.knn_topk_batched (query batches round-robin on several HIP streams) returns exactly what one
+    knn_topk call per batch returns, ragged last batch included."""
+    from ssl_wafermap_amd import functional as F
+
+    g = torch.Generator().manual_seed(9)
+    bank = torch.nn.functional.normalize(torch.randn(20000, 128, generator=g), dim=1).to(_dev()).bfloat16()
+    q = bank[100:100 + 64 * 7 + 13].contiguous()
+    for lanes in (2, 3):
+        sim, idx = F.knn_topk_batched(q, bank, 8, batch=64, lanes=lanes)
+        for o in range(0, q.shape[0], 64):
+            s1, i1 = F.knn_topk(q[o:o + 64], bank, 8)
+            assert torch.equal(sim[o:o + 64], s1) and torch.equal(idx[o:o + 64], i1)
+        assert torch.equal(idx[:, 0].long().cpu(), torch.arange(100, 100 + q.shape[0]))
