@@ -493,6 +493,12 @@ int wm_ema_update(float* ema, const float* params, long long n, float m, void* s
 int wm_lars_step(float* params, const float* grads, float* momentum_buf, const long long* seg_offsets, int n_seg,
                  const float* hyper, float* norms_ws, void* stream);
 
+/* Small float32 matmul c [M][N] = op(a) b, op(a) = a [M][K] (trans_a = 0) or a^T with a stored [K][M] (trans_a = 1);
+ * b [K][N]; row-major.  The positional-embedding resize of dino / lightly (interpolate_pos_encoding, reference call
+ * sites scripts/WM811k_benchmark.py:548-550, utilities via lightly MAEBackbone) as a fixed matrix product, and its
+ * gradient. */
+int wm_matmul_f32(const float* a, const float* b, float* c, int M, int N, int K, int trans_a, void* stream);
+
 /* Debugging probe (no reference counterpart): *slot = max(*slot, max_i |x[i]|), NaN if any x[i] is NaN
  * (+inf stays +inf).  x: n elements of WM_F32 / WM_BF16; *slot must hold a non-negative float (zero it
  * first).  Allocates nothing, so it can sit between the launches of a captured hipGraph

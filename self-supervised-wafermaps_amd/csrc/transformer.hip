@@ -1024,3 +1024,41 @@ extern "C" int wm_mean_entropy_reg_fwd_bwd(const void* logits, const float* log_
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
+
+
+// ------------------------------------------------------------------------------------ small f32 matmul
+// C [M][N] = op(A) B, op(A) = A [M][K] or A^T (A stored [K][M]); B [K][N]; all float32, row-major, any sizes.
+// For the parameter-side products of the transformers (dino / lightly interpolate_pos_encoding as a fixed
+// [g'^2][g^2] matrix times the [g^2][D] position table: 36 x 196 x 384, and its transpose product in the backward
+// pass): a few MFLOP, not worth bf16 rounding or a library GEMM.  16 x 16 tiles through LDS, one thread per output.
+namespace {
+template <bool TA>
+__global__ __launch_bounds__(256) void small_matmul_f32(const float* __restrict__ A, const float* __restrict__ B, int M,
+                                                        int N, int K, float* __restrict__ C) {
+  __shared__ float sa[16][17], sb[16][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int row = blockIdx.y * 16 + ty, col = blockIdx.x * 16 + tx;
+  float acc = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const int ka = k0 + tx, kb = k0 + ty;
+    sa[ty][tx] = (row < M && ka < K) ? (TA ? A[(size_t)ka * M + row] : A[(size_t)row * K + ka]) : 0.f;
+    sb[ty][tx] = (kb < K && col < N) ? B[(size_t)kb * N + col] : 0.f;
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < 16; ++k) acc = fmaf(sa[ty][k], sb[k][tx], acc);
+    __syncthreads();
+  }
+  if (row < M && col < N) C[(size_t)row * N + col] = acc;
+}
+}  // namespace
+
+extern "C" int wm_matmul_f32(const float* a, const float* b, float* c, int M, int N, int K, int trans_a, void* stream) {
+  WM_REQUIRE(a && b && c, WM_EINVAL);
+  WM_REQUIRE(M > 0 && N > 0 && K > 0, WM_EINVAL);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  dim3 grid(wm_cdiv(N, 16), wm_cdiv(M, 16));
+  if (trans_a) small_matmul_f32<true><<<grid, 256, 0, st>>>(a, b, M, N, K, c);
+  else small_matmul_f32<false><<<grid, 256, 0, st>>>(a, b, M, N, K, c);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

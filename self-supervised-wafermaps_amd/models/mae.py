@@ -139,7 +139,7 @@ class MAEBackbone(nn.Module):
             out = nn.functional.interpolate(basis, scale_factor=(sf, sf), mode="bicubic")
             m = out.permute(0, 2, 3, 1).reshape(g_new * g_new, n).contiguous().to(pos.device)
             cache[key] = m
-        return torch.cat([pos[:, :1], (m @ pos[0, 1:]).unsqueeze(0)], dim=1)
+        return torch.cat([pos[:, :1], vit_ops.const_matmul(m, pos[0, 1:]).unsqueeze(0)], dim=1)
 
     def images_to_tokens(self, images, add_pos: bool = True):
         """[B,3,S,S] -> bf16 [B*seq, D] rows: class token prepended; the positional embedding is added here

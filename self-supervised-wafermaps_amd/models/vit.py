@@ -133,7 +133,7 @@ class VisionTransformer(nn.Module):
         if g_new * g_new == n:
             return self.pos_embed
         m = self._interp_matrix(g_new)
-        patch = m @ self.pos_embed[0, 1:]  # [g_new^2, D]: a 36 x 196 x 384 product, parameter-side
+        patch = vit_ops.const_matmul(m, self.pos_embed[0, 1:])  # [g_new^2, D]: a 36 x 196 x 384 product, parameter-side
         return torch.cat([self.pos_embed[:, :1], patch.unsqueeze(0)], dim=1)
 
     # ---- forward ----------------------------------------------------------------------------------

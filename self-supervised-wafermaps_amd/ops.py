@@ -280,7 +280,7 @@ def _arena_grad(p: torch.Tensor):
     return None
 
 
-STAT_BUCKETS = 64  # partial-sum buckets per statistics group in the fused conv epilogue
+STAT_BUCKETS = 64  # partial-sum buckets per statistics group in the fused conv epilogue (16 .. 128 measured: no difference)
 
 
 def stats_fusable(rows: int, groups: int) -> bool:

@@ -179,6 +179,35 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
     return bias_act(y, bias, act, residual)
 
 
+class _ConstMatmul(torch.autograd.Function):
+    """m @ p for a CONSTANT float32 matrix m [M, K] and a parameter-side float32 p [K, N] (the resized positional
+    embedding): wm_matmul_f32 forward, m^T @ dout backward."""
+
+    @staticmethod
+    def forward(ctx, m, p):
+        _need_cuda(p, "const_matmul")
+        m, p = m.contiguous().float(), p.contiguous().float()
+        out = torch.empty((m.shape[0], p.shape[1]), dtype=torch.float32, device=p.device)
+        check(_lib.load().wm_matmul_f32(ptr(m), ptr(p), ptr(out), m.shape[0], p.shape[1], m.shape[1], 0, stream_ptr()),
+              "wm_matmul_f32")
+        ctx.save_for_backward(m)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (m,) = ctx.saved_tensors
+        dout = dout.contiguous().float()
+        dp = torch.empty((m.shape[1], dout.shape[1]), dtype=torch.float32, device=dout.device)
+        # dp [K, N] = m^T [K, M] @ dout [M, N]: op(a) = a^T with a = m stored [M][K]
+        check(_lib.load().wm_matmul_f32(ptr(m), ptr(dout), ptr(dp), m.shape[1], dout.shape[1], m.shape[0], 1, stream_ptr()),
+              "wm_matmul_f32")
+        return None, dp
+
+
+def const_matmul(m: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
+    return _ConstMatmul.apply(m, p)
+
+
 class _MlpGelu(torch.autograd.Function):
     """y = fc2(gelu(fc1(x))) (+ residual), four GEMM-shaped launches forward + backward each carrying the
     element-wise work in its epilogue: fc1 + bias + GELU (pre-activation kept), fc2 + bias + residual; backward:

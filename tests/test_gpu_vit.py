@@ -577,3 +577,21 @@ def test_fused_mlp_gelu_matches_torch(rows, c, hid):
     for name, a, b in zip(("dx", "dw1", "db1", "dw2", "db2", "dres"), dev_in, ref_in):
         _close(a.grad, b.grad, rel=2.5e-2, what="mlp " + name)
         assert _cos(a.grad, b.grad) > 0.999, name
+
+
+def test_const_matmul_matches_torch():
+    """wm_matmul_f32 (the positional-embedding resize product and its gradient) against torch float64."""
+    from ssl_wafermap_amd import vit_ops
+
+    g = torch.Generator().manual_seed(0)
+    for (mm, kk, nn) in ((36, 196, 384), (9, 49, 768), (17, 33, 5)):
+        m = torch.randn(mm, kk, generator=g)
+        p = torch.randn(kk, nn, generator=g, requires_grad=True)
+        dout = torch.randn(mm, nn, generator=g)
+        ref = m.double() @ p.double()
+        ref.backward(dout.double())
+        pd = p.detach().to(DEV).requires_grad_(True)
+        out = vit_ops.const_matmul(m.to(DEV), pd)
+        out.backward(dout.to(DEV))
+        torch.testing.assert_close(out.cpu().double(), ref.detach(), atol=1e-4, rtol=1e-5)
+        torch.testing.assert_close(pd.grad.cpu().double(), p.grad.double(), atol=1e-4, rtol=1e-5)
