@@ -92,6 +92,34 @@ __device__ __forceinline__ void glds16_nt_at(const void* gsrc, uint32_t lds_byte
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" : : "v"(gsrc), "s"(base) : "memory", "m0");
 }
 
+// Exact-form GELU x Phi(x) and its derivative Phi(x) + x phi(x), with erf by Abramowitz & Stegun 7.1.26
+// (|error| <= 1.5e-7, i.e. below float32 resolution of the result for |x| < 4 and four orders below the bf16
+// rounding of every tensor these feed): one v_exp, one v_rcp and a degree-5 polynomial instead of libm's erff
+// (~45 instructions, which made the GELU epilogue of the fc1 GEMM cost as much as its MFMA loop).  The exponential
+// exp(-x^2 / 2) is shared between erf(x / sqrt 2) and the density phi(x).
+__device__ __forceinline__ void wm_gelu_parts(float v, float& cdf, float& pdf) {
+  const float ax = fabsf(v) * 0.70710678118654752f;           // |x| / sqrt 2
+  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
+  const float e = __expf(-ax * ax);                            // exp(-x^2 / 2)
+  float poly = fmaf(t, 1.061405429f, -1.453152027f);
+  poly = fmaf(t, poly, 1.421413741f);
+  poly = fmaf(t, poly, -0.284496736f);
+  poly = fmaf(t, poly, 0.254829592f);
+  const float erf_abs = fmaf(-poly * t, e, 1.0f);              // erf(|x| / sqrt 2)
+  cdf = 0.5f * (1.0f + copysignf(erf_abs, v));
+  pdf = 0.3989422804014327f * e;
+}
+__device__ __forceinline__ float wm_gelu(float v) {
+  float c, p;
+  wm_gelu_parts(v, c, p);
+  return v * c;
+}
+__device__ __forceinline__ float wm_gelu_grad(float v) {
+  float c, p;
+  wm_gelu_parts(v, c, p);
+  return fmaf(v, p, c);
+}
+
 static inline int wm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
 // Zero `n_words` 32-bit words with a KERNEL.  Not hipMemsetAsync: captured as a memset NODE inside the ~400-node

@@ -67,10 +67,8 @@ struct ConvArgs {
   int act;
 };
 
-__device__ __forceinline__ float cv_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
-__device__ __forceinline__ float cv_gelu_grad(float v) {
-  return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
-}
+__device__ __forceinline__ float cv_gelu(float v) { return wm_gelu(v); }
+__device__ __forceinline__ float cv_gelu_grad(float v) { return wm_gelu_grad(v); }
 
 // 128 zero bytes: the global_load_lds source of padded / out-of-range taps
 __device__ __attribute__((aligned(256))) uint16_t conv_zero_page[128];

@@ -33,30 +33,47 @@ __device__ __forceinline__ void load8f(const float* p, float (&f)[8]) {
 // the row stays in registers between the mean, the variance and the output pass.
 constexpr int LN_MAXV = 4;
 
+// LPR = lanes per row: 64 (one row per wave, up to LN_MAXV chunks per lane) or 32 (rows of <= 32 chunks, i.e.
+// C <= 256 -- ViT-Tiny's 192: two rows per wave, one chunk per lane; with one row per wave 40 of the 64 lanes idled).
+template <int LPR>
+__device__ __forceinline__ float row_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+template <int LPR>
 __global__ __launch_bounds__(TF_THREADS) void ln_fwd(const uint16_t* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, long long rows,
                                                      int C, uint16_t* __restrict__ y, float* __restrict__ mean,
                                                      float* __restrict__ rstd) {
+  constexpr int RPW = 64 / LPR;                 // rows per wave
+  constexpr int NV = LPR == 64 ? LN_MAXV : 1;   // chunks per lane
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rsel = lane / LPR;
   const int nch = C >> 3;
   const float inv_c = 1.f / (float)C;
-  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
-    float v[LN_MAXV][8];
+  for (long long row0 = ((long long)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += (long long)gridDim.x * 4 * RPW) {
+    const long long row = row0 + rsel;
+    const bool rok = row < rows;
+    float v[NV][8];
     float s = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int ch = lane + 64 * i;
-      if (ch < nch) {
+    for (int i = 0; i < NV; ++i) {
+      const int ch = sub + LPR * i;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
+      if (rok && ch < nch) {
         unpack8(*reinterpret_cast<const uint4*>(x + row * C + ch * 8), v[i]);
 #pragma unroll
         for (int e = 0; e < 8; ++e) s += v[i][e];
       }
     }
-    const float mu = wave_sum(s) * inv_c;
+    const float mu = row_sum<LPR>(s) * inv_c;
     float q = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      if (lane + 64 * i < nch) {
+    for (int i = 0; i < NV; ++i) {
+      if (sub + LPR * i < nch) {
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
           const float d = v[i][e] - mu;
@@ -64,11 +81,11 @@ __global__ __launch_bounds__(TF_THREADS) void ln_fwd(const uint16_t* __restrict_
         }
       }
     }
-    const float r = rsqrtf(wave_sum(q) * inv_c + eps);
+    const float r = rsqrtf(row_sum<LPR>(q) * inv_c + eps);
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int ch = lane + 64 * i;
-      if (ch < nch) {
+    for (int i = 0; i < NV; ++i) {
+      const int ch = sub + LPR * i;
+      if (rok && ch < nch) {
         float g[8], b[8], o[8];
         load8f(gamma + ch * 8, g);
         load8f(beta + ch * 8, b);
@@ -77,38 +94,46 @@ __global__ __launch_bounds__(TF_THREADS) void ln_fwd(const uint16_t* __restrict_
         *reinterpret_cast<uint4*>(y + row * C + ch * 8) = pack8(o);
       }
     }
-    if (lane == 0) {
+    if (sub == 0 && rok) {
       mean[row] = mu;
       rstd[row] = r;
     }
   }
 }
 
+template <int LPR>
 __global__ __launch_bounds__(TF_THREADS) void ln_bwd(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, long long rows, int C,
                                                      uint16_t* __restrict__ dx, float* __restrict__ dgamma,
                                                      float* __restrict__ dbeta) {
   __shared__ float red[2 * 2048];
+  constexpr int RPW = 64 / LPR;
+  constexpr int NV = LPR == 64 ? LN_MAXV : 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int sub = lane % LPR, rsel = lane / LPR;
   const int nch = C >> 3;
   const float inv_c = 1.f / (float)C;
-  float dg[LN_MAXV][8], db[LN_MAXV][8], gm[LN_MAXV][8];
+  float dg[NV][8], db[NV][8], gm[NV][8];
 #pragma unroll
-  for (int i = 0; i < LN_MAXV; ++i) {
-    const int ch = lane + 64 * i;
+  for (int i = 0; i < NV; ++i) {
+    const int ch = sub + LPR * i;
 #pragma unroll
     for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = gm[i][e] = 0.f;
     if (ch < nch) load8f(gamma + ch * 8, gm[i]);
   }
-  for (long long row = (long long)blockIdx.x * 4 + wave; row < rows; row += (long long)gridDim.x * 4) {
-    const float mu = mean[row], r = rstd[row];
-    float xh[LN_MAXV][8], g[LN_MAXV][8];
+  for (long long row0 = ((long long)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += (long long)gridDim.x * 4 * RPW) {
+    const long long row = row0 + rsel;
+    const bool rok = row < rows;
+    const float mu = rok ? mean[row] : 0.f, r = rok ? rstd[row] : 0.f;
+    float xh[NV][8], g[NV][8];
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int ch = lane + 64 * i;
-      if (ch < nch) {
+    for (int i = 0; i < NV; ++i) {
+      const int ch = sub + LPR * i;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) xh[i][e] = g[i][e] = 0.f;
+      if (rok && ch < nch) {
         float fx[8], fd[8];
         unpack8(*reinterpret_cast<const uint4*>(x + row * C + ch * 8), fx);
         unpack8(*reinterpret_cast<const uint4*>(dy + row * C + ch * 8), fd);
@@ -123,11 +148,11 @@ __global__ __launch_bounds__(TF_THREADS) void ln_bwd(const uint16_t* __restrict_
         }
       }
     }
-    const float c1 = wave_sum(s1) * inv_c, c2 = wave_sum(s2) * inv_c;
+    const float c1 = row_sum<LPR>(s1) * inv_c, c2 = row_sum<LPR>(s2) * inv_c;
 #pragma unroll
-    for (int i = 0; i < LN_MAXV; ++i) {
-      const int ch = lane + 64 * i;
-      if (ch < nch) {
+    for (int i = 0; i < NV; ++i) {
+      const int ch = sub + LPR * i;
+      if (rok && ch < nch) {
         float o[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = r * (g[i][e] - c1 - xh[i][e] * c2);
@@ -135,12 +160,22 @@ __global__ __launch_bounds__(TF_THREADS) void ln_bwd(const uint16_t* __restrict_
       }
     }
   }
+  // per-channel sums: with two rows per wave the halves of a wave hold the same channels: fold them first
+  if (RPW == 2) {
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        dg[i][e] += __shfl_xor(dg[i][e], 32, 64);
+        db[i][e] += __shfl_xor(db[i][e], 32, 64);
+      }
+  }
   // per-channel sums: the four waves fold into LDS one after the other, then one atomic per channel
   for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+    if (wave == w && rsel == 0) {
 #pragma unroll
-      for (int i = 0; i < LN_MAXV; ++i) {
-        const int ch = lane + 64 * i;
+      for (int i = 0; i < NV; ++i) {
+        const int ch = sub + LPR * i;
         if (ch < nch) {
 #pragma unroll
           for (int e = 0; e < 8; ++e) {
@@ -160,10 +195,8 @@ __global__ __launch_bounds__(TF_THREADS) void ln_bwd(const uint16_t* __restrict_
 }
 
 // ------------------------------------------------------------------------------------ bias / GELU
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752f)); }
-__device__ __forceinline__ float gelu_grad(float v) {
-  return 0.5f * (1.f + erff(v * 0.70710678118654752f)) + v * 0.3989422804014327f * expf(-0.5f * v * v);
-}
+__device__ __forceinline__ float gelu_f(float v) { return wm_gelu(v); }
+__device__ __forceinline__ float gelu_grad(float v) { return wm_gelu_grad(v); }
 
 template <int ACT>
 __global__ __launch_bounds__(TF_THREADS) void bias_act_fwd(const uint16_t* __restrict__ x, const float* __restrict__ bias,
@@ -772,8 +805,12 @@ extern "C" int wm_layernorm_fwd(const void* x, const float* gamma, const float* 
   WM_REQUIRE(al16(x) && al16(y) && al16(gamma) && al16(beta), WM_EALIGN);
   long long blocks = (rows + 3) / 4;
   if (blocks > 4096) blocks = 4096;
-  ln_fwd<<<(int)blocks, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
-      static_cast<const uint16_t*>(x), gamma, beta, eps, rows, C, static_cast<uint16_t*>(y), mean, rstd);
+  if (C <= 256)
+    ln_fwd<32><<<(int)((blocks + 1) / 2), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const uint16_t*>(x), gamma, beta, eps, rows, C, static_cast<uint16_t*>(y), mean, rstd);
+  else
+    ln_fwd<64><<<(int)blocks, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const uint16_t*>(x), gamma, beta, eps, rows, C, static_cast<uint16_t*>(y), mean, rstd);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -787,9 +824,14 @@ extern "C" int wm_layernorm_bwd(const void* x, const void* dy, const float* gamm
   WM_REQUIRE(al16(x) && al16(dy) && al16(dx) && al16(gamma), WM_EALIGN);
   long long blocks = (rows + 3) / 4;
   if (blocks > 512) blocks = 512;  // same-address atomic chains at the end: keep them short
-  ln_bwd<<<(int)blocks, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
-      static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), gamma, mean, rstd, rows, C,
-      static_cast<uint16_t*>(dx), dgamma, dbeta);
+  if (C <= 256)
+    ln_bwd<32><<<(int)blocks, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), gamma, mean, rstd, rows, C,
+        static_cast<uint16_t*>(dx), dgamma, dbeta);
+  else
+    ln_bwd<64><<<(int)blocks, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
+        static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), gamma, mean, rstd, rows, C,
+        static_cast<uint16_t*>(dx), dgamma, dbeta);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
