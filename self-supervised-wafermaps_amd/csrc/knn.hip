@@ -590,12 +590,58 @@ __global__ __launch_bounds__(64) void knn_merge_lists(const float* __restrict__ 
   }
 }
 
+// Wave maximum of 64-bit keys on the DPP network (no LDS round trips): two quad permutes and the two row mirrors make
+// every lane of a 16-lane row hold the row's maximum, row_bcast15 / row_bcast31 fold the rows into lane 63, which is
+// read back as a wave-uniform scalar.  ~35 VALU instructions against six ds_bpermute round trips (x2 words) for
+// the __shfl_xor butterfly: the selection kernel below runs 3 K such reductions back to back.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ unsigned long long dpp_key(unsigned long long v) {
+  const uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+  const uint32_t ol = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  const uint32_t oh = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  return ((unsigned long long)oh << 32) | ol;
+}
+__device__ __forceinline__ unsigned long long wave_max_key(unsigned long long v) {
+  unsigned long long o;
+  o = dpp_key<0xB1, 0xf>(v);  v = o > v ? o : v;   // quad_perm [1,0,3,2]
+  o = dpp_key<0x4E, 0xf>(v);  v = o > v ? o : v;   // quad_perm [2,3,0,1]
+  o = dpp_key<0x141, 0xf>(v); v = o > v ? o : v;   // row_half_mirror
+  o = dpp_key<0x140, 0xf>(v); v = o > v ? o : v;   // row_mirror: the row's 16 lanes agree
+  o = dpp_key<0x142, 0xa>(v); v = o > v ? o : v;   // row_bcast15 into rows 1 and 3
+  o = dpp_key<0x143, 0xc>(v); v = o > v ? o : v;   // row_bcast31 into rows 2 and 3: lane 63 has the maximum
+  const uint32_t lo = __builtin_amdgcn_readlane((uint32_t)v, 63), hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), 63);
+  return ((unsigned long long)hi << 32) | lo;
+}
+
+// The K largest of the wave's P-per-lane keys, best first, as wave-uniform values (0 = none left).  Keys are
+// distinct (or 0), so removing the winner is a compare against it.
+template <int P, int K>
+__device__ __forceinline__ void wave_topk(unsigned long long (&key)[P], unsigned long long (&win)[K]) {
+#pragma unroll
+  for (int t = 0; t < K; ++t) {
+    unsigned long long m = key[0];
+#pragma unroll
+    for (int p = 1; p < P; ++p) m = key[p] > m ? key[p] : m;
+    const unsigned long long w = wave_max_key(m);
+#pragma unroll
+    for (int p = 0; p < P; ++p) key[p] = key[p] == w ? 0ull : key[p];
+    win[t] = w;
+  }
+}
+
+__device__ __forceinline__ unsigned long long group_key(float v, int g) { return g != INT_MAX ? knn_key(v, g) : 0ull; }
+__device__ __forceinline__ int key_id(unsigned long long key) { return key != 0ull ? (int)~(uint32_t)key : INT_MAX; }
+
 // One block per query: merge the per-slice group lists, rescore the winning groups, pick the top k.
-//  1. rank the heads of the `nslices` sorted runs (all pairs through LDS, total order with the run
-//     index as tie-break): the K best GROUPS can only come from the K runs with the best heads;
-//  2. rank those K*K entries the same way -> the K best groups;
-//  3. recompute the K*64 candidate rows exactly (8 lanes per row, 16-byte pieces, xor-shuffle sum);
+//  1. the K best GROUPS can only come from the K runs (slices) with the best heads: every wave picks the K best
+//     heads of its share of the `nslices` sorted runs (two per lane), wave 0 the K best of those 4 K; group ids are
+//     unique across runs, so (value, group id) as one 64-bit key is a total order and the run of a winner is
+//     (group id >> 3) % nslices (a streaming block's chunks are slice, slice + nslices, ...);
+//  2. the K x K entries of those runs -> the K best groups.  K = 8: every lane fetched the whole lists of its two
+//     runs together with their heads and parked them in LDS, so this step costs no second trip to memory;
+//  3. recompute the K*64 candidate rows exactly (4 lanes per row, 16-byte pieces, xor-shuffle sum);
 //  4. k rounds of wave arg-best (value descending, bank index ascending).
+// All arg-best rounds are wave_topk on the DPP network; three block barriers in all.
 template <int DT, int K>
 __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ query,
                                                   const uint8_t* __restrict__ bank, int n, int d,
@@ -605,16 +651,15 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
                                                   int kout, float* __restrict__ out_sim,
                                                   int* __restrict__ out_idx) {
   extern __shared__ __attribute__((aligned(16))) uint8_t sl_smem[];
-  float* hv = reinterpret_cast<float*>(sl_smem);        // [4K] wave winners (values)
-  int* hg = reinterpret_cast<int*>(hv + 4 * K);          // [4K] (group ids)
-  int* selrun = hg + 4 * K;                              // [4K] (run indices), later the K best groups
-  float* c2v = reinterpret_cast<float*>(selrun + 4 * K); // [K*K]
-  int* c2g = reinterpret_cast<int*>(c2v + K * K);        // [K*K]
-  int* topg = c2g + K * K;                               // [K]
-  float* cv = reinterpret_cast<float*>(topg + K);        // [K*64]
-  int* ci = reinterpret_cast<int*>(cv + K * 64);         // [K*64]
-  float* qf = reinterpret_cast<float*>(ci + K * 64);     // [d]
+  constexpr bool PARK = K == 8;  // whole run lists parked in LDS (512 runs x K keys = 32 KB)
+  unsigned long long* hk = reinterpret_cast<unsigned long long*>(sl_smem);  // [4K] wave winners
+  int* topg = reinterpret_cast<int*>(hk + 4 * K);                           // [K] selected runs, then groups
+  float* cv = reinterpret_cast<float*>(topg + K);                           // [K*64]
+  int* ci = reinterpret_cast<int*>(cv + K * 64);                            // [K*64]
+  float* qf = reinterpret_cast<float*>(ci + K * 64);                        // [d]
+  unsigned long long* lists = reinterpret_cast<unsigned long long*>(sl_smem + ((4 * K * 8 + K * 4 + K * 64 * 8 + d * 4 + 15) & ~15));  // [512][K] (PARK)
   const int q = blockIdx.x, tid = threadIdx.x;
+  const int lane = tid & 63, wv = tid >> 6;
   const size_t qbase = (size_t)q * nslices * K;
   unsigned long long stamp[6];  // WM_KNN_DEBUG bit 2 (kout < 0): phase timestamps, see tools/knn_stamps.py
   const bool stamps = kout < 0;
@@ -625,68 +670,92 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
     if constexpr (DT == WM_BF16) qf[c] = bf2f(reinterpret_cast<const uint16_t*>(query + (size_t)q * rowbytes)[c]);
     else qf[c] = reinterpret_cast<const float*>(query + (size_t)q * rowbytes)[c];
   }
-  if (tid < K) topg[tid] = INT_MAX;  // ranks no valid run reaches stay "no run"
-  // 1. each wave picks the K best run heads among its share (two per lane) by K rounds of wave
-  //    arg-best; run index breaks ties so the order is total
+  // 1. heads (and, K = 8, the whole lists) of this lane's two runs
   {
-    const int lane = tid & 63, wv = tid >> 6;
-    float v0 = -INFINITY, v1 = -INFINITY;
-    int g0 = INT_MAX, g1 = INT_MAX;
-    const int i0 = tid, i1 = tid + 256;
-    if (i0 < nslices) { v0 = part_sim[qbase + (size_t)i0 * K]; g0 = part_idx[qbase + (size_t)i0 * K]; }
-    if (i1 < nslices) { v1 = part_sim[qbase + (size_t)i1 * K]; g1 = part_idx[qbase + (size_t)i1 * K]; }
-    bool u0 = i0 < nslices, u1 = i1 < nslices;
-    for (int t = 0; t < K; ++t) {
-      float bv = -INFINITY;
-      int bg = INT_MAX, bi = INT_MAX;
-      if (u0) { bv = v0; bg = g0; bi = i0; }
-      if (u1 && (bi == INT_MAX || better(v1, g1, bv, bg))) { bv = v1; bg = g1; bi = i1; }
+    unsigned long long head[2] = {0ull, 0ull};
 #pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const float ov = __shfl_xor(bv, o, 64);
-        const int og = __shfl_xor(bg, o, 64);
-        const int oi = __shfl_xor(bi, o, 64);
-        if (oi != INT_MAX && (bi == INT_MAX || better(ov, og, bv, bg) || (ov == bv && og == bg && oi < bi))) {
-          bv = ov; bg = og; bi = oi;
+    for (int u = 0; u < 2; ++u) {
+      const int run = tid + 256 * u;
+      if (run < nslices) {
+        if constexpr (PARK) {
+          const float4 s0 = *reinterpret_cast<const float4*>(part_sim + qbase + (size_t)run * K);
+          const float4 s1 = *reinterpret_cast<const float4*>(part_sim + qbase + (size_t)run * K + 4);
+          const int4 g0 = *reinterpret_cast<const int4*>(part_idx + qbase + (size_t)run * K);
+          const int4 g1 = *reinterpret_cast<const int4*>(part_idx + qbase + (size_t)run * K + 4);
+          const unsigned long long k8[8] = {group_key(s0.x, g0.x), group_key(s0.y, g0.y), group_key(s0.z, g0.z),
+                                            group_key(s0.w, g0.w), group_key(s1.x, g1.x), group_key(s1.y, g1.y),
+                                            group_key(s1.z, g1.z), group_key(s1.w, g1.w)};
+#pragma unroll
+          for (int j = 0; j < 8; ++j) lists[(size_t)run * K + j] = k8[j];
+          head[u] = k8[0];
+        } else {
+          head[u] = group_key(part_sim[qbase + (size_t)run * K], part_idx[qbase + (size_t)run * K]);
         }
       }
-      if (bi == i0) u0 = false;
-      if (bi == i1) u1 = false;
-      if (lane == 0) { hv[wv * K + t] = bv; hg[wv * K + t] = bg; selrun[wv * K + t] = bi; }
+    }
+    unsigned long long win[K];
+    wave_topk<2, K>(head, win);
+    if (lane == 0) {
+#pragma unroll
+      for (int t = 0; t < K; ++t) hk[wv * K + t] = win[t];
     }
   }
   __syncthreads();
   stamp[1] = __builtin_amdgcn_s_memrealtime();
-  // 2. the K best of the 4*K wave winners -> the K runs that can hold the K best groups
-  if (tid < 4 * K) {
-    const float v = hv[tid];
-    const int g = hg[tid], ri = selrun[tid];
-    int rank = 0;
-    for (int j = 0; j < 4 * K; ++j) {
-      const bool jb = selrun[j] != INT_MAX && (ri == INT_MAX || better(hv[j], hg[j], v, g) || (hv[j] == v && hg[j] == g && selrun[j] < ri));
-      rank += jb ? 1 : 0;
+  // 2. wave 0: the K runs that can hold the K best groups, then (K = 8) the K best of their K x K entries
+  if (wv == 0) {
+    unsigned long long c[1] = {lane < 4 * K ? hk[lane] : 0ull};
+    unsigned long long win[K];
+    wave_topk<1, K>(c, win);
+    if constexpr (PARK) {
+      // lane L takes entry L % K of the (L / K)-th selected run: K x K = 64 entries, one per lane
+      unsigned long long rk = 0ull;
+#pragma unroll
+      for (int t = 0; t < K; ++t) rk = (lane / K) == t ? win[t] : rk;
+      const int rg = key_id(rk);
+      unsigned long long e[1] = {rg != INT_MAX ? lists[(size_t)((rg >> 3) % nslices) * K + (lane % K)] : 0ull};
+      wave_topk<1, K>(e, win);
+      if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < K; ++t) topg[t] = key_id(win[t]);
+      }
+    } else {
+      if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < K; ++t) {
+          const int rg = key_id(win[t]);
+          topg[t] = rg != INT_MAX ? (rg >> 3) % nslices : INT_MAX;
+        }
+      }
     }
-    if (rank < K) topg[rank] = ri;  // reuse topg as the selected-run list for a moment
   }
   __syncthreads();
-  if (tid < K * K) {
-    const int run = topg[tid / K];
-    c2v[tid] = run != INT_MAX ? part_sim[qbase + (size_t)run * K + (tid % K)] : -INFINITY;
-    c2g[tid] = run != INT_MAX ? part_idx[qbase + (size_t)run * K + (tid % K)] : INT_MAX;
+  if constexpr (!PARK) {
+    // K = 16: 256 entries, one per thread, fetched now; two-level arg-best as for the heads
+    unsigned long long e[1] = {0ull};
+    if (tid < K * K) {
+      const int run = topg[tid / K];
+      if (run != INT_MAX)
+        e[0] = group_key(part_sim[qbase + (size_t)run * K + (tid % K)], part_idx[qbase + (size_t)run * K + (tid % K)]);
+    }
+    unsigned long long win[K];
+    wave_topk<1, K>(e, win);
+    __syncthreads();  // every thread has read its run from topg
+    if (lane == 0) {
+#pragma unroll
+      for (int t = 0; t < K; ++t) hk[wv * K + t] = win[t];
+    }
+    __syncthreads();
+    if (wv == 0) {
+      unsigned long long c[1] = {lane < 4 * K ? hk[lane] : 0ull};
+      wave_topk<1, K>(c, win);
+      if (lane == 0) {
+#pragma unroll
+        for (int t = 0; t < K; ++t) topg[t] = key_id(win[t]);
+      }
+    }
+    __syncthreads();
   }
-  __syncthreads();
-  if (tid < K * K) {
-    const float v = c2v[tid];
-    const int g = c2g[tid];
-    int rank = 0;
-#pragma unroll 8
-    for (int j = 0; j < K * K; ++j)
-      rank += (better(c2v[j], c2g[j], v, g) || (c2v[j] == v && c2g[j] == g && j < tid)) ? 1 : 0;
-    if (rank < K) selrun[rank] = g;  // the K best groups (ids), best first
-  }
-  __syncthreads();
-  if (tid < K) topg[tid] = selrun[tid];
-  __syncthreads();
   stamp[2] = __builtin_amdgcn_s_memrealtime();
 
   // ---- exact rescoring: 4 lanes per row, 64 rows per pass; a lane's pieces are sub, sub+4, ...
@@ -762,10 +831,8 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
   __syncthreads();
   stamp[3] = __builtin_amdgcn_s_memrealtime();
   if (tid < 64) {
-    // one wave: every lane keeps its K candidates as 64-bit keys in registers (0 = none); a round is a
-    // lane-local maximum, a 6-step wave maximum and the removal of the winner (bank rows are distinct, so
-    // the key identifies it).  Nothing in the loop waits on memory: the stores of a round are not
-    // waited for (a full s_waitcnt here cost ~1.8 us per round).
+    // one wave: every lane keeps its K candidates as 64-bit keys in registers (0 = none); bank rows are distinct,
+    // so the key identifies the winner of a round
     unsigned long long key[K];
 #pragma unroll
     for (int i = 0; i < K; ++i) {
@@ -773,26 +840,21 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
       const int idx = ci[c];
       key[i] = idx != INT_MAX ? knn_key(cv[c], idx) : 0ull;
     }
-    for (int t = 0; t < kout; ++t) {
-      unsigned long long best = key[0];
+    unsigned long long win[K];
+    wave_topk<K, K>(key, win);
+    if (tid == 0) {
 #pragma unroll
-      for (int i = 1; i < K; ++i) best = key[i] > best ? key[i] : best;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        const unsigned long long other = __shfl_xor(best, o, 64);
-        best = other > best ? other : best;
-      }
-#pragma unroll
-      for (int i = 0; i < K; ++i) key[i] = key[i] == best ? 0ull : key[i];
-      if (tid == 0) {
-        float bv = -INFINITY;
-        int bi = -1;
-        if (best != 0ull) {
-          knn_unkey(best, bv, bi);
-          bi += index_base;
+      for (int t = 0; t < K; ++t) {
+        if (t < kout) {
+          float bv = -INFINITY;
+          int bi = -1;
+          if (win[t] != 0ull) {
+            knn_unkey(win[t], bv, bi);
+            bi += index_base;
+          }
+          out_sim[(size_t)q * kout + t] = bv;
+          out_idx[(size_t)q * kout + t] = bi;
         }
-        out_sim[(size_t)q * kout + t] = bv;
-        out_idx[(size_t)q * kout + t] = bi;
       }
     }
   }
@@ -961,7 +1023,9 @@ template <int DT, int K>
 int launch_select(const KnnPlan& p, const void* query, const void* bank, int n, int d, int rowbytes, int nq,
                   const float* ps, const int* pi, int index_base, int kout, float* out_sim, int* out_idx,
                   hipStream_t st) {
-  const size_t lds = (12 * K + 2 * K * K + K) * 4 + (size_t)K * 64 * 8 + (size_t)d * 4;
+  if (p.nslices > 512) return WM_EUNSUPPORTED;  // two runs per lane of the selection block
+  // wave winners, selected runs / groups, rescored candidates, the query; K = 8: the parked run lists (512 x K keys)
+  const size_t lds = ((4 * K * 8 + K * 4 + (size_t)K * 64 * 8 + (size_t)d * 4 + 15) & ~(size_t)15) + (K == 8 ? (size_t)512 * K * 8 : 0);
   knn_select<DT, K><<<nq, 256, lds, st>>>(static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), n, d,
                                           rowbytes, ps, pi, p.nslices, p.nslices, wm_cdiv(n, KNN_ROWS),
                                           index_base, (knn_debug_bits() & 4) ? -kout : kout, out_sim, out_idx);

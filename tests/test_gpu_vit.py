@@ -595,3 +595,22 @@ def test_const_matmul_matches_torch():
         out.backward(dout.to(DEV))
         torch.testing.assert_close(out.cpu().double(), ref.detach(), atol=1e-4, rtol=1e-5)
         torch.testing.assert_close(pd.grad.cpu().double(), p.grad.double(), atol=1e-4, rtol=1e-5)
+
+
+def test_pos_for_matches_oracle_interpolation():
+    """VisionTransformer.pos_for on the device (host-built resize matrix x wm_matmul_f32) against the oracle's
+    bicubic interpolate_pos_encoding (dino's scale-factor form) for the local-crop grids."""
+    from oracle import vit as ov
+    from ssl_wafermap_amd.models.vit import VisionTransformer
+
+    torch.manual_seed(3)
+    m = VisionTransformer(patch_size=16, embed_dim=64, depth=0, num_heads=1)
+    with torch.no_grad():
+        m.pos_embed.normal_()
+    pe = m.pos_embed.detach().clone()
+    m = m.to(DEV)
+    for g_new in (6, 7):
+        got = m.pos_for(g_new)
+        want = ov.pos_embed_for(pe, g_new)
+        assert got.shape == (1, g_new * g_new + 1, 64)
+        torch.testing.assert_close(got.detach().cpu(), want, rtol=1e-5, atol=1e-5)
