@@ -125,8 +125,7 @@ __global__ __launch_bounds__(AT_FWD_THREADS) void attn_fwd(const uint16_t* __res
       }
       sc[t] = a;
     }
-    m = fmaxf(m, __shfl_xor(m, 16, 64));
-    m = fmaxf(m, __shfl_xor(m, 32, 64));
+    m = wm_xor32_max(wm_xor16_max(m));  // lane swaps, no LDS round trip (common.h)
     float l = 0.f;
 #pragma unroll
     for (int t = 0; t < NT; ++t)
@@ -135,8 +134,7 @@ __global__ __launch_bounds__(AT_FWD_THREADS) void attn_fwd(const uint16_t* __res
         sc[t][e] = expf(sc[t][e] - m);
         l += sc[t][e];
       }
-    l += __shfl_xor(l, 16, 64);
-    l += __shfl_xor(l, 32, 64);
+    l = wm_xor32_sum(wm_xor16_sum(l));
     f32x4_t o[DJ];
 #pragma unroll
     for (int j = 0; j < DJ; ++j) o[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -198,9 +196,7 @@ __global__ __launch_bounds__(AT_BWD_THREADS) void attn_bwd(const uint16_t* __res
       d = fmaf(bf2f((uint16_t)(dw[e] & 0xffff)), bf2f((uint16_t)(ow[e] & 0xffff)), d);
       d = fmaf(bf2f((uint16_t)(dw[e] >> 16)), bf2f((uint16_t)(ow[e] >> 16)), d);
     }
-    d += __shfl_xor(d, 1, 64);
-    d += __shfl_xor(d, 2, 64);
-    if (CPR == 8) d += __shfl_xor(d, 4, 64);
+    d = group_sum<CPR>(d);
     if (c == 0) {
       s_delta[r] = d;
       s_lse[r] = r < S ? lse[((size_t)b * H + h) * S + r] : 0.f;

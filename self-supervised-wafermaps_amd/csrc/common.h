@@ -37,16 +37,61 @@ __device__ __forceinline__ uint32_t pack_bf2(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
 
-__device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+// Cross-lane reductions on the DPP network and the gfx950 lane-swap instructions instead of ds_bpermute round
+// trips (__shfl_xor): an all-reduce over aligned groups of W lanes is, in butterfly order 1, 2, 4, 8, 16, 32:
+//   1, 2  quad_perm [1,0,3,2] / [2,3,0,1] (exact xor exchanges);
+//   4, 8  row_half_mirror / row_mirror: lane i pairs with 7-i / 15-i, which after the earlier steps holds the same
+//         value as lane i^4 / i^8 -- so the result is bit-identical to the xor butterfly in this order;
+//   16    v_permlane16_swap (odd 16-lane rows of one operand <-> even rows of the other);
+//   32    v_permlane32_swap (upper 32 lanes <-> lower 32 lanes).
+// Six VALU-rate steps, no LDS traffic, no lgkmcnt waits.
+template <int CTRL>
+__device__ __forceinline__ float wm_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+// (own, partner) of the lane 16 / 32 away, in an order that depends on the lane: use with commutative operations
+// Inline asm, not __builtin_amdgcn_permlane{16,32}_swap: hipcc (ROCm 7.2) returns the FIRST result register for both
+// halves of the builtin's result pair (tools/probes/dpp_reduce_probe.hip shows it; the disassembly stores v1 twice).
+// The s_nop pair covers the VALU-write -> lane-swap-read wait states the compiler inserts for the builtin form.
+__device__ __forceinline__ void wm_pair16(float v, float& a, float& b) {
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ void wm_pair32(float v, float& a, float& b) {
+  a = v;
+  b = v;
+  asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float wm_xor16_sum(float v) { float a, b; wm_pair16(v, a, b); return a + b; }
+__device__ __forceinline__ float wm_xor32_sum(float v) { float a, b; wm_pair32(v, a, b); return a + b; }
+__device__ __forceinline__ float wm_xor16_max(float v) { float a, b; wm_pair16(v, a, b); return fmaxf(a, b); }
+__device__ __forceinline__ float wm_xor32_max(float v) { float a, b; wm_pair32(v, a, b); return fmaxf(a, b); }
+
+template <int W>
+__device__ __forceinline__ float group_sum(float v) {
+  static_assert(W >= 1 && W <= 64 && (W & (W - 1)) == 0, "group width");
+  if constexpr (W >= 2) v += wm_dpp<0xB1>(v);
+  if constexpr (W >= 4) v += wm_dpp<0x4E>(v);
+  if constexpr (W >= 8) v += wm_dpp<0x141>(v);
+  if constexpr (W >= 16) v += wm_dpp<0x140>(v);
+  if constexpr (W >= 32) v = wm_xor16_sum(v);
+  if constexpr (W >= 64) v = wm_xor32_sum(v);
   return v;
 }
-__device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+template <int W>
+__device__ __forceinline__ float group_max(float v) {
+  static_assert(W >= 1 && W <= 64 && (W & (W - 1)) == 0, "group width");
+  if constexpr (W >= 2) v = fmaxf(v, wm_dpp<0xB1>(v));
+  if constexpr (W >= 4) v = fmaxf(v, wm_dpp<0x4E>(v));
+  if constexpr (W >= 8) v = fmaxf(v, wm_dpp<0x141>(v));
+  if constexpr (W >= 16) v = fmaxf(v, wm_dpp<0x140>(v));
+  if constexpr (W >= 32) v = wm_xor16_max(v);
+  if constexpr (W >= 64) v = wm_xor32_max(v);
   return v;
 }
+__device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
+__device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 
 // LDS byte address of a __shared__ pointer (what M0 / ds instructions take).
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {

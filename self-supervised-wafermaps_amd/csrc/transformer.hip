@@ -37,9 +37,7 @@ constexpr int LN_MAXV = 4;
 // C <= 256 -- ViT-Tiny's 192: two rows per wave, one chunk per lane; with one row per wave 40 of the 64 lanes idled).
 template <int LPR>
 __device__ __forceinline__ float row_sum(float v) {
-#pragma unroll
-  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+  return group_sum<LPR>(v);  // DPP / lane-swap all-reduce (common.h)
 }
 
 template <int LPR>
@@ -166,8 +164,8 @@ __global__ __launch_bounds__(TF_THREADS) void ln_bwd(const uint16_t* __restrict_
     for (int i = 0; i < NV; ++i)
 #pragma unroll
       for (int e = 0; e < 8; ++e) {
-        dg[i][e] += __shfl_xor(dg[i][e], 32, 64);
-        db[i][e] += __shfl_xor(db[i][e], 32, 64);
+        dg[i][e] = wm_xor32_sum(dg[i][e]);
+        db[i][e] = wm_xor32_sum(db[i][e]);
       }
   }
   // per-channel sums: the four waves fold into LDS one after the other, then one atomic per channel
