@@ -406,6 +406,11 @@ int wm_layernorm_fwd(const void* x, const float* gamma, const float* beta, float
                      void* y, float* mean, float* rstd, void* stream);
 int wm_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
                      long long rows, int C, void* dx, float* dgamma, float* dbeta, void* stream);
+/* Same with the gradient of the residual connection around the normalised branch (x -> LN -> f -> + x; timm / dino
+ * Block.forward, the reference's DINOViT backbone, scripts/WM811k_benchmark.py:548-550) added in the same pass:
+ * dx = bf16(LN'(dy)) + dres, dres bf16 [rows][C].  Replaces the accumulation pass autograd runs for the two uses of x. */
+int wm_layernorm_bwd_add(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
+                         long long rows, int C, const void* dres, void* dx, float* dgamma, float* dbeta, void* stream);
 
 /* y = act(x + bias) (+ residual).  act: 0 identity, 1 exact GELU (erf), 2 ReLU (the bias-carrying heads:
  * lightly MoCoProjectionHead).  bias / residual may be NULL. */

@@ -155,6 +155,8 @@ SIGNATURES = {
                                  c_void_p]),
     "wm_layernorm_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p,
                                  c_void_p, c_void_p]),
+    "wm_layernorm_bwd_add": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p,
+                                     c_void_p, c_void_p, c_void_p, c_void_p]),
     "wm_bias_act_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p]),
     "wm_bias_act_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "wm_colsum_bf16": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_int, c_void_p]),

@@ -40,74 +40,103 @@ __device__ __forceinline__ float row_sum(float v) {
   return group_sum<LPR>(v);  // DPP / lane-swap all-reduce (common.h)
 }
 
-template <int LPR>
+// NV = chunks per lane (C <= 512 NV: 1 for the ViT-Tiny / -Small / MAE-decoder widths, 2 for ViT-B, 4 up to 2048);
+// U = independent rows (row pairs for LPR = 32) a wave loads before it reduces any of them: one 16-byte load per lane
+// and row leaves ~12 KB in flight per CU, a quarter of what HBM latency needs (measured 1.8-2.5 TB/s); with U rows in
+// flight the kernels are bandwidth- instead of latency-bound.
+template <int LPR, int NV, int U>
 __global__ __launch_bounds__(TF_THREADS) void ln_fwd(const uint16_t* __restrict__ x, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, float eps, long long rows,
                                                      int C, uint16_t* __restrict__ y, float* __restrict__ mean,
                                                      float* __restrict__ rstd) {
-  constexpr int RPW = 64 / LPR;                 // rows per wave
-  constexpr int NV = LPR == 64 ? LN_MAXV : 1;   // chunks per lane
+  constexpr int RPW = 64 / LPR;                 // rows per wave and trip-slot
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, rsel = lane / LPR;
   const int nch = C >> 3;
   const float inv_c = 1.f / (float)C;
-  for (long long row0 = ((long long)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += (long long)gridDim.x * 4 * RPW) {
-    const long long row = row0 + rsel;
-    const bool rok = row < rows;
-    float v[NV][8];
-    float s = 0.f;
+  float g[NV][8], b[NV][8];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int ch = sub + LPR * i;
+  for (int i = 0; i < NV; ++i) {
+    const int ch = sub + LPR * i;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) v[i][e] = 0.f;
-      if (rok && ch < nch) {
-        unpack8(*reinterpret_cast<const uint4*>(x + row * C + ch * 8), v[i]);
+    for (int e = 0; e < 8; ++e) g[i][e] = b[i][e] = 0.f;
+    if (ch < nch) {
+      load8f(gamma + ch * 8, g[i]);
+      load8f(beta + ch * 8, b[i]);
+    }
+  }
+  for (long long base = ((long long)blockIdx.x * 4 + wave) * (RPW * U); base < rows;
+       base += (long long)gridDim.x * 4 * (RPW * U)) {
+    float v[U][NV][8];
+    float s[U];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) s += v[i][e];
+    for (int u = 0; u < U; ++u) {
+      const long long row = base + u * RPW + rsel;
+      s[u] = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int ch = sub + LPR * i;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[u][i][e] = 0.f;
+        if (row < rows && ch < nch) unpack8(*reinterpret_cast<const uint4*>(x + row * C + ch * 8), v[u][i]);
       }
     }
-    const float mu = row_sum<LPR>(s) * inv_c;
-    float q = 0.f;
+    float mu[U], r[U];
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      if (sub + LPR * i < nch) {
+    for (int u = 0; u < U; ++u) {
 #pragma unroll
-        for (int e = 0; e < 8; ++e) {
-          const float d = v[i][e] - mu;
-          q = fmaf(d, d, q);
+      for (int i = 0; i < NV; ++i)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s[u] += v[u][i][e];
+      mu[u] = row_sum<LPR>(s[u]) * inv_c;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      float q = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        if (sub + LPR * i < nch) {
+#pragma unroll
+          for (int e = 0; e < 8; ++e) {
+            const float d = v[u][i][e] - mu[u];
+            q = fmaf(d, d, q);
+          }
         }
       }
+      r[u] = rsqrtf(row_sum<LPR>(q) * inv_c + eps);
     }
-    const float r = rsqrtf(row_sum<LPR>(q) * inv_c + eps);
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int ch = sub + LPR * i;
-      if (rok && ch < nch) {
-        float g[8], b[8], o[8];
-        load8f(gamma + ch * 8, g);
-        load8f(beta + ch * 8, b);
+    for (int u = 0; u < U; ++u) {
+      const long long row = base + u * RPW + rsel;
+      if (row >= rows) continue;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = fmaf((v[i][e] - mu) * r, g[e], b[e]);
-        *reinterpret_cast<uint4*>(y + row * C + ch * 8) = pack8(o);
+      for (int i = 0; i < NV; ++i) {
+        const int ch = sub + LPR * i;
+        if (ch < nch) {
+          float o[8];
+#pragma unroll
+          for (int e = 0; e < 8; ++e) o[e] = fmaf((v[u][i][e] - mu[u]) * r[u], g[i][e], b[i][e]);
+          *reinterpret_cast<uint4*>(y + row * C + ch * 8) = pack8(o);
+        }
       }
-    }
-    if (sub == 0 && rok) {
-      mean[row] = mu;
-      rstd[row] = r;
+      if (sub == 0) {
+        mean[row] = mu[u];
+        rstd[row] = r[u];
+      }
     }
   }
 }
 
-template <int LPR>
+template <int LPR, int NV, int U>
 __global__ __launch_bounds__(TF_THREADS) void ln_bwd(const uint16_t* __restrict__ x, const uint16_t* __restrict__ dy,
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, long long rows, int C,
-                                                     uint16_t* __restrict__ dx, float* __restrict__ dgamma,
-                                                     float* __restrict__ dbeta) {
+                                                     const uint16_t* __restrict__ dres, uint16_t* __restrict__ dx,
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  // dres (optional): the gradient that reaches x along the residual connection around the normalised branch
+  // (x -> LN -> f -> + x); added here so autograd needs no separate accumulation pass over the activation
   __shared__ float red[2 * 2048];
   constexpr int RPW = 64 / LPR;
-  constexpr int NV = LPR == 64 ? LN_MAXV : 1;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int sub = lane % LPR, rsel = lane / LPR;
   const int nch = C >> 3;
@@ -120,41 +149,67 @@ __global__ __launch_bounds__(TF_THREADS) void ln_bwd(const uint16_t* __restrict_
     for (int e = 0; e < 8; ++e) dg[i][e] = db[i][e] = gm[i][e] = 0.f;
     if (ch < nch) load8f(gamma + ch * 8, gm[i]);
   }
-  for (long long row0 = ((long long)blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += (long long)gridDim.x * 4 * RPW) {
-    const long long row = row0 + rsel;
-    const bool rok = row < rows;
-    const float mu = rok ? mean[row] : 0.f, r = rok ? rstd[row] : 0.f;
-    float xh[NV][8], g[NV][8];
-    float s1 = 0.f, s2 = 0.f;
+  for (long long base = ((long long)blockIdx.x * 4 + wave) * (RPW * U); base < rows;
+       base += (long long)gridDim.x * 4 * (RPW * U)) {
+    uint4 vx[U][NV], vd[U][NV], vr[U][NV];
+    float mu[U], r[U];
+    // every load of the trip first
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int ch = sub + LPR * i;
+    for (int u = 0; u < U; ++u) {
+      const long long row = base + u * RPW + rsel;
+      const bool rok = row < rows;
+      mu[u] = rok ? mean[row] : 0.f;
+      r[u] = rok ? rstd[row] : 0.f;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) xh[i][e] = g[i][e] = 0.f;
-      if (rok && ch < nch) {
+      for (int i = 0; i < NV; ++i) {
+        const int ch = sub + LPR * i;
+        vx[u][i] = vd[u][i] = vr[u][i] = make_uint4(0, 0, 0, 0);
+        if (rok && ch < nch) {
+          vx[u][i] = *reinterpret_cast<const uint4*>(x + row * C + ch * 8);
+          vd[u][i] = *reinterpret_cast<const uint4*>(dy + row * C + ch * 8);
+          if (dres != nullptr) vr[u][i] = *reinterpret_cast<const uint4*>(dres + row * C + ch * 8);
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long long row = base + u * RPW + rsel;
+      const bool rok = row < rows;
+      float xh[NV][8], g[NV][8];
+      float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
         float fx[8], fd[8];
-        unpack8(*reinterpret_cast<const uint4*>(x + row * C + ch * 8), fx);
-        unpack8(*reinterpret_cast<const uint4*>(dy + row * C + ch * 8), fd);
+        unpack8(vx[u][i], fx);
+        unpack8(vd[u][i], fd);
+        const bool on = rok && sub + LPR * i < nch;
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          xh[i][e] = (fx[e] - mu) * r;
-          g[i][e] = fd[e] * gm[i][e];
+          xh[i][e] = on ? (fx[e] - mu[u]) * r[u] : 0.f;
+          g[i][e] = fd[e] * gm[i][e];   // (zero where off: fd is zero there)
           s1 += g[i][e];
           s2 = fmaf(g[i][e], xh[i][e], s2);
           dg[i][e] = fmaf(fd[e], xh[i][e], dg[i][e]);
           db[i][e] += fd[e];
         }
       }
-    }
-    const float c1 = row_sum<LPR>(s1) * inv_c, c2 = row_sum<LPR>(s2) * inv_c;
+      const float c1 = row_sum<LPR>(s1) * inv_c, c2 = row_sum<LPR>(s2) * inv_c;
+      if (rok) {
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int ch = sub + LPR * i;
-      if (rok && ch < nch) {
-        float o[8];
+        for (int i = 0; i < NV; ++i) {
+          const int ch = sub + LPR * i;
+          if (ch < nch) {
+            float o[8], sk[8];
+            unpack8(vr[u][i], sk);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = r * (g[i][e] - c1 - xh[i][e] * c2);
-        *reinterpret_cast<uint4*>(dx + row * C + ch * 8) = pack8(o);
+            for (int e = 0; e < 8; ++e) o[e] = r[u] * (g[i][e] - c1 - xh[i][e] * c2);
+            if (dres != nullptr) {  // the un-fused chain rounds the LayerNorm gradient to bf16 before the add
+#pragma unroll
+              for (int e = 0; e < 8; ++e) o[e] = bf2f(f2bf(o[e])) + sk[e];
+            }
+            *reinterpret_cast<uint4*>(dx + row * C + ch * 8) = pack8(o);
+          }
+        }
       }
     }
   }
@@ -801,14 +856,42 @@ extern "C" int wm_layernorm_fwd(const void* x, const float* gamma, const float* 
   WM_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
   WM_REQUIRE(C <= 64 * 8 * LN_MAXV, WM_EUNSUPPORTED);
   WM_REQUIRE(al16(x) && al16(y) && al16(gamma) && al16(beta), WM_EALIGN);
-  long long blocks = (rows + 3) / 4;
-  if (blocks > 4096) blocks = 4096;
-  if (C <= 256)
-    ln_fwd<32><<<(int)((blocks + 1) / 2), TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
-        static_cast<const uint16_t*>(x), gamma, beta, eps, rows, C, static_cast<uint16_t*>(y), mean, rstd);
-  else
-    ln_fwd<64><<<(int)blocks, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
-        static_cast<const uint16_t*>(x), gamma, beta, eps, rows, C, static_cast<uint16_t*>(y), mean, rstd);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const uint16_t* xp = static_cast<const uint16_t*>(x);
+  uint16_t* yp = static_cast<uint16_t*>(y);
+  auto grid = [&](int rows_per_block) {
+    long long blocks = (rows + rows_per_block - 1) / rows_per_block;
+    return (int)(blocks > 1536 ? 1536 : blocks);  // 6 resident blocks per CU (76-84 VGPRs): one round, rows strided
+  };
+  // rows per block and trip: 4 waves x (64 / LPR) x U
+  if (C <= 256) ln_fwd<32, 1, 4><<<grid(32), TF_THREADS, 0, st>>>(xp, gamma, beta, eps, rows, C, yp, mean, rstd);
+  else if (C <= 512) ln_fwd<64, 1, 4><<<grid(16), TF_THREADS, 0, st>>>(xp, gamma, beta, eps, rows, C, yp, mean, rstd);
+  else if (C <= 1024) ln_fwd<64, 2, 2><<<grid(8), TF_THREADS, 0, st>>>(xp, gamma, beta, eps, rows, C, yp, mean, rstd);
+  else ln_fwd<64, 4, 1><<<grid(4), TF_THREADS, 0, st>>>(xp, gamma, beta, eps, rows, C, yp, mean, rstd);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+static int layernorm_bwd_impl(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
+                              long long rows, int C, const void* dres, void* dx, float* dgamma, float* dbeta,
+                              void* stream) {
+  WM_REQUIRE(x && dy && gamma && mean && rstd && dx && dgamma && dbeta, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(C <= 64 * 8 * LN_MAXV, WM_EUNSUPPORTED);
+  WM_REQUIRE(al16(x) && al16(dy) && al16(dx) && al16(gamma) && al16(dres), WM_EALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const uint16_t* xp = static_cast<const uint16_t*>(x);
+  const uint16_t* dp = static_cast<const uint16_t*>(dy);
+  const uint16_t* rp = static_cast<const uint16_t*>(dres);
+  uint16_t* op = static_cast<uint16_t*>(dx);
+  auto grid = [&](int rows_per_block) {
+    long long blocks = (rows + rows_per_block - 1) / rows_per_block;
+    return (int)(blocks > 768 ? 768 : blocks);  // 3 resident blocks per CU: one round; short atomic chains
+  };
+  if (C <= 256) ln_bwd<32, 1, 4><<<grid(32), TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta);
+  else if (C <= 512) ln_bwd<64, 1, 4><<<grid(16), TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta);
+  else if (C <= 1024) ln_bwd<64, 2, 2><<<grid(8), TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta);
+  else ln_bwd<64, 4, 1><<<grid(4), TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -816,22 +899,14 @@ extern "C" int wm_layernorm_fwd(const void* x, const float* gamma, const float* 
 extern "C" int wm_layernorm_bwd(const void* x, const void* dy, const float* gamma, const float* mean,
                                 const float* rstd, long long rows, int C, void* dx, float* dgamma, float* dbeta,
                                 void* stream) {
-  WM_REQUIRE(x && dy && gamma && mean && rstd && dx && dgamma && dbeta, WM_EINVAL);
-  WM_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
-  WM_REQUIRE(C <= 64 * 8 * LN_MAXV, WM_EUNSUPPORTED);
-  WM_REQUIRE(al16(x) && al16(dy) && al16(dx) && al16(gamma), WM_EALIGN);
-  long long blocks = (rows + 3) / 4;
-  if (blocks > 512) blocks = 512;  // same-address atomic chains at the end: keep them short
-  if (C <= 256)
-    ln_bwd<32><<<(int)blocks, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
-        static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), gamma, mean, rstd, rows, C,
-        static_cast<uint16_t*>(dx), dgamma, dbeta);
-  else
-    ln_bwd<64><<<(int)blocks, TF_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
-        static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(dy), gamma, mean, rstd, rows, C,
-        static_cast<uint16_t*>(dx), dgamma, dbeta);
-  WM_LAUNCH_CHECK();
-  return WM_OK;
+  return layernorm_bwd_impl(x, dy, gamma, mean, rstd, rows, C, nullptr, dx, dgamma, dbeta, stream);
+}
+
+extern "C" int wm_layernorm_bwd_add(const void* x, const void* dy, const float* gamma, const float* mean,
+                                    const float* rstd, long long rows, int C, const void* dres, void* dx,
+                                    float* dgamma, float* dbeta, void* stream) {
+  WM_REQUIRE(dres, WM_EINVAL);
+  return layernorm_bwd_impl(x, dy, gamma, mean, rstd, rows, C, dres, dx, dgamma, dbeta, stream);
 }
 
 extern "C" int wm_bias_act_fwd(const void* x, const float* bias, const void* residual, int act, long long rows, int C,

@@ -68,8 +68,10 @@ class EncoderBlock(nn.Module):
             nn.init.normal_(m.bias, std=1e-6)
 
     def forward(self, x, batch, seq):
-        x = self.self_attention(self.ln_1(x), batch, seq, residual=x)
-        return vit_ops.mlp_gelu(self.ln_2(x), self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight, self.mlp[3].bias, x)
+        h, skip = self.ln_1.forward_skip(x)
+        x = self.self_attention(h, batch, seq, residual=skip)
+        h, skip = self.ln_2.forward_skip(x)
+        return vit_ops.mlp_gelu(h, self.mlp[0].weight, self.mlp[0].bias, self.mlp[3].weight, self.mlp[3].bias, skip)
 
 
 class _Encoder(nn.Module):

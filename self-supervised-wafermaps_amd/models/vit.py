@@ -58,8 +58,10 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x, batch: int, seq: int):
-        x = self.attn(self.norm1(x), batch, seq, residual=x)
-        return self.mlp(self.norm2(x), residual=x)
+        h, skip = self.norm1.forward_skip(x)
+        x = self.attn(h, batch, seq, residual=skip)
+        h, skip = self.norm2.forward_skip(x)
+        return self.mlp(h, residual=skip)
 
 
 class PatchEmbed(nn.Module):

@@ -3,6 +3,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -119,6 +121,13 @@ class LayerNorm(nn.Module):
 
     def forward(self, x):
         return vit_ops.layer_norm(x, self.weight, self.bias, self.eps)
+
+    def forward_skip(self, x):
+        """(LayerNorm(x), x) as one autograd node: hand the second value to the branch's residual add, and the
+        gradients of both uses of x are combined inside the LayerNorm backward launch."""
+        if os.environ.get("WM_LN_SKIP", "1") == "0":  # A/B switch: two autograd nodes, gradients added by autograd
+            return vit_ops.layer_norm(x, self.weight, self.bias, self.eps), x
+        return vit_ops.layer_norm_skip(x, self.weight, self.bias, self.eps)
 
 
 class GELU(nn.Module):

@@ -68,6 +68,52 @@ def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: fl
     return _LayerNorm.apply(x, gamma, beta, float(eps))
 
 
+class _LayerNormSkip(torch.autograd.Function):
+    """(LayerNorm(x), x): the two uses of x in a pre-norm residual block (x -> LN -> f -> + x) as ONE autograd node, so
+    the gradients of both uses meet inside the LayerNorm backward kernel (wm_layernorm_bwd_add) instead of in a
+    separate accumulation pass over the activation (two of those per transformer block and step otherwise)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _need_cuda(x, "layer_norm_skip")
+        x = _bf16_rows(x)
+        rows, c = x.shape
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, dtype=torch.float32, device=x.device)
+        rstd = torch.empty(rows, dtype=torch.float32, device=x.device)
+        check(_lib.load().wm_layernorm_fwd(ptr(x), ptr(gamma), ptr(beta), eps, rows, c, ptr(y), ptr(mean), ptr(rstd),
+                                           stream_ptr()), "wm_layernorm_fwd")
+        ctx.save_for_backward(x, mean, rstd)
+        ctx.params = (gamma, beta)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dskip):
+        x, mean, rstd = ctx.saved_tensors
+        gamma, beta = ctx.params
+        rows, c = x.shape
+        lib = _lib.load()
+        if dy is None:  # the normalised branch was not used
+            return dskip, None, None, None
+        dy = _bf16_rows(dy)
+        dx = torch.empty_like(x)
+        dg, dg_ret = _grad_target(gamma)
+        db, db_ret = _grad_target(beta)
+        if dskip is None:
+            check(lib.wm_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), rows, c, ptr(dx), ptr(dg),
+                                       ptr(db), stream_ptr()), "wm_layernorm_bwd")
+        else:
+            dskip = _bf16_rows(dskip)
+            check(lib.wm_layernorm_bwd_add(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), rows, c, ptr(dskip), ptr(dx),
+                                           ptr(dg), ptr(db), stream_ptr()), "wm_layernorm_bwd_add")
+        return dx, dg_ret, db_ret, None
+
+
+def layer_norm_skip(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6):
+    """(LayerNorm(x), x) for a pre-norm residual block; use the second value as the residual operand."""
+    return _LayerNormSkip.apply(x, gamma, beta, float(eps))
+
+
 class _BiasAct(torch.autograd.Function):
     """out = act(x + bias) (+ residual)."""
 

@@ -52,6 +52,39 @@ def test_layer_norm(rows, c):
     _close(bd.grad, br.grad, what="dbeta")
 
 
+@pytest.mark.parametrize("rows,c", [(37, 384), (1000, 192), (130, 768), (9, 2048), (64, 8)])
+def test_layer_norm_skip_combines_both_gradients(rows, c):
+    """layer_norm_skip returns (LN(x), x) as one autograd node; its backward (wm_layernorm_bwd_add) must equal
+    LN'(dy) + dskip, with either gradient absent handled too."""
+    from ssl_wafermap_amd import vit_ops
+
+    g = torch.Generator().manual_seed(rows * 3 + c)
+    x = _bf(torch.randn(rows, c, generator=g) * 2 + 0.5)
+    gamma, beta = torch.rand(c, generator=g) + 0.5, torch.randn(c, generator=g) * 0.1
+    dy, ds = _bf(torch.randn(rows, c, generator=g)), _bf(torch.randn(rows, c, generator=g))
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    ref = F.layer_norm(xr, (c,), gr, br, 1e-6)
+    (ref * dy).sum().backward(retain_graph=True)
+    dx_ln = xr.grad.clone()
+    for use_ln, use_skip in ((True, True), (True, False), (False, True)):
+        xd = x.to(DEV).bfloat16().requires_grad_(True)
+        gd, bd = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+        y, skip = vit_ops.layer_norm_skip(xd, gd, bd, 1e-6)
+        assert torch.equal(skip.detach(), xd.detach())
+        _close(y, ref.detach(), what="y")
+        loss = 0.0
+        if use_ln:
+            loss = loss + (y.float() * dy.to(DEV)).sum()
+        if use_skip:
+            loss = loss + (skip.float() * ds.to(DEV)).sum()
+        loss.backward()
+        want = (dx_ln if use_ln else 0) + (ds if use_skip else 0)
+        _close(xd.grad, want, what=f"dx ln={use_ln} skip={use_skip}")
+        if use_ln:
+            _close(gd.grad, gr.grad, rel=2e-2, what="dgamma")
+            _close(bd.grad, br.grad, what="dbeta")
+
+
 @pytest.mark.parametrize("rows,c,act,res", [(197, 384, 0, True), (300, 1536, 1, False), (64, 1152, 0, False),
                                             (50, 3072, 1, False), (33, 8, 1, True), (256, 2048, 2, False),
                                             (70, 512, 2, True)])
