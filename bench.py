@@ -391,7 +391,7 @@ def main():
 
         # consecutive query batches alternate between two HIP streams (each call = streaming kernel + selection kernel
         # on its stream): the latency-bound selection of batch i runs under the streaming kernel of batch i + 1
-        n_lanes = int(os.environ.get("WM_KNN_LANES", "3" if bq <= 128 else "2"))
+        n_lanes = int(os.environ.get("WM_KNN_LANES", "3" if bq <= 64 else "2"))
         lanes = [torch.cuda.Stream() for _ in range(n_lanes)] if not args.no_overlap else None
         last = [None] * n_lanes
 

@@ -637,13 +637,18 @@ __device__ __forceinline__ int key_id(unsigned long long key) { return key != 0u
 //     heads of its share of the `nslices` sorted runs (two per lane), wave 0 the K best of those 4 K; group ids are
 //     unique across runs, so (value, group id) as one 64-bit key is a total order and the run of a winner is
 //     (group id >> 3) % nslices (a streaming block's chunks are slice, slice + nslices, ...);
-//  2. the K x K entries of those runs -> the K best groups.  K = 8: every lane fetched the whole lists of its two
-//     runs together with their heads and parked them in LDS, so this step costs no second trip to memory;
+//  2. the K x K entries of those runs -> the K best groups (K = 8: one entry per lane of wave 0; K = 16: one per
+//     thread, two-level as for the heads);
 //  3. recompute the K*64 candidate rows exactly (4 lanes per row, 16-byte pieces, xor-shuffle sum);
 //  4. k rounds of wave arg-best (value descending, bank index ascending).
-// All arg-best rounds are wave_topk on the DPP network; three block barriers in all.
+// All arg-best rounds are wave_topk on the DPP network; three block barriers in all (K = 8).  The K = 8 form is kept
+// LEAN on purpose -- 64 registers per lane, ~5 KB of LDS, rescoring in four rounds of two passes -- so that its blocks
+// fit on CUs that already hold two blocks of the NEXT batch's streaming kernel (214 registers and 64 KB each): with
+// batches issued round-robin on streams the selection runs under the following streaming kernel.  (Parking the whole
+// run lists in LDS saved the second trip to memory of step 2 but cost 37 KB and 178 registers: same 51 us for one
+// call, 40.0 instead of 39.0 us per batch pipelined.)
 template <int DT, int K>
-__global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ query,
+__global__ __launch_bounds__(256, K == 8 ? 6 : 1) void knn_select(const uint8_t* __restrict__ query,
                                                   const uint8_t* __restrict__ bank, int n, int d,
                                                   int rowbytes, const float* __restrict__ part_sim,
                                                   const int* __restrict__ part_idx, int nslices,
@@ -651,13 +656,11 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
                                                   int kout, float* __restrict__ out_sim,
                                                   int* __restrict__ out_idx) {
   extern __shared__ __attribute__((aligned(16))) uint8_t sl_smem[];
-  constexpr bool PARK = K == 8;  // whole run lists parked in LDS (512 runs x K keys = 32 KB)
   unsigned long long* hk = reinterpret_cast<unsigned long long*>(sl_smem);  // [4K] wave winners
   int* topg = reinterpret_cast<int*>(hk + 4 * K);                           // [K] selected runs, then groups
   float* cv = reinterpret_cast<float*>(topg + K);                           // [K*64]
   int* ci = reinterpret_cast<int*>(cv + K * 64);                            // [K*64]
   float* qf = reinterpret_cast<float*>(ci + K * 64);                        // [d]
-  unsigned long long* lists = reinterpret_cast<unsigned long long*>(sl_smem + ((4 * K * 8 + K * 4 + K * 64 * 8 + d * 4 + 15) & ~15));  // [512][K] (PARK)
   const int q = blockIdx.x, tid = threadIdx.x;
   const int lane = tid & 63, wv = tid >> 6;
   const size_t qbase = (size_t)q * nslices * K;
@@ -676,22 +679,7 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int run = tid + 256 * u;
-      if (run < nslices) {
-        if constexpr (PARK) {
-          const float4 s0 = *reinterpret_cast<const float4*>(part_sim + qbase + (size_t)run * K);
-          const float4 s1 = *reinterpret_cast<const float4*>(part_sim + qbase + (size_t)run * K + 4);
-          const int4 g0 = *reinterpret_cast<const int4*>(part_idx + qbase + (size_t)run * K);
-          const int4 g1 = *reinterpret_cast<const int4*>(part_idx + qbase + (size_t)run * K + 4);
-          const unsigned long long k8[8] = {group_key(s0.x, g0.x), group_key(s0.y, g0.y), group_key(s0.z, g0.z),
-                                            group_key(s0.w, g0.w), group_key(s1.x, g1.x), group_key(s1.y, g1.y),
-                                            group_key(s1.z, g1.z), group_key(s1.w, g1.w)};
-#pragma unroll
-          for (int j = 0; j < 8; ++j) lists[(size_t)run * K + j] = k8[j];
-          head[u] = k8[0];
-        } else {
-          head[u] = group_key(part_sim[qbase + (size_t)run * K], part_idx[qbase + (size_t)run * K]);
-        }
-      }
+      if (run < nslices) head[u] = group_key(part_sim[qbase + (size_t)run * K], part_idx[qbase + (size_t)run * K]);
     }
     unsigned long long win[K];
     wave_topk<2, K>(head, win);
@@ -707,13 +695,17 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
     unsigned long long c[1] = {lane < 4 * K ? hk[lane] : 0ull};
     unsigned long long win[K];
     wave_topk<1, K>(c, win);
-    if constexpr (PARK) {
-      // lane L takes entry L % K of the (L / K)-th selected run: K x K = 64 entries, one per lane
+    if constexpr (K * K <= 64) {
+      // K = 8: lane L takes entry L % K of the (L / K)-th selected run: K x K = 64 entries, one per lane
       unsigned long long rk = 0ull;
 #pragma unroll
       for (int t = 0; t < K; ++t) rk = (lane / K) == t ? win[t] : rk;
       const int rg = key_id(rk);
-      unsigned long long e[1] = {rg != INT_MAX ? lists[(size_t)((rg >> 3) % nslices) * K + (lane % K)] : 0ull};
+      unsigned long long e[1] = {0ull};
+      if (rg != INT_MAX) {
+        const size_t o = qbase + (size_t)((rg >> 3) % nslices) * K + (lane % K);
+        e[0] = group_key(part_sim[o], part_idx[o]);
+      }
       wave_topk<1, K>(e, win);
       if (lane == 0) {
 #pragma unroll
@@ -730,7 +722,7 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
     }
   }
   __syncthreads();
-  if constexpr (!PARK) {
+  if constexpr (K * K > 64) {
     // K = 16: 256 entries, one per thread, fetched now; two-level arg-best as for the heads
     unsigned long long e[1] = {0ull};
     if (tid < K * K) {
@@ -763,7 +755,8 @@ __global__ __launch_bounds__(256) void knn_select(const uint8_t* __restrict__ qu
   const int sub = tid & 3, slot = tid >> 2;
   const int pieces = rowbytes >> 4;  // 16-byte pieces per row
   constexpr int EPP = DT == WM_BF16 ? 8 : 4;  // elements per piece
-  constexpr int PASSES = K == 8 ? 8 : 4;
+  // K = 8: two passes in flight (the lean form, see the kernel's header)
+  constexpr int PASSES = K == 8 ? 2 : 4;
   constexpr int ncand = K * 64;  // 4 chunks x 16 rows per group
   for (int c0p = 0; c0p < ncand; c0p += 64 * PASSES) {
     int rows[PASSES];
@@ -1024,11 +1017,11 @@ int launch_select(const KnnPlan& p, const void* query, const void* bank, int n, 
                   const float* ps, const int* pi, int index_base, int kout, float* out_sim, int* out_idx,
                   hipStream_t st) {
   if (p.nslices > 512) return WM_EUNSUPPORTED;  // two runs per lane of the selection block
-  // wave winners, selected runs / groups, rescored candidates, the query; K = 8: the parked run lists (512 x K keys)
-  const size_t lds = ((4 * K * 8 + K * 4 + (size_t)K * 64 * 8 + (size_t)d * 4 + 15) & ~(size_t)15) + (K == 8 ? (size_t)512 * K * 8 : 0);
+  // wave winners, selected runs / groups, rescored candidates, the query
+  const size_t lds = (4 * K * 8 + K * 4 + (size_t)K * 64 * 8 + (size_t)d * 4 + 15) & ~(size_t)15;
   knn_select<DT, K><<<nq, 256, lds, st>>>(static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), n, d,
-                                          rowbytes, ps, pi, p.nslices, p.nslices, wm_cdiv(n, KNN_ROWS),
-                                          index_base, (knn_debug_bits() & 4) ? -kout : kout, out_sim, out_idx);
+                                          rowbytes, ps, pi, p.nslices, p.nslices, wm_cdiv(n, KNN_ROWS), index_base,
+                                          (knn_debug_bits() & 4) ? -kout : kout, out_sim, out_idx);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

@@ -79,13 +79,14 @@ def knn_topk_batched(queries: torch.Tensor, bank: torch.Tensor, k: int, batch: i
                      index_base: int = 0) -> Tuple[torch.Tensor, torch.Tensor]:
     """knn_topk for many queries (embedding retrieval, all-pairs): query batches of `batch` rows are issued
     round-robin on `lanes` HIP streams, so the latency-bound selection kernel of one batch runs under the streaming
-    kernel of the next (measured on 811 457 x 128 bf16, 64 queries per batch: 65 us per batch on one stream, 43 us
-    on three = 0.61 of the HBM roofline end to end; default lanes: 3 up to 128 queries per batch, else 2).
+    kernel of the next (measured on 811 457 x 128 bf16, 64 queries per batch: 51 us per batch on one stream, 39 us
+    on three = 0.66 of the HBM roofline end to end; 128 per batch: 72 -> 48 us on two; default lanes: 3 up to 64
+    queries per batch, else 2; tools/bench_knn_pipeline.py).
     Returns (sim [nq, k], idx [nq, k]) as knn_topk; the current stream waits for all lanes before returning."""
     require_gpu(queries, bank)
     nq = queries.shape[0]
     if lanes is None:
-        lanes = 3 if batch <= 128 else 2
+        lanes = 3 if batch <= 64 else 2
     if nq <= batch or lanes <= 1:
         return knn_topk(queries, bank, k, index_base)
     dev = queries.device
