@@ -213,34 +213,56 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restri
   }
 }
 
-// Reduce the [nblk] partial sums of one (group, channel) pair: 32 lanes of a 1024-thread block
-// stride over the partials of 32 adjacent channels (128-byte coalesced rows), then combine in LDS.
-__device__ __forceinline__ void finalize_sums(float* __restrict__ part, int nblk, int g, int C, int c,
-                                              int bl, int cl, double (*red)[32][33], double& s, double& ss,
-                                              bool clear = false) {
-  double a = 0.0, b = 0.0;
+// Reduce the [nblk] partial sums of (group, channel) pairs: 32 lanes of a 1024-thread block stride over the partials
+// of 32 adjacent channels (128-byte coalesced rows), then combine in LDS.  TWO groups (the two views of a training
+// step) go through together: their loads are in flight at the same time and they share the barriers, which is most
+// of what these few-microsecond launches cost (44 of them per SimCLR step).
+__device__ __forceinline__ void finalize_sums2(float* __restrict__ part, int nblk, int g, int ng, int C, int c,
+                                               int bl, int cl, double (*red)[2][32][33], double (&s)[2],
+                                               double (&ss)[2], bool clear = false) {
+  double a[2] = {0.0, 0.0}, b[2] = {0.0, 0.0};
   if (c < C) {
     for (int k = bl; k < nblk; k += 32) {
-      float* p0 = part + ((size_t)(g * nblk + k) * 2 + 0) * C + c;
-      float* p1 = part + ((size_t)(g * nblk + k) * 2 + 1) * C + c;
-      a += (double)*p0;
-      b += (double)*p1;
-      if (clear) {  // read-and-clear: the conv epilogue's atomics start from zero next step
-        *p0 = 0.f;
-        *p1 = 0.f;
+      float va[2] = {0.f, 0.f}, vb[2] = {0.f, 0.f};
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u < ng) {
+          float* p0 = part + ((size_t)((g + u) * nblk + k) * 2 + 0) * C + c;
+          float* p1 = part + ((size_t)((g + u) * nblk + k) * 2 + 1) * C + c;
+          va[u] = *p0;
+          vb[u] = *p1;
+          if (clear) {  // read-and-clear: the conv epilogue's atomics start from zero next step
+            *p0 = 0.f;
+            *p1 = 0.f;
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        a[u] += (double)va[u];
+        b[u] += (double)vb[u];
       }
     }
   }
-  __syncthreads();  // previous group's readers are done with `red`
-  red[0][bl][cl] = a;
-  red[1][bl][cl] = b;
+  __syncthreads();  // previous pair's readers are done with `red`
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    red[0][u][bl][cl] = a[u];
+    red[1][u][bl][cl] = b[u];
+  }
   __syncthreads();
-  s = 0.0;
-  ss = 0.0;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    s[u] = 0.0;
+    ss[u] = 0.0;
+  }
   if (bl == 0) {
     for (int k = 0; k < 32; ++k) {
-      s += red[0][k][cl];
-      ss += red[1][k][cl];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        s[u] += red[0][u][k][cl];
+        ss[u] += red[1][u][k][cl];
+      }
     }
   }
 }
@@ -251,7 +273,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize(
     const float* __restrict__ gamma, const float* __restrict__ beta, float eps, float momentum,
     float* __restrict__ running_mean, float* __restrict__ running_var, long long* __restrict__ num_batches_tracked,
     float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
-  __shared__ double red[2][32][33];
+  __shared__ double red[2][2][32][33];
   // torch's num_batches_tracked += 1 per forward call; the G groups are G calls (one lane of the launch)
   if (num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += G;
   const int bl = threadIdx.x >> 5, cl = threadIdx.x & 31;
@@ -262,24 +284,29 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize(
     rm = running_mean ? running_mean[c] : 0.f;
     rv = running_var ? running_var[c] : 0.f;
   }
-  for (int g = 0; g < G; ++g) {
-    double s, ss;
-    finalize_sums(part, nblk, g, C, c, bl, cl, red, s, ss, clear != 0);
+  for (int g0 = 0; g0 < G; g0 += 2) {
+    const int ng = G - g0 < 2 ? G - g0 : 2;
+    double s2[2], ss2[2];
+    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s2, ss2, clear != 0);
     if (owner) {
-      const double m = s / rows_per_group;
-      double var = ss / rows_per_group - m * m;
-      if (var < 0.0) var = 0.0;
-      const float fm = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
-      mean[(size_t)g * C + c] = fm;
-      invstd[(size_t)g * C + c] = is;
-      const float sc = (gamma ? gamma[c] : 1.f) * is;
-      scale[(size_t)g * C + c] = sc;
-      shift[(size_t)g * C + c] = (beta ? beta[c] : 0.f) - fm * sc;
-      // torch: running = (1-momentum)*running + momentum*stat, unbiased variance; the G groups
-      // are the reference's G consecutive forward calls
-      const double unb = rows_per_group > 1 ? var * rows_per_group / (rows_per_group - 1.0) : var;
-      rm = (1.f - momentum) * rm + momentum * fm;
-      rv = (1.f - momentum) * rv + momentum * (float)unb;
+      for (int u = 0; u < ng; ++u) {
+        const int g = g0 + u;
+        const double s = s2[u], ss = ss2[u];
+        const double m = s / rows_per_group;
+        double var = ss / rows_per_group - m * m;
+        if (var < 0.0) var = 0.0;
+        const float fm = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+        mean[(size_t)g * C + c] = fm;
+        invstd[(size_t)g * C + c] = is;
+        const float sc = (gamma ? gamma[c] : 1.f) * is;
+        scale[(size_t)g * C + c] = sc;
+        shift[(size_t)g * C + c] = (beta ? beta[c] : 0.f) - fm * sc;
+        // torch: running = (1-momentum)*running + momentum*stat, unbiased variance; the G groups
+        // are the reference's G consecutive forward calls
+        const double unb = rows_per_group > 1 ? var * rows_per_group / (rows_per_group - 1.0) : var;
+        rm = (1.f - momentum) * rm + momentum * fm;
+        rv = (1.f - momentum) * rv + momentum * (float)unb;
+      }
     }
   }
   if (owner) {
@@ -364,27 +391,32 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize(
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
     float* __restrict__ coef) {
-  __shared__ double red[2][32][33];
+  __shared__ double red[2][2][32][33];
   const int bl = threadIdx.x >> 5, cl = threadIdx.x & 31;
   const int c = blockIdx.x * 32 + cl;
   const bool owner = bl == 0 && c < C;
   double tg = 0.0, tb = 0.0;
-  for (int g = 0; g < G; ++g) {
-    double s1, s2;
-    finalize_sums(part, nblk, g, C, c, bl, cl, red, s1, s2);
+  for (int g0 = 0; g0 < G; g0 += 2) {
+    const int ng = G - g0 < 2 ? G - g0 : 2;
+    double s1v[2], s2v[2];
+    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s1v, s2v);
     if (owner) {
-      tb += s1;
-      tg += s2;
-      const float is = invstd[(size_t)g * C + c];
-      const float mu = mean[(size_t)g * C + c];
-      const float sc = (gamma ? gamma[c] : 1.f) * is;
-      coef[((size_t)g * 7 + 0) * C + c] = mu;
-      coef[((size_t)g * 7 + 1) * C + c] = is;
-      coef[((size_t)g * 7 + 2) * C + c] = sc;
-      coef[((size_t)g * 7 + 3) * C + c] = (float)(s1 / rows_per_group);
-      coef[((size_t)g * 7 + 4) * C + c] = (float)(s2 / rows_per_group);
-      coef[((size_t)g * 7 + 5) * C + c] = sc;
-      coef[((size_t)g * 7 + 6) * C + c] = (beta ? beta[c] : 0.f) - mu * sc;
+      for (int u = 0; u < ng; ++u) {
+        const int g = g0 + u;
+        const double s1 = s1v[u], s2 = s2v[u];
+        tb += s1;
+        tg += s2;
+        const float is = invstd[(size_t)g * C + c];
+        const float mu = mean[(size_t)g * C + c];
+        const float sc = (gamma ? gamma[c] : 1.f) * is;
+        coef[((size_t)g * 7 + 0) * C + c] = mu;
+        coef[((size_t)g * 7 + 1) * C + c] = is;
+        coef[((size_t)g * 7 + 2) * C + c] = sc;
+        coef[((size_t)g * 7 + 3) * C + c] = (float)(s1 / rows_per_group);
+        coef[((size_t)g * 7 + 4) * C + c] = (float)(s2 / rows_per_group);
+        coef[((size_t)g * 7 + 5) * C + c] = sc;
+        coef[((size_t)g * 7 + 6) * C + c] = (beta ? beta[c] : 0.f) - mu * sc;
+      }
     }
   }
   if (owner) {
