@@ -495,7 +495,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __res
 __global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply(const uint16_t* __restrict__ y,
                                                                 const float* __restrict__ coef, int N, int C,
                                                                 int imgs_per_group, int remask,
-                                                                uint16_t* __restrict__ dy, const PoolSrc ps) {
+                                                                uint16_t* __restrict__ dy, const PoolSrc ps,
+                                                                const WmDiv d_cpr, const WmDiv d_wb, const WmDiv d_ha,
+                                                                const WmDiv d_ipg) {
   // 32-bit index arithmetic (host-checked range): the kernel is VALU-bound, see pool.hip
   const uint32_t cpr = (uint32_t)C >> 3;
   const uint32_t HA = (uint32_t)ps.H >> 1, WB = (uint32_t)ps.W >> 1;
@@ -503,12 +505,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply(const uint16_t* 
   int cur_g = -1;
   float k[7][8];
   for (uint32_t t = blockIdx.x * BN_THREADS + threadIdx.x; t < total; t += gridDim.x * BN_THREADS) {
-    const int c0 = (int)(t % cpr) * 8;
-    uint32_t u = t / cpr;
-    const int b = (int)(u % WB);
-    u /= WB;
-    const int a = (int)(u % HA), n = (int)(u / HA);
-    const int g = n / imgs_per_group;
+    uint32_t rc, rb, ra;
+    uint32_t u = wm_divmod(t, d_cpr, rc);
+    const int c0 = (int)rc * 8;
+    u = wm_divmod(u, d_wb, rb);
+    const int n = (int)wm_divmod(u, d_ha, ra);
+    const int b = (int)rb, a = (int)ra;
+    const int g = (int)wm_div((uint32_t)n, d_ipg);
     if (g != cur_g) {
       const float* cf = coef + (size_t)g * 7 * C + c0;
 #pragma unroll
@@ -958,7 +961,9 @@ static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, in
       rows * tpr < (1ll << 31)) {  // (32-bit item indices in the quad kernel)
     const int n_img = (int)(rows / ((long long)ps.H * ps.W));
     bn_pool_bwd_apply<<<stream_grid(rows / 4 * tpr), BN_THREADS, 0, st>>>(
-        static_cast<const uint16_t*>(y), coef, n_img, C, n_img / G, remask ? 1 : 0, static_cast<uint16_t*>(dy), ps);
+        static_cast<const uint16_t*>(y), coef, n_img, C, n_img / G, remask ? 1 : 0, static_cast<uint16_t*>(dy), ps,
+        wm_div_make((uint32_t)(C >> 3)), wm_div_make((uint32_t)(ps.W >> 1)), wm_div_make((uint32_t)(ps.H >> 1)),
+        wm_div_make((uint32_t)(n_img / G)));
     WM_LAUNCH_CHECK();
     return WM_OK;
   }

@@ -167,6 +167,31 @@ __device__ __forceinline__ float wm_gelu_grad(float v) {
 
 static inline int wm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 
+// Division of a 31-bit index by a run-time constant (image sides, channels / 8, images per group) as a multiply-high,
+// an add and a shift instead of the ~40-instruction expansion of an integer division: with l = ceil(log2 d) and
+// m = ceil(2^(32+l) / d) - 2^32, floor(x / d) = (umulhi(x, m) + x) >> l for every x < 2^31 (the error term
+// x (m d - 2^(32+l)) stays below 2^(32+l)).  The index decode of the per-element kernels and the prologues of the
+// tile kernels were a measurable share of their instruction streams (stem / layer1 patch kernels: -20 .. -40 % time).
+struct WmDiv {
+  uint32_t m, l, d;
+};
+static inline WmDiv wm_div_make(uint32_t d) {
+  WmDiv v;
+  uint32_t l = 0;
+  while ((1ull << l) < d) ++l;
+  v.l = l;
+  v.d = d;
+  v.m = (uint32_t)((((1ull << (32 + l)) + d - 1) / d) - (1ull << 32));
+  return v;
+}
+__device__ __forceinline__ uint32_t wm_div(uint32_t x, const WmDiv& v) { return (__umulhi(x, v.m) + x) >> v.l; }
+// quotient and remainder
+__device__ __forceinline__ uint32_t wm_divmod(uint32_t x, const WmDiv& v, uint32_t& rem) {
+  const uint32_t q = wm_div(x, v);
+  rem = x - q * v.d;
+  return q;
+}
+
 // Zero `n_words` 32-bit words with a KERNEL.  Not hipMemsetAsync: captured as a memset NODE inside the ~400-node
 // hipGraph of a training step, the clear of the NT-Xent gradient buffer was not reliably applied before the
 // kernel that adds into it (first non-finite tensor of the bs-256 run: that buffer, with finite inputs; a fill

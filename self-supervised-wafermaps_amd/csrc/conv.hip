@@ -65,6 +65,8 @@ struct ConvArgs {
   const uint16_t* pre_in;
   uint16_t* pre_out;
   int act;
+  // multiply-high forms of the divisions by DH * DW and by DW in the row decode (common.h)
+  WmDiv d_dhw, d_dw, d_h2w2, d_w2;  // (the last two: DH/2 * DW/2 and DW/2, the parity-class order of MODE 2)
 };
 
 __device__ __forceinline__ float cv_gelu(float v) { return wm_gelu(v); }
@@ -127,8 +129,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
     for (int i = 0; i < NR; ++i) {
       const int m = m0 + rowl + 32 * i - pc * cls;  // index inside the class
       mv[i] = true;                                   // class size % 128 == 0 (host-checked)
-      const int n = m / h2w2, rem = m - n * h2w2;
-      const int h2 = rem / (a.DW >> 1), w2 = rem - h2 * (a.DW >> 1);
+      uint32_t urem2, uw2;
+      const int n = (int)wm_divmod((uint32_t)m, a.d_h2w2, urem2);
+      const int h2 = (int)wm_divmod(urem2, a.d_w2, uw2), w2 = (int)uw2;
       // source pixel of tap (r, s): (h2 + (ph + pad - r)/2, w2 + (pw + pad - s)/2)
       bh[i] = h2 + ((ph + a.pad - r0) >> 1);
       bw[i] = w2 + ((pw + a.pad - s0) >> 1);
@@ -141,8 +144,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
       const int m = m0 + rowl + 32 * i;
       mv[i] = m < a.M;
       const int mm = mv[i] ? m : 0;
-      const int n = mm / dhw, rem = mm - n * dhw;
-      const int dh = rem / a.DW, dw = rem - dh * a.DW;
+      uint32_t urem, udw;
+      const int n = (int)wm_divmod((uint32_t)mm, a.d_dhw, urem);
+      const int dh = (int)wm_divmod(urem, a.d_dw, udw), dw = (int)udw;
       if constexpr (!DGRAD) {
         bh[i] = dh * a.stride - a.pad;
         bw[i] = dw * a.stride - a.pad;
@@ -326,8 +330,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
         const int pc = m0 / cls;
         const int m = m0 + row - pc * cls;
         const int h2w2 = (a.DH >> 1) * (a.DW >> 1);
-        const int n = m / h2w2, rem = m - n * h2w2;
-        const int h2 = rem / (a.DW >> 1), w2 = rem - h2 * (a.DW >> 1);
+        uint32_t urem2, uw2;
+        const int n = (int)wm_divmod((uint32_t)m, a.d_h2w2, urem2);
+        const int h2 = (int)wm_divmod(urem2, a.d_w2, uw2), w2 = (int)uw2;
         pix = ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
       }
       pixs[it] = pix;
@@ -396,8 +401,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
         const int pc = m0 / cls;
         const int m = m0 + row - pc * cls;
         const int h2w2 = (a.DH >> 1) * (a.DW >> 1);
-        const int n = m / h2w2, rem = m - n * h2w2;
-        const int h2 = rem / (a.DW >> 1), w2 = rem - h2 * (a.DW >> 1);
+        uint32_t urem2, uw2;
+        const int n = (int)wm_divmod((uint32_t)m, a.d_h2w2, urem2);
+        const int h2 = (int)wm_divmod(urem2, a.d_w2, uw2), w2 = (int)uw2;
         pix = ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
       }
       if (m0 + row < a.M) {
@@ -457,6 +463,18 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
   const uint32_t smem_base = lds_addr(cv_smem);
 
   // ---- patches: 28 instructions x 8 pixel slots; wave w issues instructions w, w + 4, ...
+  // (the two tile origins are decoded ONCE from the block index, as wave-uniform values: integer divisions by the
+  // run-time image sizes per fetched piece and per stored chunk were a third of this kernel's instructions)
+  int tn[2], th0[2], tw0[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int T = blockIdx.x * 2 + t;
+    tn[t] = T / tiles_img;
+    const int tr = T - tn[t] * tiles_img;
+    const int th = tr / tw_n;
+    th0[t] = th * 8;
+    tw0[t] = (tr - th * tw_n) * 8;
+  }
   {
     const int sl = lane & 7;
 #pragma unroll
@@ -466,13 +484,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
       const int t = gp >= PT_PIX ? 1 : 0;
       const int pp = gp - t * PT_PIX;
       const int py = pp / PT_PITCH, px = pp - py * PT_PITCH;
-      const int T = blockIdx.x * 2 + t;
-      const int n = T / tiles_img, tr = T - n * tiles_img;
-      const int th = tr / tw_n, tw = tr - th * tw_n;
-      const int h = th * 8 - 1 + py, w = tw * 8 - 1 + px;
+      const int h = (t ? th0[1] : th0[0]) - 1 + py, w = (t ? tw0[1] : tw0[0]) - 1 + px;
       const bool ok = gp < 2 * PT_PIX && px < 10 && (unsigned)h < (unsigned)a.SH && (unsigned)w < (unsigned)a.SW;
       const int chunk = sl ^ (px & 7);
-      const uint16_t* src = ok ? a.src + ((size_t)(n * a.SH + h) * a.SW + w) * 64 + chunk * 8
+      const uint16_t* src = ok ? a.src + ((size_t)((t ? tn[1] : tn[0]) * a.SH + h) * a.SW + w) * 64 + chunk * 8
                                : conv_zero_page + chunk * 8;
       glds16_at(src, smem_base + j * 1024);
     }
@@ -576,18 +591,18 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
         sm += v;
         sq = fmaf(v, v, sq);
       }
-      const int g = (int)(((long long)(T0 / tiles_img) * a.DH * a.DW) / a.stat_rpg);
+      const int g = (int)(((long long)tn[0] * a.DH * a.DW) / a.stat_rpg);
       float* base = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 2) * 64 + c;
       atomicAdd(base, sm);
       atomicAdd(base + 64, sq);
     }
   }
-  for (int p = tid; p < 128 * 8; p += CV_THREADS) {
+  const size_t org[2] = {((size_t)tn[0] * a.DH + th0[0]) * a.DW + tw0[0], ((size_t)tn[1] * a.DH + th0[1]) * a.DW + tw0[1]};
+#pragma unroll
+  for (int q = 0; q < 128 * 8 / CV_THREADS; ++q) {
+    const int p = tid + q * CV_THREADS;
     const int row = p >> 3, ch = p & 7;
-    const int T = T0 + (row >> 6);
-    const int n = T / tiles_img, tr = T - n * tiles_img;
-    const int th = tr / tw_n, tw = tr - th * tw_n;
-    const size_t pix = ((size_t)n * a.DH + th * 8 + ((row >> 3) & 7)) * a.DW + tw * 8 + (row & 7);
+    const size_t pix = org[row >> 6] + (size_t)((row >> 3) & 7) * a.DW + (row & 7);
     uint4 v = *reinterpret_cast<const uint4*>(cv_smem + row * CS + ch * 16);
     if (a.res != nullptr) {
       const uint4 r4 = *reinterpret_cast<const uint4*>(a.res + pix * 64 + ch * 8);
@@ -600,6 +615,171 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
       v = make_uint4(o[0], o[1], o[2], o[3]);
     }
     *reinterpret_cast<uint4*>(a.dst + pix * 64 + ch * 8) = v;
+  }
+}
+
+// ------------------------------------------------------------- the stem as a patch-resident kernel
+// The stem (4x4 window over the 2x2 space-to-depth image, 16 channels, 64 outputs) through conv_igemm fetches, per
+// 128 output pixels, four 16-KB pixel tiles (every source pixel once per kernel row and four times along a row) and
+// the 32 KB of weights again: 96 KB of L2 -> LDS traffic and one cold start per 16 KB of output, 50 176 blocks of
+// ~7 us each (525 us where the output alone costs ~200).  Here a block is PERSISTENT (four per CU): it keeps its
+// share of the weights in REGISTERS (a wave's 32 outputs x 256 reduction elements = 16 fragments, 64 VGPRs) and
+// walks over pairs of 8x8 output tiles; per pair it DMAs the two 11x11-pixel source patches (7.7 KB; the next pair's
+// are in flight under the MFMAs and the epilogue of this one), and the sixteen taps only shift the fragment-read
+// address inside the patch.
+//   patch: [tile][row 0..10][col 0..11] x 32-byte pixels (col 11 is padding: a row pitch of 12 pixels = 384 B
+//   puts the two pixel rows of a fragment read in different halves of the 256-byte bank line; the 8 pixels x 2
+//   channel halves of a row are 256 contiguous bytes): conflict free without a swizzle.
+// The MFMA sequence (kernel row, then the two 32-element halves of it) and the fragments are those of
+// conv_igemm<128, 64, 2, 0>, so the results are bit-identical; the epilogue (bf16 tile through LDS, fused
+// BatchNorm sums) is conv3x3_patch's.
+constexpr int ST_PITCH = 12;
+constexpr int ST_PIX = 11 * ST_PITCH;              // pixel slots per patch
+constexpr int ST_PATCH_INSTR = 9;                  // 2 x 132 x 32 B = 8448 B -> nine 1-KB DMA instructions
+constexpr int ST_PATCH_BYTES = ST_PATCH_INSTR * 1024;
+constexpr int ST_CS = 64 * 2 + 16;                 // staged output row (64 channels bf16 + 16 B)
+constexpr int ST_LDS = 2 * ST_PATCH_BYTES + 128 * ST_CS;
+
+__global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs a, int npairs) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t cv_smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;  // 8x8 tile of the pair, 32-output half
+  const int tw_n = a.DW >> 3, tiles_img = (a.DH >> 3) * tw_n;
+  const uint32_t smem_base = lds_addr(cv_smem);
+  uint8_t* stage = cv_smem + 2 * ST_PATCH_BYTES;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // ---- this wave's weights: outputs wn*32 + j*16 + fr, reduction chunk r*8 + ks*4 + fg (8 elements each)
+  bf16x8_t wreg[2][4][2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks)
+        wreg[j][r][ks] = *reinterpret_cast<const bf16x8_t*>(a.wt + (size_t)(wn * 32 + j * 16 + fr) * 256 + (r * 8 + ks * 4 + fg) * 8);
+
+  // ---- patches of one tile pair: 9 instructions x 64 sixteen-byte pieces (piece = (pixel slot, channel half)).
+  // The lane's slot decode (tile, row, column, half) does not depend on the pair: it is done once, here; per pair
+  // only the two tile origins are decoded, from the wave-uniform pair index (the integer divisions by run-time
+  // image sizes, repeated per piece and per stored chunk, were most of this kernel's instruction count).
+  int pc_t[3], pc_py[3], pc_px[3], pc_half[3];
+  bool pc_on[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    const int piece = 64 * (wave + 4 * i) + lane;
+    const int gp = piece >> 1;
+    pc_half[i] = piece & 1;
+    pc_t[i] = gp >= ST_PIX ? 1 : 0;
+    const int pp = gp - pc_t[i] * ST_PIX;
+    pc_py[i] = pp / ST_PITCH;
+    pc_px[i] = pp - pc_py[i] * ST_PITCH;
+    pc_on[i] = gp < 2 * ST_PIX && pc_px[i] < 11;
+  }
+  auto tile_origin = [&](int T, int& n, int& h0, int& w0) {  // T is wave-uniform
+    T = __builtin_amdgcn_readfirstlane(T);
+    n = T / tiles_img;
+    const int tr = T - n * tiles_img;
+    const int th = tr / tw_n;
+    h0 = th * 8;
+    w0 = (tr - th * tw_n) * 8;
+  };
+  auto issue_patch = [&](int pair, uint32_t buf) {
+    int n[2], h0[2], w0[2];
+    tile_origin(pair * 2, n[0], h0[0], w0[0]);
+    tile_origin(pair * 2 + 1, n[1], h0[1], w0[1]);
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int j = wave + 4 * i;
+      if (j < ST_PATCH_INSTR) {
+        const int t = pc_t[i];
+        const int h = (t ? h0[1] : h0[0]) - a.pad + pc_py[i], w = (t ? w0[1] : w0[0]) - a.pad + pc_px[i];
+        const bool ok = pc_on[i] && (unsigned)h < (unsigned)a.SH && (unsigned)w < (unsigned)a.SW;
+        const uint16_t* src = ok ? a.src + ((size_t)((t ? n[1] : n[0]) * a.SH + h) * a.SW + w) * 16 + pc_half[i] * 8
+                                 : conv_zero_page + pc_half[i] * 8;
+        glds16_at(src, buf + j * 1024);
+      }
+    }
+  };
+
+  const int dy = fr >> 3, dx = fr & 7;
+  // pixel fragment: pixel (2 i + dy + r, dx + 2 ks + (fg >> 1)) of the patch, channel half fg & 1
+  const uint32_t xbase = (uint32_t)((wm * ST_PIX + dy * ST_PITCH + dx + (fg >> 1)) * 32 + (fg & 1) * 16);
+
+  int pair = blockIdx.x;
+  if (pair < npairs) issue_patch(pair, smem_base);
+  for (int it = 0; pair < npairs; pair += gridDim.x, ++it) {
+    // the patches of this pair have landed (this wave's pieces; the barrier: everyone's), the previous pair's
+    // staged tile has been read by every wave.  Vector-memory operations retire in issue order, so the counted
+    // wait leaves the previous pair's 4 output stores (and 2 statistics atomics) per lane in flight: they were issued
+    // AFTER these patch fetches (waiting for them too cost 0.5 us per pair and block).
+    if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    else if (a.stat != nullptr) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (pair + (int)gridDim.x < npairs) issue_patch(pair + gridDim.x, smem_base + ((it + 1) & 1) * ST_PATCH_BYTES);
+    const uint8_t* pb = cv_smem + (it & 1) * ST_PATCH_BYTES;
+
+    f32x4_t acc[2][4];
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) acc[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        bf16x8_t xf[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          xf[i] = *reinterpret_cast<const bf16x8_t*>(pb + xbase + ((2 * i + r) * ST_PITCH + 2 * ks) * 32);
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int i = 0; i < 4; ++i)
+            acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wreg[j][r][ks], xf[i], acc[j][i], 0, 0, 0);
+      }
+    }
+
+    // ---- epilogue: accumulators -> bf16 tile in LDS ([pixel][channel], rows padded by 16 B) -> HBM
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int pix = wm * 64 + i * 16 + fr;  // = wm*64 + (2i + dy)*8 + dx
+        const int ch = wn * 32 + j * 16 + fg * 4;
+        const uint2 v = make_uint2(pack_bf2(acc[j][i][0], acc[j][i][1]), pack_bf2(acc[j][i][2], acc[j][i][3]));
+        *reinterpret_cast<uint2*>(stage + pix * ST_CS + ch * 2) = v;
+      }
+    __syncthreads();
+    const int T0 = pair * 2;
+    if (a.stat != nullptr) {
+      const int c = tid & 63, part = tid >> 6;
+      float sm = 0.f, sq = 0.f;
+      for (int rr = part * 32; rr < (part + 1) * 32; ++rr) {
+        const float v = bf2f(*reinterpret_cast<const uint16_t*>(stage + rr * ST_CS + c * 2));
+        sm += v;
+        sq = fmaf(v, v, sq);
+      }
+      const int g = __builtin_amdgcn_readfirstlane((int)(((long long)(T0 / tiles_img) * a.DH * a.DW) / a.stat_rpg));
+      float* base = a.stat + ((size_t)(g * a.stat_nb + (pair % a.stat_nb)) * 2) * 64 + c;
+      atomicAdd(base, sm);
+      atomicAdd(base + 64, sq);
+    }
+    {
+      int n[2], h0[2], w0[2];
+      tile_origin(T0, n[0], h0[0], w0[0]);
+      tile_origin(T0 + 1, n[1], h0[1], w0[1]);
+      const size_t org[2] = {((size_t)n[0] * a.DH + h0[0]) * a.DW + w0[0], ((size_t)n[1] * a.DH + h0[1]) * a.DW + w0[1]};
+#pragma unroll
+      for (int q = 0; q < 128 * 8 / CV_THREADS; ++q) {
+        const int p = tid + q * CV_THREADS;
+        const int row = p >> 3, ch = p & 7;
+        const size_t pix = org[row >> 6] + (size_t)((row >> 3) & 7) * a.DW + (row & 7);
+        *reinterpret_cast<uint4*>(a.dst + pix * 64 + ch * 8) = *reinterpret_cast<const uint4*>(stage + row * ST_CS + ch * 16);
+      }
+    }
   }
 }
 
@@ -877,6 +1057,21 @@ inline bool conv_patch_ok(const ConvArgs& a) {
   return true;
 }
 
+// The space-to-depth stem in its patch-resident form: 4x4 window, stride 1, 16 source channels, 64 outputs, output
+// the size of the source, sides multiples of 8, an even number of 8x8 tiles (per statistics group too).
+inline bool stem_patch_ok(const ConvArgs& a) {
+  if (!conv_patch_enabled()) return false;
+  if (a.SC != 16 || a.DC != 64 || a.R != 4 || a.S != 4 || a.stride != 1 || a.pad < 0 || a.pad > 3) return false;
+  if (a.SH != a.DH || a.SW != a.DW || (a.DH & 7) || (a.DW & 7) || a.bias != nullptr || a.res != nullptr) return false;
+  const long long tiles = (long long)a.N * (a.DH >> 3) * (a.DW >> 3);
+  if (tiles & 1) return false;
+  if (a.stat != nullptr) {
+    if (a.stat_rpg % 128 != 0) return false;
+    if (a.stat_rpg % (a.DH * a.DW) != 0) return false;
+  }
+  return true;
+}
+
 template <int MODE>
 int launch_patch(const ConvArgs& a, hipStream_t st) {
   static bool attr = false;
@@ -990,6 +1185,8 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   a.dst = static_cast<uint16_t*>(y);
   a.N = N; a.SH = H; a.SW = W; a.SC = C; a.DH = P; a.DW = Q; a.DC = K;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.M = N * P * Q;
+  a.d_dhw = wm_div_make((uint32_t)(P * Q)); a.d_dw = wm_div_make((uint32_t)Q);
+  a.d_h2w2 = wm_div_make(1); a.d_w2 = wm_div_make(1);
   a.stat = stat; a.stat_nb = stat_nb; a.stat_rpg = stat_rpg;
   a.res = static_cast<const uint16_t*>(residual);
   a.bias = bias;
@@ -1000,6 +1197,23 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   if (C == 16) {
     WM_REQUIRE(bias == nullptr && residual == nullptr, WM_EUNSUPPORTED);
     a.nkt = R;
+    if (stem_patch_ok(a)) {
+      const int npairs = (int)((long long)a.N * (a.DH >> 3) * (a.DW >> 3) / 2);
+      static int slots = 0;
+      if (slots == 0) {
+        const int rc2 = set_lds(&conv_stem_patch, ST_LDS);
+        if (rc2 != WM_OK) return rc2;
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+          cus = 256;
+        const char* e = getenv("WM_STEM_BLOCKS_PER_CU");
+        slots = cus * (e ? atoi(e) : 3);  // 36 KB of LDS, 168 registers per lane: three resident blocks per CU
+      }
+      conv_stem_patch<<<npairs < slots ? npairs : slots, CV_THREADS, ST_LDS, st>>>(a, npairs);
+      WM_LAUNCH_CHECK();
+      return WM_OK;
+    }
     // (256-pixel tiles for the 64-channel stem are 7 % faster alone but 10 % slower inside the training
     // step, where the epilogue also accumulates the BatchNorm statistics: 564 vs 509 us)
     return K % 128 == 0 ? launch_igemm<128, 128, 2, 0>(a, st) : launch_igemm<128, 64, 2, 0>(a, st);
@@ -1061,6 +1275,9 @@ static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const v
   a.dst = static_cast<uint16_t*>(dx);
   a.N = N; a.SH = P; a.SW = Q; a.SC = K; a.DH = H; a.DW = W; a.DC = C;
   a.R = R; a.S = S; a.stride = stride; a.pad = pad; a.M = N * H * W;
+  a.d_dhw = wm_div_make((uint32_t)(H * W)); a.d_dw = wm_div_make((uint32_t)W);
+  a.d_h2w2 = wm_div_make((uint32_t)((H >> 1) * (W >> 1) > 0 ? (H >> 1) * (W >> 1) : 1));
+  a.d_w2 = wm_div_make((uint32_t)((W >> 1) > 0 ? (W >> 1) : 1));
   a.stat = nullptr; a.stat_nb = 0; a.stat_rpg = 1;
   a.res = static_cast<const uint16_t*>(residual);
   a.nkt = R * S * (K / 64);

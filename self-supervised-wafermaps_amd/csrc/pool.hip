@@ -75,18 +75,20 @@ __global__ __launch_bounds__(PL_THREADS) void bn_relu_maxpool_fwd(const uint16_t
                                                                   int imgs_per_group,
                                                                   uint16_t* __restrict__ y,
                                                                   uint8_t* __restrict__ idx,
-                                                                  uint16_t* __restrict__ xsel) {
+                                                                  uint16_t* __restrict__ xsel, const WmDiv d_cpr,
+                                                                  const WmDiv d_q, const WmDiv d_p, const WmDiv d_ipg) {
   // 32-bit index arithmetic (the host checks N*P*Q*C/8 < 2^31): the kernel is VALU-bound and 64-bit
   // divisions by run-time values cost ~150 instructions per item
   const uint32_t cpr = (uint32_t)C >> 3;
   const uint32_t total = (uint32_t)N * P * Q * cpr;
   for (uint32_t t = blockIdx.x * PL_THREADS + threadIdx.x; t < total; t += gridDim.x * PL_THREADS) {
-    const int c0 = (int)(t % cpr) * 8;
-    uint32_t pix = t / cpr;
-    const int q = (int)(pix % (uint32_t)Q);
-    pix /= (uint32_t)Q;
-    const int p = (int)(pix % (uint32_t)P), n = (int)(pix / (uint32_t)P);
-    const int g = n / imgs_per_group;
+    uint32_t rc, rq, rp;
+    uint32_t pix = wm_divmod(t, d_cpr, rc);
+    const int c0 = (int)rc * 8;
+    pix = wm_divmod(pix, d_q, rq);
+    const int n = (int)wm_divmod(pix, d_p, rp);
+    const int q = (int)rq, p = (int)rp;
+    const int g = (int)wm_div((uint32_t)n, d_ipg);
     float sc[8], sh[8], bx[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -245,7 +247,8 @@ extern "C" int wm_bn_relu_maxpool3x3s2_fwd(const void* x, const float* scale, co
   const int P = (H + 2 - 3) / 2 + 1, Q = (W + 2 - 3) / 2 + 1;
   bn_relu_maxpool_fwd<<<grid_for((long long)N * P * Q * (C >> 3)), PL_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
       static_cast<const uint16_t*>(x), scale, shift, N, H, W, C, P, Q, N / G, static_cast<uint16_t*>(y),
-      static_cast<uint8_t*>(idx), static_cast<uint16_t*>(xsel));
+      static_cast<uint8_t*>(idx), static_cast<uint16_t*>(xsel), wm_div_make((uint32_t)(C >> 3)), wm_div_make((uint32_t)Q),
+      wm_div_make((uint32_t)P), wm_div_make((uint32_t)(N / G)));
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
