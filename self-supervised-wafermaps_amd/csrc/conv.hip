@@ -640,7 +640,8 @@ constexpr int ST_PATCH_BYTES = ST_PATCH_INSTR * 1024;
 constexpr int ST_CS = 64 * 2 + 16;                 // staged output row (64 channels bf16 + 16 B)
 constexpr int ST_LDS = 2 * ST_PATCH_BYTES + 128 * ST_CS;
 
-__global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs a, int npairs) {
+__global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs a, int npairs, const WmDiv d_timg,
+                                                                 const WmDiv d_twn) {
   extern __shared__ __attribute__((aligned(16))) uint8_t cv_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -679,11 +680,10 @@ __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs 
   }
   auto tile_origin = [&](int T, int& n, int& h0, int& w0) {  // T is wave-uniform
     T = __builtin_amdgcn_readfirstlane(T);
-    n = T / tiles_img;
-    const int tr = T - n * tiles_img;
-    const int th = tr / tw_n;
-    h0 = th * 8;
-    w0 = (tr - th * tw_n) * 8;
+    uint32_t tr, tw;
+    n = (int)wm_divmod((uint32_t)T, d_timg, tr);
+    h0 = (int)wm_divmod(tr, d_twn, tw) * 8;
+    w0 = (int)tw * 8;
   };
   auto issue_patch = [&](int pair, uint32_t buf) {
     int n[2], h0[2], w0[2];
@@ -762,7 +762,7 @@ __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs 
         sm += v;
         sq = fmaf(v, v, sq);
       }
-      const int g = __builtin_amdgcn_readfirstlane((int)(((long long)(T0 / tiles_img) * a.DH * a.DW) / a.stat_rpg));
+      const int g = __builtin_amdgcn_readfirstlane((int)(((long long)wm_div((uint32_t)T0, d_timg) * a.DH * a.DW) / a.stat_rpg));
       float* base = a.stat + ((size_t)(g * a.stat_nb + (pair % a.stat_nb)) * 2) * 64 + c;
       atomicAdd(base, sm);
       atomicAdd(base + 64, sq);
@@ -1210,7 +1210,8 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
         const char* e = getenv("WM_STEM_BLOCKS_PER_CU");
         slots = cus * (e ? atoi(e) : 3);  // 36 KB of LDS, 168 registers per lane: three resident blocks per CU
       }
-      conv_stem_patch<<<npairs < slots ? npairs : slots, CV_THREADS, ST_LDS, st>>>(a, npairs);
+      conv_stem_patch<<<npairs < slots ? npairs : slots, CV_THREADS, ST_LDS, st>>>(
+          a, npairs, wm_div_make((uint32_t)((a.DH >> 3) * (a.DW >> 3))), wm_div_make((uint32_t)(a.DW >> 3)));
       WM_LAUNCH_CHECK();
       return WM_OK;
     }
