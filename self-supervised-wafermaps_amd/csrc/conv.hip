@@ -343,6 +343,17 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
       // (act 2 never comes with a residual: the same registers carry the pre-activation chunk)
       if (a.act == 2 && m0 + row < a.M) rv[it] = *reinterpret_cast<const uint4*>(a.pre_in + pix * a.DC + n0 + ch * 8);
     }
+    // the lane's eight bias values: its chunk column (tid % CPR) is the same in every pass (CV_THREADS % CPR == 0),
+    // and inside the loop the loads could not move above the previous pass's stores (they may alias as far as hipcc
+    // knows): eight dependent L2 round trips per tile
+    static_assert(CV_THREADS % CPR == 0, "chunk column constant per lane");
+    float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
+    if constexpr (MODE == 0) {
+      if (a.bias != nullptr) {
+        b0 = *reinterpret_cast<const float4*>(a.bias + n0 + (tid % CPR) * 8);
+        b1 = *reinterpret_cast<const float4*>(a.bias + n0 + (tid % CPR) * 8 + 4);
+      }
+    }
   #pragma unroll
     for (int it = 0; it < NIT; ++it) {
       const int p = tid + it * CV_THREADS;
@@ -352,8 +363,6 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
         uint4 v = *reinterpret_cast<const uint4*>(cv_smem + row * CS + ch * 16);
         if constexpr (MODE == 0) {
           if (a.bias != nullptr) {
-            const float4 b0 = *reinterpret_cast<const float4*>(a.bias + n0 + ch * 8);
-            const float4 b1 = *reinterpret_cast<const float4*>(a.bias + n0 + ch * 8 + 4);
             v = make_uint4(pack_bf2(bf2f((uint16_t)(v.x & 0xffff)) + b0.x, bf2f((uint16_t)(v.x >> 16)) + b0.y),
                            pack_bf2(bf2f((uint16_t)(v.y & 0xffff)) + b0.z, bf2f((uint16_t)(v.y >> 16)) + b0.w),
                            pack_bf2(bf2f((uint16_t)(v.z & 0xffff)) + b1.x, bf2f((uint16_t)(v.z >> 16)) + b1.y),
