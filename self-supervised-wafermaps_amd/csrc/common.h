@@ -177,6 +177,7 @@ struct WmDiv {
 };
 static inline WmDiv wm_div_make(uint32_t d) {
   WmDiv v;
+  if (d == 0) d = 1;  // (never a valid divisor here; keeps the host side total)
   uint32_t l = 0;
   while ((1ull << l) < d) ++l;
   v.l = l;

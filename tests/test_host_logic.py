@@ -241,3 +241,27 @@ def test_ingest_reads_a_real_reference_split():
     vals = np.unique(store.bytes_np)
     assert set(vals.tolist()) <= {0, 128, 255}
     assert 1 <= store.heights_np.min() and store.heights_np.max() <= 256
+
+
+def test_multiply_high_division_identity():
+    """common.h WmDiv: floor(x / d) == (umulhi(x, m) + x) >> l with l = ceil(log2 d), m = ceil(2^(32+l) / d) - 2^32,
+    for every x < 2^31 -- the index decode of the tile kernels and the pooled BatchNorm kernels relies on it.  Checked
+    here with the device's 32-bit wrap-around arithmetic on the divisors those kernels see and on random ones."""
+    rng = np.random.default_rng(0)
+    divisors = [1, 2, 3, 5, 7, 8, 12, 14, 16, 24, 28, 49, 56, 64, 96, 112, 196, 224, 256, 784, 3136, 12544, 50176,
+                65535, 65536, 1000003, (1 << 30) + 1] + [int(v) for v in rng.integers(1, 1 << 20, 40)]
+    xs = np.concatenate([np.arange(0, 70000, dtype=np.uint64), rng.integers(0, 1 << 31, 200000).astype(np.uint64),
+                         np.array([(1 << 31) - 1, (1 << 31) - 2], dtype=np.uint64)])
+    for d in divisors:
+        l = 0
+        while (1 << l) < d:
+            l += 1
+        m = ((1 << (32 + l)) + d - 1) // d - (1 << 32)
+        assert 0 <= m < (1 << 32)
+        hi = (xs * np.uint64(m)) >> np.uint64(32)
+        q = ((hi + xs) & np.uint64(0xFFFFFFFF)) >> np.uint64(l)   # the device adds in 32 bits
+        edge = np.array([d * 1000 - 1, d * 1000], dtype=np.uint64)
+        edge = edge[edge < (1 << 31)]
+        assert np.array_equal(q, xs // np.uint64(d)), d
+        hi_e = (edge * np.uint64(m)) >> np.uint64(32)
+        assert np.array_equal(((hi_e + edge) & np.uint64(0xFFFFFFFF)) >> np.uint64(l), edge // np.uint64(d)), d
