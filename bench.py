@@ -49,8 +49,8 @@ HBM_PEAK_GBS = 8000.0           # HBM3E, same table
 # WRITE_SIZE in separate passes of this script, FETCH_SIZE doubled per the gfx950 correction (calibrated on
 # sgd_step).  A PMC pass cannot run inside the timed region: this is the committed measurement of the file named
 # below, not a live one.  Algorithmic bytes (every operand once): 230 MB per launch.
-CONV_TRAFFIC_BYTES_PER_LAUNCH = 523.5e6
-CONV_TRAFFIC_SOURCE = "profiles/r02_hbm_traffic_simclr_r18.md (rocprofv3 --pmc, separate passes; 260 launches of 4 steps)"
+CONV_TRAFFIC_BYTES_PER_LAUNCH = 510.1e6
+CONV_TRAFFIC_SOURCE = "profiles/r02_hbm_traffic_simclr_r18_v2.md (rocprofv3 --pmc, separate passes; 260 launches of 4 steps)"
 R18_GFLOP_PER_SAMPLE = 21.76    # ResNet-18 fwd 3.627 GFLOP x 3 (fwd+bwd) x 2 views
 KNN_N, KNN_D, KNN_K = 811457, 128, 8
 
