@@ -119,7 +119,9 @@ def test_conv_weight_cache_follows_updates():
     _close(y2, (2 * y1).cpu(), what="after in-place update")
 
 
-@pytest.mark.parametrize("n,hw", [(2, 224), (3, 64)])
+# (2, 224), (3, 64), (5, 32): an even number of 8x8 output tiles -> the persistent patch-resident stem kernel;
+# (1, 48): 9 tiles -> conv_igemm<128,64,2,0> (the two are bit-identical: tools/probes/stem_patch_check.py)
+@pytest.mark.parametrize("n,hw", [(2, 224), (3, 64), (5, 32), (1, 48)])
 def test_stem_conv(n, hw):
     from ssl_wafermap_amd import ops
 
