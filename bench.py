@@ -182,11 +182,14 @@ def knn_object(dev):
             nb = 48 if bq <= 256 else 12
             qq = bank[2000:2000 + nb * bq].contiguous()
             F.knn_topk_batched(qq, bank, KNN_K, batch=bq)
-            a.record()
-            F.knn_topk_batched(qq, bank, KNN_K, batch=bq)
-            b.record()
             torch.cuda.synchronize()
-            us_p = a.elapsed_time(b) * 1e3 / nb
+            us_p = float("inf")
+            for _ in range(3):  # best of three calls of nb batches each (one call is 0.5 - 4 ms: host jitter shows)
+                a.record()
+                F.knn_topk_batched(qq, bank, KNN_K, batch=bq)
+                b.record()
+                torch.cuda.synchronize()
+                us_p = min(us_p, a.elapsed_time(b) * 1e3 / nb)
             out["rows"].append({"dtype": dtype, "queries": bq, "us_per_batch": round(us, 1),
                                 "pipelined_us_per_batch": round(us_p, 1),
                                 "pipelined_hbm_frac": round(bytes_ / us_p / 1e3 / HBM_PEAK_GBS, 3),
