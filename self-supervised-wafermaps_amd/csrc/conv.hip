@@ -42,7 +42,6 @@ namespace {
 #endif
 
 constexpr int CV_THREADS = 256;
-constexpr int CV_BM = 128;
 constexpr int CV_ROW = 128;  // bytes per LDS row of an operand tile (64 bf16)
 
 struct ConvArgs {
@@ -112,7 +111,6 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   int bh[NR], bw[NR], nb[NR];
   bool mv[NR];
   const uint16_t* p0[NR];
-  const int dhw = a.DH * a.DW;
   // MODE 2: parity class of this tile and its valid-tap grid
   int r0 = 0, s0 = 0, nr = 0, ns = 0, nkt = a.nkt;
   if constexpr (MODE == 2) {
@@ -124,7 +122,6 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
     nr = r0 < a.R ? (a.R - r0 + 1) >> 1 : 0;
     ns = s0 < a.S ? (a.S - s0 + 1) >> 1 : 0;
     nkt = nr * ns * (a.SC >> 6);
-    const int h2w2 = (a.DH >> 1) * (a.DW >> 1);
 #pragma unroll
     for (int i = 0; i < NR; ++i) {
       const int m = m0 + rowl + 32 * i - pc * cls;  // index inside the class
@@ -329,8 +326,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
         const int cls = a.M >> 2;
         const int pc = m0 / cls;
         const int m = m0 + row - pc * cls;
-        const int h2w2 = (a.DH >> 1) * (a.DW >> 1);
-        uint32_t urem2, uw2;
+            uint32_t urem2, uw2;
         const int n = (int)wm_divmod((uint32_t)m, a.d_h2w2, urem2);
         const int h2 = (int)wm_divmod(urem2, a.d_w2, uw2), w2 = (int)uw2;
         pix = ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
@@ -409,8 +405,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
         const int cls = a.M >> 2;
         const int pc = m0 / cls;
         const int m = m0 + row - pc * cls;
-        const int h2w2 = (a.DH >> 1) * (a.DW >> 1);
-        uint32_t urem2, uw2;
+            uint32_t urem2, uw2;
         const int n = (int)wm_divmod((uint32_t)m, a.d_h2w2, urem2);
         const int h2 = (int)wm_divmod(urem2, a.d_w2, uw2), w2 = (int)uw2;
         pix = ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
@@ -588,7 +583,6 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
       *reinterpret_cast<uint2*>(cv_smem + pix * CS + ch * 2) = v;
     }
   __syncthreads();
-  const int T0 = blockIdx.x * 2;
   if constexpr (MODE == 0) {
     if (a.stat != nullptr) {
       // column sums of the staged tile: 64 channels x 4 row slices; both 8x8 tiles lie in one statistics
@@ -655,7 +649,6 @@ __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;  // 8x8 tile of the pair, 32-output half
-  const int tw_n = a.DW >> 3, tiles_img = (a.DH >> 3) * tw_n;
   const uint32_t smem_base = lds_addr(cv_smem);
   uint8_t* stage = cv_smem + 2 * ST_PATCH_BYTES;
   const int fr = lane & 15, fg = lane >> 4;
