@@ -10,6 +10,7 @@ BatchNorm statistics kept per view (`ops.bn_groups`), which is exactly what per-
 from __future__ import annotations
 
 import copy
+import os
 
 import torch
 
@@ -83,11 +84,16 @@ class DINOViT(KNNBenchmarkModule):
             g = self._stack(views, 0, 2)
             yt = self.teacher_backbone(g).flatten(start_dim=1)
             teacher_out = self.teacher_head(yt)
-        feats = []
-        for i, j in self._group_by_size(views):
-            with ops.bn_groups(j - i):
-                feats.append(self.backbone(self._stack(views, i, j)).flatten(start_dim=1))
-        y = feats[0] if len(feats) == 1 else torch.cat(feats, dim=0)
+        groups = self._group_by_size(views)
+        if len(groups) > 1 and hasattr(self.backbone, "forward_multi") and os.environ.get("WM_DINO_MERGE", "1") != "0":
+            # ViT backbone: all resolutions through the blocks together (one launch per per-token layer)
+            y = self.backbone.forward_multi([self._stack(views, i, j) for i, j in groups]).flatten(start_dim=1)
+        else:
+            feats = []
+            for i, j in groups:
+                with ops.bn_groups(j - i):
+                    feats.append(self.backbone(self._stack(views, i, j)).flatten(start_dim=1))
+            y = feats[0] if len(feats) == 1 else torch.cat(feats, dim=0)
         if self.log_rep_std:
             self.log("rep_std", debug.std_of_l2_normalized(y[-b:]))
         with ops.bn_groups(n_views):

@@ -29,9 +29,12 @@ class Attention(nn.Module):
         self.qkv = hnn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = hnn.Linear(dim, dim, bias=True)
 
-    def forward(self, x, batch: int, seq: int, residual):
+    def forward(self, x, batch: int, seq: int, residual, segments=None):
         qkv = self.qkv(x)
-        a = vit_ops.attention(qkv, batch, seq, self.num_heads, self.scale)
+        if segments is not None:  # several (batch, seq) groups row-concatenated in x
+            a = vit_ops.attention_segments(qkv, segments, self.num_heads, self.scale)
+        else:
+            a = vit_ops.attention(qkv, batch, seq, self.num_heads, self.scale)
         return self.proj(a, residual=residual)
 
 
@@ -57,9 +60,9 @@ class Block(nn.Module):
         self.norm2 = hnn.LayerNorm(dim, eps=eps)
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
-    def forward(self, x, batch: int, seq: int):
+    def forward(self, x, batch: int, seq: int, segments=None):
         h, skip = self.norm1.forward_skip(x)
-        x = self.attn(h, batch, seq, residual=skip)
+        x = self.attn(h, batch, seq, residual=skip, segments=segments)
         h, skip = self.norm2.forward_skip(x)
         return self.mlp(h, residual=skip)
 
@@ -145,6 +148,29 @@ class VisionTransformer(nn.Module):
         g = s // p
         patches = self.patch_embed(x)
         return vit_ops.tokens_assemble(patches, self.cls_token, self.pos_for(g), n, g * g), n, g * g + 1
+
+    def forward_multi(self, xs):
+        """A list of image batches of DIFFERENT resolutions (DINO's multi-crop student: [2B, 3, 224, 224] and
+        [6B, 3, 96, 96]) -> class-token features of all of them, [sum N_g, D] in list order.  dino runs the backbone
+        once per resolution; here the token rows of all groups are concatenated, so every per-token layer (LayerNorm,
+        the four Linear layers of a block and their weight gradients) is ONE launch over all rows, and only the attention
+        itself runs per group (vit_ops.attention_segments).  Per-row arithmetic is unchanged."""
+        toks, segments = [], []
+        for x in xs:
+            tok, n, seq = self.prepare_tokens(x)
+            toks.append(tok)
+            segments.append((n, seq))
+        if len(toks) == 1:
+            return self.forward(xs[0])
+        tok = torch.cat(toks, dim=0)
+        for blk in self.blocks:
+            tok = blk(tok, 0, 0, segments=segments)
+        cls, off = [], 0
+        for n, seq in segments:
+            idx = torch.zeros((n, 1), dtype=torch.int64, device=tok.device)
+            cls.append(vit_ops.gather_rows(tok[off:off + n * seq], idx, n, seq))
+            off += n * seq
+        return self.norm(torch.cat(cls, dim=0))
 
     def forward(self, x):
         """images [N, 3, S, S] -> class-token features [N, D] (bf16), as dino's forward()."""

@@ -360,6 +360,58 @@ def attention(qkv: torch.Tensor, batch: int, seq: int, heads: int, scale: Option
                             float(head_dim ** -0.5 if scale is None else scale))
 
 
+class _AttentionSegments(torch.autograd.Function):
+    """Attention over SEGMENTS of one row-concatenated token tensor: segment g holds b_g sequences of s_g tokens (DINO's
+    multi-crop student: 2 x B global crops of 197 tokens and 6 x B local crops of 37).  One attention launch per
+    segment, straight into / out of row slices of the shared buffers, so every other layer of the block (LayerNorm,
+    qkv / proj / MLP GEMMs and their weight gradients) runs ONCE over all rows instead of once per resolution."""
+
+    @staticmethod
+    def forward(ctx, qkv, segments, h, hd, scale):
+        _need_cuda(qkv, "attention_segments")
+        qkv = _bf16_rows(qkv)
+        rows = sum(b * s for b, s in segments)
+        if qkv.shape != (rows, 3 * h * hd):
+            raise ValueError(f"attention_segments: qkv {tuple(qkv.shape)} vs segments {segments} H={h} head_dim={hd}")
+        out = torch.empty((rows, h * hd), dtype=torch.bfloat16, device=qkv.device)
+        lses, off = [], 0
+        lib = _lib.load()
+        for b, s in segments:
+            lse = torch.empty((b, h, s), dtype=torch.float32, device=qkv.device)
+            check(ops._run("attn_fwd", 4.0 * b * h * s * s * hd, lib.wm_attention_fwd, ptr(qkv[off:off + b * s]), b, s, h,
+                           hd, scale, ptr(out[off:off + b * s]), ptr(lse), stream_ptr()), "wm_attention_fwd")
+            lses.append(lse)
+            off += b * s
+        ctx.save_for_backward(qkv, out, *lses)
+        ctx.geom = (tuple(segments), h, hd, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        qkv, out, *lses = ctx.saved_tensors
+        segments, h, hd, scale = ctx.geom
+        dout = _bf16_rows(dout)
+        dqkv = torch.empty_like(qkv)
+        lib = _lib.load()
+        off = 0
+        for (b, s), lse in zip(segments, lses):
+            sl = slice(off, off + b * s)
+            check(ops._run("attn_bwd", 8.0 * b * h * s * s * hd, lib.wm_attention_bwd, ptr(qkv[sl]), ptr(out[sl]),
+                           ptr(dout[sl]), ptr(lse), b, s, h, hd, scale, ptr(dqkv[sl]), stream_ptr()), "wm_attention_bwd")
+            off += b * s
+        return dqkv, None, None, None, None
+
+
+def attention_segments(qkv: torch.Tensor, segments, heads: int, scale: Optional[float] = None,
+                       head_dim: int = 64) -> torch.Tensor:
+    """attention() over row-concatenated segments [(batch, seq), ...] of one qkv tensor."""
+    segments = [(int(b), int(s)) for b, s in segments]
+    if len(segments) == 1:
+        return attention(qkv, segments[0][0], segments[0][1], heads, scale, head_dim)
+    return _AttentionSegments.apply(qkv, segments, int(heads), int(head_dim),
+                                    float(head_dim ** -0.5 if scale is None else scale))
+
+
 class _PatchEmbed(torch.autograd.Function):
     """Conv2d(3, D, kernel = stride = p) as patchify + GEMM; images need no gradient."""
 

@@ -647,3 +647,38 @@ def test_pos_for_matches_oracle_interpolation():
         want = ov.pos_embed_for(pe, g_new)
         assert got.shape == (1, g_new * g_new + 1, 64)
         torch.testing.assert_close(got.detach().cpu(), want, rtol=1e-5, atol=1e-5)
+
+
+def test_forward_multi_equals_per_resolution_forward():
+    """VisionTransformer.forward_multi (all resolutions' token rows through the blocks together, attention per
+    segment) gives the per-resolution forward's features row for row (same per-row arithmetic: bit-identical), and
+    parameter gradients that agree to the split-K atomics' summation order."""
+    from ssl_wafermap_amd.models.vit import vit_tiny
+
+    torch.manual_seed(11)
+    m = vit_tiny(patch_size=16)
+    for blk in list(m.blocks)[2:]:
+        pass
+    m.blocks = torch.nn.ModuleList(list(m.blocks)[:2])
+    m = m.to(DEV)
+    g = torch.Generator().manual_seed(5)
+    xa = torch.randn(4, 3, 224, 224, generator=g).to(DEV)
+    xb = torch.randn(6, 3, 96, 96, generator=g).to(DEV)
+    dy = torch.randn(10, 192, generator=g).to(DEV)
+
+    def run(merged):
+        for p in m.parameters():
+            p.grad = None
+        y = m.forward_multi([xa, xb]) if merged else torch.cat([m(xa), m(xb)], dim=0)
+        (y.float() * dy).sum().backward()
+        return y.detach().clone(), {n: p.grad.detach().clone() for n, p in m.named_parameters() if p.grad is not None}
+
+    y1, g1 = run(True)
+    y0, g0 = run(False)
+    assert y1.shape == (10, 192)
+    assert torch.equal(y1, y0)
+    assert set(g1) == set(g0)
+    for n in g0:
+        a, b = g1[n].float().flatten(), g0[n].float().flatten()
+        assert float(F.cosine_similarity(a, b, dim=0)) > 0.9995, n
+        assert float((a - b).norm() / (b.norm() + 1e-12)) < 2e-2, n
