@@ -1,4 +1,5 @@
 // Checks the DPP / lane-swap reductions of csrc/common.h against plain sums on one wave.
+// Build and run on the GPU box: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/probes/dpp_reduce_probe.hip -o tools/probes/dpp_reduce_probe && ./tools/probes/dpp_reduce_probe
 #include "../../self-supervised-wafermaps_amd/csrc/common.h"
 #include <cstdio>
 #include <vector>
