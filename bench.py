@@ -487,6 +487,8 @@ def main():
         except Exception as e:  # capture is an optimisation: report and continue eagerly
             print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
             graphed = None
+            # a failed capture leaves torch's side stream current (torch.cuda.graph's exit raised before restoring it)
+            torch.cuda.set_stream(torch.cuda.default_stream(dev))
 
     def step(i):
         if graphed is None:

@@ -187,5 +187,8 @@ class GraphedTrainStep:
                 hi = lo
             if sync is not None:
                 sync.wait()
+        hook = getattr(self.model, "post_graph_step", None)
+        if hook is not None:   # host-side collectives a model keeps out of the captured graph (DINO: the centre)
+            hook()
         self.opt.step()
         return self.loss

@@ -554,6 +554,8 @@ class DINOLoss(nn.Module):
         self.student_temp = student_temp
         self.center_momentum = center_momentum
         self.register_buffer("center", torch.zeros(1, 1, output_dim))
+        self._center_mean = None      # graph-replayed data-parallel steps: local batch centre awaiting its all-reduce
+        self._center_pending = False
         self.teacher_temp_schedule = torch.linspace(warmup_teacher_temp, teacher_temp, warmup_teacher_temp_epochs)
 
     def forward(self, teacher_out, student_out, epoch: int, batch: int = None):
@@ -576,12 +578,32 @@ class DINOLoss(nn.Module):
         return loss
 
     @torch.no_grad()
+    def finish_center_update(self) -> None:
+        """The deferred half of update_center for graph-replayed data-parallel steps (see there)."""
+        if not getattr(self, "_center_pending", False) or self._center_mean is None:
+            return
+        mean = self._center_mean.clone()
+        dist.all_reduce(mean)
+        mean /= _world()
+        self.center.mul_(self.center_momentum).add_(mean, alpha=1 - self.center_momentum)
+
+    @torch.no_grad()
     def update_center(self, teacher: torch.Tensor) -> None:
         from . import vit_ops
 
         if _world() > 1:
             # lightly: batch_center = mean over (views, batch), all-reduced and divided by world size
             mean = teacher.float().mean(dim=0, keepdim=True)
+            if torch.cuda.is_available() and teacher.is_cuda and torch.cuda.is_current_stream_capturing():
+                # inside a hipGraph capture (graph.GraphedTrainStep): the collective cannot be part of the graph (gloo
+                # is a host call; RCCL inside a captured step is not relied on).  The local mean is parked in a
+                # persistent buffer by the graph; finish_center_update() -- called by the step after the replay --
+                # does the exchange and the moving average.
+                if self._center_mean is None:
+                    self._center_mean = torch.zeros_like(self.center)
+                self._center_mean.copy_(mean.view_as(self.center))
+                self._center_pending = True
+                return
             dist.all_reduce(mean)
             mean /= _world()
             self.center.mul_(self.center_momentum).add_(mean.view_as(self.center), alpha=1 - self.center_momentum)

@@ -102,6 +102,10 @@ class DINOViT(KNNBenchmarkModule):
         self.log("train_loss_ssl", loss)
         return loss
 
+    def post_graph_step(self):
+        """graph.GraphedTrainStep calls this after the replay: the cross-rank part of the DINO centre update."""
+        self.criterion.finish_center_update()
+
     def configure_optimizers(self):
         param = list(self.backbone.parameters()) + list(self.head.parameters())
         opt = optim.AdamW(param, lr=1.5e-4 * self.lr_factor, weight_decay=0.05, betas=(0.9, 0.95))
