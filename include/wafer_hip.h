@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 2
+#define WM_ABI_VERSION 3
 
 /* error codes */
 #define WM_OK 0
@@ -179,9 +179,12 @@ int wm_l2_normalize_bwd(const float* dy, const float* y, const float* inv_norm, 
  * ------------------------------------------------------------------------------------------- */
 int wm_ntxent_fwd(const float* zn, const float* zall, int b_local, int b_global, int rank_offset,
                   int d, float temperature, float* lse, float* loss_rows, void* stream);
+/* The backward splits the columns over ~one block per CU; the splits' partial row gradients go to `workspace`
+ * (wm_ntxent_bwd_workspace_bytes) and are summed in split order: no atomics, bit-reproducible. */
+size_t wm_ntxent_bwd_workspace_bytes(int b_local, int b_global, int d);
 int wm_ntxent_bwd(const float* zn, const float* zall, const float* lse_all, int b_local,
                   int b_global, int rank_offset, int d, float temperature, float grad_scale,
-                  float* dzn, void* stream);
+                  float* dzn, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * ResNet-18 / projection-head building blocks: bf16 NHWC activations, f32
@@ -199,11 +202,14 @@ int wm_ntxent_bwd(const float* zn, const float* zall, const float* lse_all, int 
 int wm_conv2d_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
                   int R, int S, int P, int Q, int stride, int pad, void* stream);
 /* The same convolution, also accumulating the per-channel (sum, sum of squares) of its bf16 outputs
- * into stat_part [G][stat_buckets][2][K] f32 (G = N*P*Q / rows_per_group row groups; f32 atomics into
- * bucket (tile % stat_buckets)); rows_per_group % 128 == 0.  stat_part must be zero on entry;
- * wm_bn_train_fwd_from_stats clears it again as it reads it. */
+ * into stat_part: int64 [G][stat_buckets][2 statistics][2 (hi, lo)][K] (G = N*P*Q / rows_per_group row groups,
+ * bucket = tile % stat_buckets).  A tile's f32 partial sum p is split exactly into hi = rint(p * 2^8) and
+ * lo = rint((p - hi * 2^-8) * 2^48) and both are added with 64-bit INTEGER atomics, so a bucket holds the exact sum
+ * of the partials whatever the arrival order: the statistics (and everything downstream) are bit-reproducible from
+ * run to run.  rows_per_group % 128 == 0.  stat_part must be zero on entry; wm_bn_train_fwd_from_stats clears it again
+ * as it reads it. */
 int wm_conv2d_fwd_stats(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
-                        int R, int S, int P, int Q, int stride, int pad, float* stat_part,
+                        int R, int S, int P, int Q, int stride, int pad, void* stat_part,
                         int stat_buckets, int rows_per_group, void* stream);
 /* dx = conv_transpose(dy, w): w_crsk bf16 [C][R][S][K]; C % 64 == 0. */
 int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W, int C, int K,
@@ -213,19 +219,38 @@ int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, 
  * epilogue replaces a separate three-pass elementwise add. */
 int wm_conv2d_dgrad_add(const void* dy, const void* w_crsk, const void* residual, void* dx, int N, int H,
                         int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, void* stream);
-/* dw_krsc (f32 [K][R][S][C]) += sum over pixels of dy (x) x; split-K partials are combined with
- * f32 atomics, so the caller zeroes dw_krsc first and the low bits depend on arrival order. */
-int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_krsc, int N, int H, int W, int C, int K,
+/* dgrad whose input was relu(BN(bn_y) (+ shortcut)) -- i.e. the convolution that FOLLOWS a BatchNorm + ReLU
+ * (timm BasicBlock: conv2 after bn1/act1, and the next block's conv1 after bn2 + shortcut + act2;
+ * scripts/WM811k_benchmark.py:231): the epilogue takes the gradient through the ReLU and accumulates the
+ * BatchNorm-backward sums, so that BatchNorm's backward needs no reduction pass and no mask:
+ *   g  = (conv_transpose(dy, w) (+ residual)) * mask          -> dx (the MASKED gradient, bf16)
+ *   stat_part [G][stat_buckets][2][2][C] int64 += (sum g, sum g * (bn_y - mean) * invstd) per channel
+ *        (wm_conv2d_fwd_stats's exact fixed-point form; zero on entry, cleared by wm_bn_train_bwd_from_stats)
+ * mask = relu_x > 0 when relu_x (the convolution's own forward input, shape of dx) is given; else recomputed from
+ * bn_y as bf16(bn_y * gamma * invstd + beta - mean * gamma * invstd) > 0 (a BatchNorm without shortcut).
+ * bn_y has the shape of dx; save_mean / save_invstd [G][C] over G equal groups of images.
+ * wm_conv2d_dgrad_bnstat_ok: 1 when the shape is served (every 128-row tile inside one statistics group). */
+int wm_conv2d_dgrad_bnstat_ok(int N, int H, int W, int C, int K, int R, int S, int P, int Q, int stride, int pad,
+                              int G);
+int wm_conv2d_dgrad_bnstat(const void* dy, const void* w_crsk, const void* residual, void* dx, int N, int H, int W,
+                           int C, int K, int R, int S, int P, int Q, int stride, int pad, const void* bn_y,
+                           const void* relu_x, const float* gamma, const float* beta, const float* save_mean,
+                           const float* save_invstd, int G, void* stat_part, int stat_buckets, void* stream);
+/* Weight gradient: sum over pixels of dy (x) x, split over pixel ranges.  Split z STORES its partial sums into slab z
+ * of dw_slabs (f32 [nsplit][K][R][S][C], nsplit = wm_conv2d_wgrad_splits(same geometry)): no atomics, nothing to zero;
+ * wm_wgrad_fold / wm_wgrad_finalize / wm_stem_wgrad_finalize sum the slabs in a fixed order (bit-reproducible). */
+int wm_conv2d_wgrad_splits(int N, int H, int W, int C, int K, int R, int S, int P, int Q, int stride, int pad);
+int wm_conv2d_wgrad(const void* dy, const void* x, float* dw_slabs, int N, int H, int W, int C, int K,
                     int R, int S, int P, int Q, int stride, int pad, void* stream);
 /* Forward with y = conv(x) + bias[k] (+ residual, same shape as y), both optional, added in the
  * epilogue: a Linear layer's bias and the residual add of a transformer block cost no extra pass. */
 int wm_conv2d_fwd_bias_res(const void* x, const void* w_krsc, const float* bias, const void* residual, void* y,
                            int N, int H, int W, int C, int K, int R, int S, int P, int Q, int stride, int pad,
                            void* stream);
-/* Same, and dbias[K] += sum over pixels of dy (dbias may be NULL): a Linear layer's bias gradient comes
- * out of the weight-gradient launch (one extra MFMA per dY fragment in the first column group's
- * blocks) instead of a separate reduction pass over dy. */
-int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_krsc, float* dbias, int N, int H, int W, int C,
+/* Same, and dbias_slabs [nsplit][K] = per-split sums over pixels of dy (may be NULL): a Linear layer's bias gradient
+ * comes out of the weight-gradient launch (one extra MFMA per dY fragment in the first column group's blocks)
+ * instead of a separate reduction pass over dy. */
+int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_slabs, float* dbias_slabs, int N, int H, int W, int C,
                          int K, int R, int S, int P, int Q, int stride, int pad, void* stream);
 
 /* The two Linear layers around a GELU (ViT MLP: dino vision_transformer.py Mlp, torchvision MLPBlock; reference
@@ -244,32 +269,35 @@ int wm_linear_dgrad_gelu(const void* dy, const void* w_crsk, const void* pre, vo
 int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int S, void* w_krsc, void* w_crsk,
                        void* stream);
 /* Batched forms of the two layout passes: one launch for every convolution / Linear parameter of a model.
- * descs (DEVICE, n_desc entries, tile0 ascending): w = f32 OIHW master weights [K][C][RS]; krsc / crsk = bf16
- * [K][RS][C] / [C][RS][K] kernel layouts (either may be NULL); ws = f32 [K][RS][C] weight-gradient accumulator and
- * grad = f32 OIHW gradient (wm_wgrad_fold: grad += ws, ws cleared); RS = R*S in {1, 9}; tiles_c = ceil(C / 32);
- * tile0 = index of the parameter's first 32 x 32 (k, c) tile in the launch; total_tiles = sum over parameters of
- * ceil(K / 32) * tiles_c.  Replaces 24-100 wm_weights_prepare / 19 wm_wgrad_finalize launches per training step. */
+ * descs (DEVICE, n_desc entries, tile0 ascending).
+ * wm_layouts_refresh: w = f32 OIHW master weights [K][C][RS]; krsc / crsk = bf16 [K][RS][C] / [C][RS][K] kernel
+ *   layouts (either may be NULL); RS = R*S in {1, 9}; tiles_c = ceil(C / 32); tile0 = index of the parameter's first
+ *   32 x 32 (k, c) tile in the launch; total_tiles = sum over parameters of ceil(K / 32) * tiles_c.
+ * wm_wgrad_fold: ws = f32 weight-gradient slabs [nsplit][K][RS][C] (wm_conv2d_wgrad), nsplit slabs summed in order;
+ *   grad = f32 OIHW gradient (grad += sum); a block owns (32 x 32 (k, c) tile, one tap): tiles per parameter =
+ *   ceil(K / 32) * tiles_c * RS.  Optional bias: w = f32 bias slabs [nsplit][K], krsc = (float*) bias gradient [K]
+ *   (+=), both NULL when absent (crsk unused).
+ * Replaces 24-100 wm_weights_prepare / 19 wm_wgrad_finalize launches per training step. */
 typedef struct WmLayoutDesc {
   const float* w;
   uint16_t* krsc;
   uint16_t* crsk;
   float* ws;
   float* grad;
-  int32_t K, C, RS, tiles_c, tile0, reserved;
+  int32_t K, C, RS, tiles_c, tile0, nsplit;
 } WmLayoutDesc; /* 64 bytes */
 int wm_layouts_refresh(const WmLayoutDesc* descs_dev, int n_desc, int total_tiles, void* stream);
 int wm_wgrad_fold(const WmLayoutDesc* descs_dev, int n_desc, int total_tiles, void* stream);
 
-/* wgrad accumulator [K][R][S][C] f32 -> OIHW gradient (= or +=); the accumulator is cleared as it
- * is read, so a persistent one needs zeroing only once. */
-int wm_wgrad_finalize(float* dw_krsc, int K, int C, int R, int S, float* grad_oihw,
+/* weight-gradient slabs [nsplit][K][R][S][C] f32 -> OIHW gradient (= or += the sum of the slabs, in order). */
+int wm_wgrad_finalize(const float* dw_slabs, int nsplit, int K, int C, int R, int S, float* grad_oihw,
                       int accumulate, void* stream);
 /* The 7x7/2 pad-3 stem on 3 channels run as a 4x4/1 pad-2 convolution over the 2x2 space-to-depth
  * image [N][H/2][W/2][16] (channel (dh*2+dw)*3+c, 12 used): weights [K][3][7][7] f32 ->
  * [K][4][4][16] bf16, its gradient back, and the image transform (fmt WM_IMG_NCHW_F32 or
  * WM_IMG_NHWC_BF16 with 3 channels). */
 int wm_stem_weights_prepare(const float* w_oihw, int K, void* w_s2d, void* stream);
-int wm_stem_wgrad_finalize(float* dw_s2d, int K, float* grad_oihw, int accumulate, void* stream);
+int wm_stem_wgrad_finalize(const float* dw_s2d_slabs, int nsplit, int K, float* grad_oihw, int accumulate, void* stream);
 int wm_image_to_s2d(const void* img, int fmt, int N, int H, int W, void* out, void* stream);
 int wm_cast_f32_bf16(const float* x, long long n, void* y, void* stream);
 
@@ -289,13 +317,13 @@ int wm_bn_train_fwd_from_stats(const void* y, const void* residual, const float*
                                float* running_mean, float* running_var, long long* num_batches_tracked,
                                long long rows, int C, int G, float eps, float momentum, int relu, float* save_mean,
                                float* save_invstd,
-                               void* out, float* stat_part, int stat_buckets, void* workspace,
+                               void* out, void* stat_part, int stat_buckets, void* workspace,
                                size_t workspace_bytes, void* stream);
 /* Statistics only: mean / invstd / running stats and the [G][C] scale, shift of the normalisation, for a
  * consumer that applies it itself (the fused stem below).  stat_part NULL: computed from y here. */
 int wm_bn_train_stats(const void* y, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, long long* num_batches_tracked, long long rows, int C, int G, float eps, float momentum,
-                      float* save_mean, float* save_invstd, float* scale, float* shift, float* stat_part,
+                      float* save_mean, float* save_invstd, float* scale, float* shift, void* stat_part,
                       int stat_buckets, void* workspace, size_t workspace_bytes, void* stream);
 int wm_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, int C, float eps, float* scale, float* shift, void* stream);
@@ -310,6 +338,13 @@ int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, int r
                     const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                     long long rows, int C, int G, float* dgamma, float* dbeta, int accumulate, void* dy,
                     void* dz, void* workspace, size_t workspace_bytes, void* stream);
+/* Backward whose sums were accumulated by wm_conv2d_dgrad_bnstat: g is the gradient ALREADY taken through the ReLU
+ * (it is also the gradient of the shortcut branch, if any): finalize (and clear) stat_part, dgamma / dbeta (= or +=),
+ * then one pass dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)).  workspace >= 7 * G * C floats. */
+int wm_bn_train_bwd_from_stats(const void* y, const void* g, const float* gamma, const float* beta,
+                               const float* save_mean, const float* save_invstd, long long rows, int C, int G,
+                               float* dgamma, float* dbeta, int accumulate, void* dy, void* stat_part,
+                               int stat_buckets, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the fused stem tail max_pool3x3s2(relu(BN(y))): y [N][H][W][C]; the gradient entering
  * the BN is gathered from pooled_dy / pool_idx [N][P][Q][C] inside the apply pass; with ysel (the
  * inputs at the selected positions, from the forward; may be NULL) the per-channel sums run over the

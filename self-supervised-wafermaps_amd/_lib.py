@@ -77,9 +77,11 @@ SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     ),
+    "wm_ntxent_bwd_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "wm_ntxent_bwd": (
         c_int,
-        [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p],
+        [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_size_t,
+         c_void_p],
     ),
     "wm_conv2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p]),
     "wm_conv2d_fwd_stats": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_int, c_void_p]),
@@ -91,9 +93,18 @@ SIGNATURES = {
     "wm_conv2d_wgrad_bias": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
                                      c_int, c_int, c_int, c_int, c_void_p]),
     "wm_weights_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
-    "wm_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "wm_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
+    "wm_conv2d_wgrad_splits": (c_int, [c_int] * 11),
+    "wm_conv2d_dgrad_bnstat_ok": (c_int, [c_int] * 12),
+    "wm_conv2d_dgrad_bnstat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 11 +
+                               [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "wm_bn_train_bwd_from_stats": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_int,
+         c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
+    ),
     "wm_stem_weights_prepare": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
-    "wm_stem_wgrad_finalize": (c_int, [c_void_p, c_int, c_void_p, c_int, c_void_p]),
+    "wm_stem_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "wm_image_to_s2d": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_cast_f32_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p]),
     "wm_bn_workspace_bytes": (c_size_t, [c_longlong, c_int, c_int]),

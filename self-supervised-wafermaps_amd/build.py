@@ -30,6 +30,7 @@ FLAGS = [
     "-Wall",
     "-Wno-unused-function",
     "-Wno-pass-failed",
+    "-Wno-inline-asm",  # (glds16_at declares m0 clobbered: intended)
 ]
 # per-source additions.  knn.hip: MFMA results in VGPRs (the running group maxima read every accumulator
 # register with VALU right after the MFMAs; in AGPR form that is one v_accvgpr_read per register per chunk)

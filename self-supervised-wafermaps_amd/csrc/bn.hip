@@ -219,9 +219,37 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restri
 // of what these few-microsecond launches cost (44 of them per SimCLR step).
 __device__ __forceinline__ void finalize_sums2(float* __restrict__ part, int nblk, int g, int ng, int C, int c,
                                                int bl, int cl, double (*red)[2][32][33], double (&s)[2],
-                                               double (&ss)[2], bool clear = false) {
+                                               double (&ss)[2], bool clear = false, bool fx = false) {
   double a[2] = {0.0, 0.0}, b[2] = {0.0, 0.0};
-  if (c < C) {
+  if (c < C && fx) {
+    // exact fixed-point buckets of the convolution epilogues (wm_fx_add): int64 [nblk][2][hi, lo][C] per group;
+    // integer sums first (exact), one conversion per lane
+    long long* fxp = reinterpret_cast<long long*>(part);
+    long long h0[2] = {0, 0}, l0[2] = {0, 0}, h1[2] = {0, 0}, l1[2] = {0, 0};
+    for (int k = bl; k < nblk; k += 32) {
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        if (u < ng) {
+          long long* q = fxp + ((size_t)((g + u) * nblk + k) * 4) * C + c;
+          h0[u] += q[0];
+          l0[u] += q[(size_t)C];
+          h1[u] += q[(size_t)2 * C];
+          l1[u] += q[(size_t)3 * C];
+          if (clear) {
+            q[0] = 0;
+            q[(size_t)C] = 0;
+            q[(size_t)2 * C] = 0;
+            q[(size_t)3 * C] = 0;
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      a[u] = wm_fx_value(h0[u], l0[u]);
+      b[u] = wm_fx_value(h1[u], l1[u]);
+    }
+  } else if (c < C) {
     for (int k = bl; k < nblk; k += 32) {
       float va[2] = {0.f, 0.f}, vb[2] = {0.f, 0.f};
 #pragma unroll
@@ -231,7 +259,7 @@ __device__ __forceinline__ void finalize_sums2(float* __restrict__ part, int nbl
           float* p1 = part + ((size_t)((g + u) * nblk + k) * 2 + 1) * C + c;
           va[u] = *p0;
           vb[u] = *p1;
-          if (clear) {  // read-and-clear: the conv epilogue's atomics start from zero next step
+          if (clear) {  // read-and-clear
             *p0 = 0.f;
             *p1 = 0.f;
           }
@@ -287,7 +315,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize(
   for (int g0 = 0; g0 < G; g0 += 2) {
     const int ng = G - g0 < 2 ? G - g0 : 2;
     double s2[2], ss2[2];
-    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s2, ss2, clear != 0);
+    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s2, ss2, clear != 0, clear != 0);
     if (owner) {
       for (int u = 0; u < ng; ++u) {
         const int g = g0 + u;
@@ -390,7 +418,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize(
     float* __restrict__ part, int nblk, int G, int C, int rows_per_group,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-    float* __restrict__ coef) {
+    float* __restrict__ coef, int fx) {
   __shared__ double red[2][2][32][33];
   const int bl = threadIdx.x >> 5, cl = threadIdx.x & 31;
   const int c = blockIdx.x * 32 + cl;
@@ -399,7 +427,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize(
   for (int g0 = 0; g0 < G; g0 += 2) {
     const int ng = G - g0 < 2 ? G - g0 : 2;
     double s1v[2], s2v[2];
-    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s1v, s2v);
+    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s1v, s2v, fx != 0, fx != 0);
     if (owner) {
       for (int u = 0; u < ng; ++u) {
         const int g = g0 + u;
@@ -785,7 +813,7 @@ extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, c
                                           const float* beta, float* running_mean, float* running_var,
                                           long long* num_batches_tracked, long long rows, int C, int G, float eps,
                                           float momentum, int relu,
-                                          float* save_mean, float* save_invstd, void* out, float* stat_part,
+                                          float* save_mean, float* save_invstd, void* out, void* stat_part,
                                           int stat_buckets, void* workspace, size_t workspace_bytes,
                                           void* stream) {
   WM_REQUIRE(y && out && save_mean && save_invstd && workspace && stat_part, WM_EINVAL);
@@ -797,7 +825,7 @@ extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, c
   const int rpg = (int)(rows / G);
   float* scale = static_cast<float*>(workspace);
   float* shift = scale + (size_t)G * C;
-  bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(stat_part, stat_buckets, G, C, rpg, 1, gamma, beta, eps, momentum,
+  bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(static_cast<float*>(stat_part), stat_buckets, G, C, rpg, 1, gamma, beta, eps, momentum,
                                                    running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   WM_LAUNCH_CHECK();
   launch_bn_apply(y, residual, scale, shift, rows, C, rpg, relu, out, st);
@@ -810,7 +838,7 @@ extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, c
 // stat_part non-NULL: statistics were fused into the producing convolution; else they are computed here.
 extern "C" int wm_bn_train_stats(const void* y, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, long long* num_batches_tracked, long long rows, int C, int G, float eps, float momentum,
-                                 float* save_mean, float* save_invstd, float* scale, float* shift, float* stat_part,
+                                 float* save_mean, float* save_invstd, float* scale, float* shift, void* stat_part,
                                  int stat_buckets, void* workspace, size_t workspace_bytes, void* stream) {
   WM_REQUIRE(y && save_mean && save_invstd && scale && shift && workspace, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
@@ -819,7 +847,7 @@ extern "C" int wm_bn_train_stats(const void* y, const float* gamma, const float*
   const int rpg = (int)(rows / G);
   if (stat_part) {
     WM_REQUIRE(stat_buckets > 0, WM_EINVAL);
-    bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(stat_part, stat_buckets, G, C, rpg, 1, gamma, beta, eps, momentum,
+    bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(static_cast<float*>(stat_part), stat_buckets, G, C, rpg, 1, gamma, beta, eps, momentum,
                                                      running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   } else {
     WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
@@ -891,6 +919,38 @@ extern "C" int wm_bn_train_bwd(const void* y, const void* dout, const void* out_
                      accumulate, dy, dz, workspace, workspace_bytes, stream, PoolSrc{});
 }
 
+// Backward when the producing dgrad (wm_conv2d_dgrad_bnstat) already took the gradient through the ReLU and
+// accumulated (sum g, sum g * xhat): finalize (and clear) the buckets, then ONE pass over (y, g).
+extern "C" int wm_bn_train_bwd_from_stats(const void* y, const void* g, const float* gamma, const float* beta,
+                                          const float* save_mean, const float* save_invstd, long long rows, int C,
+                                          int G, float* dgamma, float* dbeta, int accumulate, void* dy,
+                                          void* stat_part, int stat_buckets, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(y && g && save_mean && save_invstd && dy && stat_part && workspace && stat_buckets > 0, WM_EINVAL);
+  const int rc = bn_shape_check(rows, C, G);
+  if (rc != WM_OK) return rc;
+  WM_REQUIRE(!bn_wide(rows, C, G), WM_EUNSUPPORTED);
+  WM_REQUIRE(workspace_bytes >= (size_t)7 * G * C * sizeof(float), WM_EWORKSPACE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rpg = (int)(rows / G);
+  float* coef = static_cast<float*>(workspace);
+  bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(static_cast<float*>(stat_part), stat_buckets, G, C, rpg, gamma, beta,
+                                                   save_mean, save_invstd, dgamma, dbeta, accumulate, coef, 1);
+  WM_LAUNCH_CHECK();
+  const int tpr = C >> 3;
+  int csh = 0;
+  if (chunk_pow2(C, &csh))
+    bn_bwd_apply<true><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(g), nullptr, coef, rows, C, rpg, 0, csh,
+        static_cast<uint16_t*>(dy), nullptr, PoolSrc{});
+  else
+    bn_bwd_apply<false><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(g), nullptr, coef, rows, C, rpg, 0, csh,
+        static_cast<uint16_t*>(dy), nullptr, PoolSrc{});
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
 // Backward of max_pool3x3s2(relu(BN(y))) (the fused stem): the gradient entering the BN is gathered
 // from the pooled gradient + window positions instead of being materialised by wm_maxpool3x3s2_bwd.
 extern "C" int wm_bn_relu_maxpool_bwd(const void* y, const void* ysel, const void* pooled_dy, const void* pool_idx,
@@ -954,7 +1014,7 @@ static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, in
   }
   WM_LAUNCH_CHECK();
   bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk_used, G, C, rpg, gamma, beta, save_mean, save_invstd,
-                                                   dgamma, dbeta, accumulate, coef);
+                                                   dgamma, dbeta, accumulate, coef, 0);
   WM_LAUNCH_CHECK();
   int csh = 0;
   if (ps.dy != nullptr && !dz && !out_relu && (ps.H & 1) == 0 && (ps.W & 1) == 0 && BN_THREADS % tpr == 0 &&

@@ -51,8 +51,20 @@ struct ConvArgs {
   int N, SH, SW, SC, DH, DW, DC, R, S, stride, pad, M, nkt;
   // optional fused BatchNorm statistics (forward only): per-channel (sum, sum of squares) of the
   // bf16-rounded outputs, added into bucket (tile % stat_nb) of the tile's row group
-  float* stat;          // [G][stat_nb][2][DC] f32, or NULL
+  unsigned long long* stat;  // [G][stat_nb][2][hi, lo][DC] int64 (wm_fx_add: order-independent sums), or NULL
   int stat_nb, stat_rpg;
+  // optional BatchNorm-BACKWARD epilogue (dgrad only, template flag BNB): this convolution's input was
+  // relu(BN(bn_y) (+ shortcut)), so the gradient this kernel produces is the one entering that ReLU.  The epilogue
+  // applies the ReLU mask (bn_x > 0 when the convolution's forward input bn_x is given, else recomputed from bn_y as
+  // bf16(bn_y * gamma * invstd + beta - mean * gamma * invstd) > 0), stores the MASKED gradient, and accumulates the
+  // BatchNorm backward sums (sum g, sum g * xhat) per channel into `stat`: the separate reduction pass over
+  // (bn_y, gradient, mask) and the mask / dz handling of the BatchNorm backward apply pass disappear.
+  const uint16_t* bn_y;
+  const uint16_t* bn_x;
+  const float* bn_mean;    // [G][DC]
+  const float* bn_invstd;  // [G][DC]
+  const float* bn_gamma;   // [DC]
+  const float* bn_beta;    // [DC]
   // optional tensor added to the result in the epilogue (dgrad: the gradient that reached the same
   // input through a second path, e.g. the identity shortcut of a residual block), same shape as dst
   const uint16_t* res;
@@ -74,6 +86,129 @@ __device__ __forceinline__ float cv_gelu_grad(float v) { return wm_gelu_grad(v);
 // 128 zero bytes: the global_load_lds source of padded / out-of-range taps
 __device__ __attribute__((aligned(256))) uint16_t conv_zero_page[128];
 
+
+// (sum, sum of squares) per channel of a staged bf16 tile [128 rows][CS bytes], BNC channels, added to the tile's
+// statistics slot.  `red` = LDS scratch of 2 * (256 / BNC) * BNC floats outside the tile.  The row slices are combined
+// in a fixed order and the block's sums go out through wm_fx_add: bit-reproducible.
+template <int BNC>
+__device__ __forceinline__ void tile_stats_fwd(const uint8_t* tile, int CS, int valid_rows, float* red,
+                                               unsigned long long* slot, int DC, int c_base, int tid) {
+  constexpr int TPC = CV_THREADS / BNC;
+  const int c = tid % BNC, part = tid / BNC;
+  float sm = 0.f, sq = 0.f;
+  for (int rr = part * (128 / TPC); rr < (part + 1) * (128 / TPC); ++rr) {
+    if (rr < valid_rows) {
+      const float v = bf2f(*reinterpret_cast<const uint16_t*>(tile + rr * CS + c * 2));
+      sm += v;
+      sq = fmaf(v, v, sq);
+    }
+  }
+  red[part * BNC + c] = sm;
+  red[(TPC + part) * BNC + c] = sq;
+  __syncthreads();
+  if (tid < 2 * BNC) {
+    const int which = tid / BNC, cc = tid % BNC;
+    float t = 0.f;
+#pragma unroll
+    for (int q = 0; q < TPC; ++q) t += red[(which * TPC + q) * BNC + cc];
+    wm_fx_add(slot + (size_t)(which * 2) * DC + c_base + cc, slot + (size_t)(which * 2 + 1) * DC + c_base + cc, t);
+  }
+}
+
+// BatchNorm-backward epilogue of a dgrad tile (ConvArgs: bn_*): staged bf16 tile [128 rows][CS bytes] of BNC
+// channels -> (+ residual) -> ReLU mask -> store, and the tile's (sum g, sum g * xhat) into its statistics slot.
+// pix_of(row) = destination pixel of tile row `row`; rows >= valid_rows are skipped.
+template <int BNC, typename PixOf>
+__device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, uint8_t* smem, int CS, int valid_rows, int g, int n0,
+                                             int bucket, int tid, PixOf pix_of) {
+  constexpr int CPR = BNC / 8;
+  constexpr int NIT = 128 * CPR / CV_THREADS;
+  constexpr int RG = CV_THREADS / CPR;  // threads that share a chunk column
+  const int chl = tid % CPR, rg = tid / CPR;
+  const int c0 = n0 + chl * 8;
+  float mu[8], is[8], sc[8], sh[8];
+  {
+    const float* pm = a.bn_mean + (size_t)g * a.DC + c0;
+    const float* pi = a.bn_invstd + (size_t)g * a.DC + c0;
+    const float4 m0v = *reinterpret_cast<const float4*>(pm), m1v = *reinterpret_cast<const float4*>(pm + 4);
+    const float4 i0v = *reinterpret_cast<const float4*>(pi), i1v = *reinterpret_cast<const float4*>(pi + 4);
+    mu[0] = m0v.x; mu[1] = m0v.y; mu[2] = m0v.z; mu[3] = m0v.w; mu[4] = m1v.x; mu[5] = m1v.y; mu[6] = m1v.z; mu[7] = m1v.w;
+    is[0] = i0v.x; is[1] = i0v.y; is[2] = i0v.z; is[3] = i0v.w; is[4] = i1v.x; is[5] = i1v.y; is[6] = i1v.z; is[7] = i1v.w;
+  }
+  const bool remask = a.bn_x == nullptr;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = sh[e] = 0.f;
+    if (remask) {  // the forward's own arithmetic (bn_fwd_finalize: scale = gamma * invstd, shift = beta - mean * scale)
+      sc[e] = a.bn_gamma[c0 + e] * is[e];
+      sh[e] = a.bn_beta[c0 + e] - mu[e] * sc[e];
+    }
+  }
+  size_t pixs[NIT];
+  uint4 yv[NIT], rv[NIT], xv[NIT];
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {  // every global load of the thread is requested before the first store
+    const int row = (tid + it * CV_THREADS) / CPR;
+    const size_t pix = pix_of(row);
+    pixs[it] = pix;
+    yv[it] = rv[it] = xv[it] = make_uint4(0, 0, 0, 0);
+    if (row < valid_rows) {
+      yv[it] = *reinterpret_cast<const uint4*>(a.bn_y + pix * a.DC + c0);
+      if (a.res != nullptr) rv[it] = *reinterpret_cast<const uint4*>(a.res + pix * a.DC + c0);
+      if (!remask) xv[it] = *reinterpret_cast<const uint4*>(a.bn_x + pix * a.DC + c0);
+    }
+  }
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = (tid + it * CV_THREADS) / CPR;
+    if (row < valid_rows) {
+      const uint4 v4 = *reinterpret_cast<const uint4*>(smem + row * CS + chl * 16);
+      const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
+      const uint32_t rr[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
+      const uint32_t yy[4] = {yv[it].x, yv[it].y, yv[it].z, yv[it].w};
+      const uint32_t xx[4] = {xv[it].x, xv[it].y, xv[it].z, xv[it].w};
+      uint32_t o[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float gv[2];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int e = q * 2 + h;
+          float v = bf2f((uint16_t)(h ? vv[q] >> 16 : vv[q] & 0xffff));
+          if (a.res != nullptr) v = bf2f(f2bf(v + bf2f((uint16_t)(h ? rr[q] >> 16 : rr[q] & 0xffff))));
+          const float y = bf2f((uint16_t)(h ? yy[q] >> 16 : yy[q] & 0xffff));
+          const bool keep = remask ? bf2f(f2bf(fmaf(y, sc[e], sh[e]))) > 0.f
+                                   : bf2f((uint16_t)(h ? xx[q] >> 16 : xx[q] & 0xffff)) > 0.f;
+          v = keep ? v : 0.f;
+          s1[e] += v;
+          s2[e] = fmaf(v, (y - mu[e]) * is[e], s2[e]);
+          gv[h] = v;
+        }
+        o[q] = pack_bf2(gv[0], gv[1]);
+      }
+      *reinterpret_cast<uint4*>(a.dst + pixs[it] * a.DC + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  __syncthreads();  // every read of the staged tile is over: its LDS carries the cross-thread sums now
+  float* red = reinterpret_cast<float*>(smem);  // [2][RG][BNC]
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    red[rg * BNC + chl * 8 + e] = s1[e];
+    red[(RG + rg) * BNC + chl * 8 + e] = s2[e];
+  }
+  __syncthreads();
+  if (tid < 2 * BNC) {
+    const int which = tid / BNC, cc = tid % BNC;
+    float t = 0.f;
+    for (int q = 0; q < RG; ++q) t += red[(which * RG + q) * BNC + cc];
+    unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + bucket) * 4) * a.DC;
+    wm_fx_add(slot + (size_t)(which * 2) * a.DC + n0 + cc, slot + (size_t)(which * 2 + 1) * a.DC + n0 + cc, t);
+  }
+}
+
 // Both operand tiles go HBM -> LDS by global_load_lds (16 B per lane, 1 KiB per wave instruction,
 // no VGPR staging, no ds_write).  The DMA destination is lane-linear, so a lane fetches the LOGICAL
 // chunk that belongs at its physical slot: chunk = slot ^ (row & 7) (the same involution is applied
@@ -86,9 +221,10 @@ __device__ __attribute__((aligned(256))) uint16_t conv_zero_page[128];
 // pixel for 3x3, and three of four classes of the 1x1 downsample just store zeros.
 // EPI: epilogue with bias / prefetched residual (Linear layers).  It is a separate instantiation
 // because carrying its registers in the convolution kernels cost them ~8 %.
-template <int BM, int BN, int CPT, int MODE, bool EPI = false>
+template <int BM, int BN, int CPT, int MODE, bool EPI = false, bool BNB = false>
 __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   constexpr bool DGRAD = MODE != 0;
+  static_assert(!BNB || (DGRAD && !EPI && BM == 128), "BatchNorm-backward epilogue: dgrad tiles of 128 rows");
   extern __shared__ __attribute__((aligned(16))) uint8_t cv_smem[];
   // BM x BN tile, 4 waves: 2 x 2 waves of 64 px x BN/2 ch for BM = 128; 4 x 1 waves of 64 px x BN ch
   // for BM = 256 (measured no faster than 128 x 64 on the 64-channel layers: those are bound by the
@@ -294,23 +430,34 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   __syncthreads();
   if constexpr (MODE == 0) {
     if (a.stat != nullptr) {
-      // column sums of the staged tile: BN channels x (256/BN) row slices; rows_per_group % BM == 0,
-      // so the whole tile belongs to one statistics group
-      constexpr int TPC = CV_THREADS / BN;
-      const int c = tid % BN, part = tid / BN;
-      float sm = 0.f, sq = 0.f;
-      for (int rr = part * (BM / TPC); rr < (part + 1) * (BM / TPC); ++rr) {
-        if (m0 + rr < a.M) {
-          const float v = bf2f(*reinterpret_cast<const uint16_t*>(cv_smem + rr * CS + c * 2));
-          sm += v;
-          sq = fmaf(v, v, sq);
-        }
-      }
+      // column sums of the staged tile; rows_per_group % BM == 0, so the whole tile belongs to one statistics group
       const int g = m0 / a.stat_rpg;
-      float* base = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 2) * a.DC + n0 + c;
-      atomicAdd(base, sm);
-      atomicAdd(base + a.DC, sq);
+      unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 4) * a.DC;
+      tile_stats_fwd<BN>(cv_smem, CS, a.M - m0, reinterpret_cast<float*>(cv_smem + BM * CS), slot, a.DC, n0, tid);
     }
+  }
+  if constexpr (BNB) {
+    int g;
+    if constexpr (MODE == 2) {
+      const int cls = a.M >> 2;
+      g = (m0 % cls) / a.stat_rpg;  // stat_rpg: rows of one statistics group inside a parity class
+    } else {
+      g = m0 / a.stat_rpg;
+    }
+    bnb_epilogue<BN>(a, cv_smem, CS, a.M - m0, g, n0, (int)(blockIdx.x % a.stat_nb), tid, [&](int row) -> size_t {
+      if constexpr (MODE == 2) {  // class-ordered row -> pixel (n, 2 h2 + ph, 2 w2 + pw)
+        const int cls = a.M >> 2;
+        const int pc = m0 / cls;
+        const int m = m0 + row - pc * cls;
+        uint32_t urem2, uw2;
+        const int n = (int)wm_divmod((uint32_t)m, a.d_h2w2, urem2);
+        const int h2 = (int)wm_divmod(urem2, a.d_w2, uw2), w2 = (int)uw2;
+        return ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
+      } else {
+        return (size_t)(m0 + row);
+      }
+    });
+    return;
   }
   if constexpr (EPI) {
     constexpr int CPR = BN / 8;
@@ -456,9 +603,10 @@ constexpr int PT_W_BYTES = 64 * CV_ROW;      // one tap's weights: 64 rows x 64 
 constexpr int PT_WSTAGES = 3;                 // weight ring: two taps in flight ahead of the one being multiplied
 constexpr int PT_LDS = PT_PATCH_BYTES + PT_WSTAGES * PT_W_BYTES;
 
-template <int MODE>
+template <int MODE, bool BNB = false>
 __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
   constexpr bool DGRAD = MODE != 0;
+  static_assert(!BNB || DGRAD, "BatchNorm-backward epilogue: dgrad only");
   extern __shared__ __attribute__((aligned(16))) uint8_t cv_smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -585,22 +733,21 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
   __syncthreads();
   if constexpr (MODE == 0) {
     if (a.stat != nullptr) {
-      // column sums of the staged tile: 64 channels x 4 row slices; both 8x8 tiles lie in one statistics
-      // group (host-checked: an even number of tiles per group)
-      const int c = tid & 63, part = tid >> 6;
-      float sm = 0.f, sq = 0.f;
-      for (int rr = part * 32; rr < (part + 1) * 32; ++rr) {
-        const float v = bf2f(*reinterpret_cast<const uint16_t*>(cv_smem + rr * CS + c * 2));
-        sm += v;
-        sq = fmaf(v, v, sq);
-      }
+      // column sums of the staged tile; both 8x8 tiles lie in one statistics group (host-checked: an even number of
+      // tiles per group)
       const int g = (int)(((long long)tn[0] * a.DH * a.DW) / a.stat_rpg);
-      float* base = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 2) * 64 + c;
-      atomicAdd(base, sm);
-      atomicAdd(base + 64, sq);
+      unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 4) * 64;
+      tile_stats_fwd<64>(cv_smem, CS, 128, reinterpret_cast<float*>(cv_smem + 128 * CS), slot, 64, 0, tid);
     }
   }
   const size_t org[2] = {((size_t)tn[0] * a.DH + th0[0]) * a.DW + tw0[0], ((size_t)tn[1] * a.DH + th0[1]) * a.DW + tw0[1]};
+  if constexpr (BNB) {
+    const int g = (int)(((long long)tn[0] * a.DH * a.DW) / a.stat_rpg);
+    bnb_epilogue<64>(a, cv_smem, CS, 128, g, 0, (int)(blockIdx.x % a.stat_nb), tid, [&](int row) -> size_t {
+      return org[row >> 6] + (size_t)((row >> 3) & 7) * a.DW + (row & 7);
+    });
+    return;
+  }
 #pragma unroll
   for (int q = 0; q < 128 * 8 / CV_THREADS; ++q) {
     const int p = tid + q * CV_THREADS;
@@ -641,7 +788,7 @@ constexpr int ST_PIX = 11 * ST_PITCH;              // pixel slots per patch
 constexpr int ST_PATCH_INSTR = 9;                  // 2 x 132 x 32 B = 8448 B -> nine 1-KB DMA instructions
 constexpr int ST_PATCH_BYTES = ST_PATCH_INSTR * 1024;
 constexpr int ST_CS = 64 * 2 + 16;                 // staged output row (64 channels bf16 + 16 B)
-constexpr int ST_LDS = 2 * ST_PATCH_BYTES + 128 * ST_CS;
+constexpr int ST_LDS = 2 * ST_PATCH_BYTES + 128 * ST_CS + 2 * 4 * 64 * 4;  // + scratch of the statistics flush
 
 __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs a, int npairs, const WmDiv d_timg,
                                                                  const WmDiv d_twn) {
@@ -709,16 +856,33 @@ __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs 
   // pixel fragment: pixel (2 i + dy + r, dx + 2 ks + (fg >> 1)) of the patch, channel half fg & 1
   const uint32_t xbase = (uint32_t)((wm * ST_PIX + dy * ST_PITCH + dx + (fg >> 1)) * 32 + (fg & 1) * 16);
 
+  int st_g = -1;
+  float st_sm = 0.f, st_sq = 0.f;
+  float* st_red = reinterpret_cast<float*>(cv_smem + 2 * ST_PATCH_BYTES + 128 * ST_CS);  // [2][4][64]
+  auto stat_flush = [&](int g) {  // block-uniform call sites only
+    const int c = tid & 63, part = tid >> 6;
+    __syncthreads();  // (the previous flush's readers are done with st_red)
+    st_red[part * 64 + c] = st_sm;
+    st_red[(4 + part) * 64 + c] = st_sq;
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6;
+      const float t = st_red[(which * 4) * 64 + c] + st_red[(which * 4 + 1) * 64 + c] + st_red[(which * 4 + 2) * 64 + c] +
+                      st_red[(which * 4 + 3) * 64 + c];
+      unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 4) * 64;
+      wm_fx_add(slot + (size_t)(which * 2) * 64 + c, slot + (size_t)(which * 2 + 1) * 64 + c, t);
+    }
+  };
+
   int pair = blockIdx.x;
   if (pair < npairs) issue_patch(pair, smem_base);
   for (int it = 0; pair < npairs; pair += gridDim.x, ++it) {
     // the patches of this pair have landed (this wave's pieces; the barrier: everyone's), the previous pair's
     // staged tile has been read by every wave.  Vector-memory operations retire in issue order, so the counted
-    // wait leaves the previous pair's 4 output stores (and 2 statistics atomics) per lane in flight: they were issued
+    // wait leaves the previous pair's 4 output stores per lane in flight: they were issued
     // AFTER these patch fetches (waiting for them too cost 0.5 us per pair and block).
     if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if (a.stat != nullptr) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (a statistics flush's atomics precede the stores: covered)
     __builtin_amdgcn_s_barrier();
     if (pair + (int)gridDim.x < npairs) issue_patch(pair + gridDim.x, smem_base + ((it + 1) & 1) * ST_PATCH_BYTES);
     const uint8_t* pb = cv_smem + (it & 1) * ST_PATCH_BYTES;
@@ -757,17 +921,20 @@ __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs 
     __syncthreads();
     const int T0 = pair * 2;
     if (a.stat != nullptr) {
+      // running per-thread sums over this block's pairs (static schedule: pair = blockIdx.x + it * gridDim.x, so the
+      // order is fixed), flushed when the statistics group changes and after the last pair
+      const int g = __builtin_amdgcn_readfirstlane((int)(((long long)wm_div((uint32_t)T0, d_timg) * a.DH * a.DW) / a.stat_rpg));
+      if (g != st_g) {
+        if (st_g >= 0) stat_flush(st_g);
+        st_g = g;
+        st_sm = st_sq = 0.f;
+      }
       const int c = tid & 63, part = tid >> 6;
-      float sm = 0.f, sq = 0.f;
       for (int rr = part * 32; rr < (part + 1) * 32; ++rr) {
         const float v = bf2f(*reinterpret_cast<const uint16_t*>(stage + rr * ST_CS + c * 2));
-        sm += v;
-        sq = fmaf(v, v, sq);
+        st_sm += v;
+        st_sq = fmaf(v, v, st_sq);
       }
-      const int g = __builtin_amdgcn_readfirstlane((int)(((long long)wm_div((uint32_t)T0, d_timg) * a.DH * a.DW) / a.stat_rpg));
-      float* base = a.stat + ((size_t)(g * a.stat_nb + (pair % a.stat_nb)) * 2) * 64 + c;
-      atomicAdd(base, sm);
-      atomicAdd(base + 64, sq);
     }
     {
       int n[2], h0[2], w0[2];
@@ -783,18 +950,20 @@ __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs 
       }
     }
   }
+  if (a.stat != nullptr && st_g >= 0) stat_flush(st_g);
 }
 
 // ------------------------------------------------------------------------------------ wgrad
 struct WgradArgs {
   const uint16_t* dy;  // [M][K]
   const uint16_t* x;   // [N][H][W][C]
-  float* dw;           // [K][R][S][C] f32, accumulated with atomics
+  float* dw;           // [nsplit][K][R][S][C] f32: split z STORES its partial sums into slab z (no atomics: the
+                       // slabs are summed in a fixed order by wm_wgrad_fold / wm_wgrad_finalize -- bit-reproducible)
   int N, H, W, C, K, R, S, P, Q, stride, pad, M, chunks_per_split, total_chunks;
   // optional bias gradient dbias[K] += sum over pixels of dy: the blocks of the first column group
   // multiply their dY fragments with an all-ones B operand (one extra MFMA per fragment and k-step),
   // so a Linear layer's bias gradient costs no extra pass over dY
-  float* dbias;
+  float* dbias;        // [nsplit][K] slabs, like dw
 };
 
 constexpr int WG_PIX = 64;  // pixels per staged chunk (two MFMA k-steps)
@@ -846,8 +1015,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   const int chunk_begin = blockIdx.z * a.chunks_per_split;
   int chunk_end = chunk_begin + a.chunks_per_split;
   if (chunk_end > a.total_chunks) chunk_end = a.total_chunks;
-  const int iters = chunk_end - chunk_begin;
-  if (iters <= 0) return;
+  const int iters = chunk_end - chunk_begin;  // >= 1: the host derives the split count from chunks_per_split
 
   // running (n, p, q) of this lane's two X rows (shared by the NT tiles).  Every chunk advances a row
   // by 64 pixels: (dq, dpp, dn) is that step in mixed radix (Q, P), applied with two carries.
@@ -993,6 +1161,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
 
   const size_t rsc = (size_t)a.R * a.S * a.C;
   const int fr = lane & 15, fg = lane >> 4;
+  float* slab = a.dw + (size_t)blockIdx.z * (size_t)a.K * rsc;
 #pragma unroll
   for (int i = 0; i < MJ; ++i)
 #pragma unroll
@@ -1003,13 +1172,13 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
         for (int e = 0; e < 4; ++e) {
           const int kk = k0 + cout_w + i * 16 + fg * 4 + e;
           const int col = (ct0 + tile_w + t) * 64 + col_w + j * 16 + fr;
-          atomicAdd(a.dw + (size_t)kk * rsc + col, acc[i][t * NJ + j][e]);
+          slab[(size_t)kk * rsc + col] = acc[i][t * NJ + j][e];
         }
   if (BIAS && bias_wave && fr == 0) {  // every column of bacc holds the same sums: lane column 0 reports
 #pragma unroll
     for (int i = 0; i < MJ; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) atomicAdd(a.dbias + k0 + cout_w + i * 16 + fg * 4 + e, bacc[i][e]);
+      for (int e = 0; e < 4; ++e) a.dbias[(size_t)blockIdx.z * a.K + k0 + cout_w + i * 16 + fg * 4 + e] = bacc[i][e];
   }
 }
 
@@ -1020,17 +1189,20 @@ int set_lds(K kernel, int bytes) {
   return e == hipSuccess ? WM_OK : (int)e;
 }
 
-template <int BM, int BN, int CPT, int MODE, bool EPI = false>
+template <int BM, int BN, int CPT, int MODE, bool EPI = false, bool BNB = false>
 int launch_igemm(const ConvArgs& a, hipStream_t st) {
+  // two operand stages; the epilogue reuses them: staged tile BM x (BN * 2 + 16) B + the forward-statistics scratch
+  // (2 x 256 floats) or the 16 KB of cross-thread sums of the BatchNorm-backward epilogue -- always smaller
   constexpr int lds = 2 * (BM * CV_ROW + BN * CV_ROW);
+  static_assert(BM * (BN * 2 + 16) + 2 * CV_THREADS * 4 <= lds, "epilogue LDS");
   static bool attr = false;
   if (!attr) {
-    const int rc = set_lds(&conv_igemm<BM, BN, CPT, MODE, EPI>, lds);
+    const int rc = set_lds(&conv_igemm<BM, BN, CPT, MODE, EPI, BNB>, lds);
     if (rc != WM_OK) return rc;
     attr = true;
   }
   dim3 grid(wm_cdiv(a.M, BM), a.DC / BN);
-  conv_igemm<BM, BN, CPT, MODE, EPI><<<grid, CV_THREADS, lds, st>>>(a);
+  conv_igemm<BM, BN, CPT, MODE, EPI, BNB><<<grid, CV_THREADS, lds, st>>>(a);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -1074,18 +1246,40 @@ inline bool stem_patch_ok(const ConvArgs& a) {
   return true;
 }
 
-template <int MODE>
+template <int MODE, bool BNB = false>
 int launch_patch(const ConvArgs& a, hipStream_t st) {
+  static_assert(128 * (64 * 2 + 16) + 2 * CV_THREADS * 4 <= PT_LDS, "epilogue LDS");
   static bool attr = false;
   if (!attr) {
-    const int rc = set_lds(&conv3x3_patch<MODE>, PT_LDS);
+    const int rc = set_lds(&conv3x3_patch<MODE, BNB>, PT_LDS);
     if (rc != WM_OK) return rc;
     attr = true;
   }
   const int blocks = (int)((long long)a.N * (a.DH >> 3) * (a.DW >> 3) / 2);
-  conv3x3_patch<MODE><<<blocks, CV_THREADS, PT_LDS, st>>>(a);
+  conv3x3_patch<MODE, BNB><<<blocks, CV_THREADS, PT_LDS, st>>>(a);
   WM_LAUNCH_CHECK();
   return WM_OK;
+}
+
+// split-K plan of a weight-gradient launch: enough blocks to fill the chip (2 resident per CU), no more -- every split
+// writes (and the fold reads) one K x R x S x C slab
+inline void wgrad_plan(const WgradArgs& a, int BMO, int NT, int& nsplit, int& chunks_per_split, int& total_chunks) {
+  const int colgroups = a.R * a.S * a.C / 64 / NT;
+  const int ktiles = a.K / BMO;
+  total_chunks = wm_cdiv((long long)a.N * a.P * a.Q, WG_PIX);
+  static int target = 0;
+  if (target == 0) {
+    const char* e = getenv("WM_WGRAD_BLOCKS");
+    target = e ? atoi(e) : 512;
+  }
+  // Linear layers (1 x 1 on a 1 x 1 image: the transformer GEMMs): the output tile is small and every split ends in
+  // a K x C f32 slab, so half the blocks (measured on DINO ViT-Tiny with atomics: 3.06 vs 3.57 ms of wgrad per step)
+  const int tgt = (a.R * a.S == 1 && a.H * a.W == 1 && target == 512) ? 256 : target;
+  nsplit = tgt / (colgroups * ktiles);
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > total_chunks) nsplit = total_chunks;
+  chunks_per_split = wm_cdiv(total_chunks, nsplit);
+  nsplit = wm_cdiv(total_chunks, chunks_per_split);
 }
 
 template <int BMO, int CPT, int NT, bool BIAS>
@@ -1097,25 +1291,9 @@ int launch_wgrad_impl(WgradArgs a, hipStream_t st) {
     if (rc != WM_OK) return rc;
     attr = true;
   }
-  const int colgroups = a.R * a.S * a.C / 64 / NT;
-  const int ktiles = a.K / BMO;
-  a.total_chunks = wm_cdiv(a.M, WG_PIX);
-  // split-K factor: enough blocks to fill the chip (2 resident per CU), no more — every block ends
-  // with one f32 atomic per accumulator element, so the atomic traffic grows with the split count
-  static int target = 0;
-  if (target == 0) {
-    const char* e = getenv("WM_WGRAD_BLOCKS");
-    target = e ? atoi(e) : 512;
-  }
-  // Linear layers (1 x 1 on a 1 x 1 image: the transformer GEMMs): the output tile is small and every split ends in
-  // K x C f32 atomics, so half the blocks (measured on DINO ViT-Tiny: 3.06 vs 3.57 ms of wgrad per step)
-  const int tgt = (a.R * a.S == 1 && a.H * a.W == 1 && target == 512) ? 256 : target;
-  int nsplit = tgt / (colgroups * ktiles);
-  if (nsplit < 1) nsplit = 1;
-  if (nsplit > a.total_chunks) nsplit = a.total_chunks;
-  a.chunks_per_split = wm_cdiv(a.total_chunks, nsplit);
-  nsplit = wm_cdiv(a.total_chunks, a.chunks_per_split);
-  dim3 grid(colgroups, ktiles, nsplit);
+  int nsplit;
+  wgrad_plan(a, BMO, NT, nsplit, a.chunks_per_split, a.total_chunks);
+  dim3 grid(a.R * a.S * a.C / 64 / NT, a.K / BMO, nsplit);
   conv_wgrad<BMO, CPT, NT, BIAS><<<grid, CV_THREADS, lds, st>>>(a);
   WM_LAUNCH_CHECK();
   return WM_OK;
@@ -1126,6 +1304,43 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   if (a.dbias == nullptr) return launch_wgrad_impl<BMO, CPT, NT, false>(a, st);
   if constexpr (CPT == 8) return launch_wgrad_impl<BMO, CPT, NT, true>(a, st);
   return WM_EUNSUPPORTED;  // no bias gradient on the space-to-depth stem form
+}
+
+// tile configuration of a weight-gradient shape (one place: the launch and wm_conv2d_wgrad_splits must agree)
+inline void wgrad_config(int C, int K, int R, int S, int& bmo, int& cpt, int& nt) {
+  const int coltiles = R * S * C / 64;
+  if (C == 16) {  // stem: the 4 kernel rows together
+    cpt = 2;
+    if (K % 128 == 0) { bmo = 128; nt = coltiles % 2 == 0 ? 2 : 1; }
+    else { bmo = 64; nt = coltiles % 4 == 0 ? 4 : 1; }
+    return;
+  }
+  cpt = 8;
+  if (K % 128 == 0) {
+    bmo = 128;
+    static int force_nt = -1;  // WM_WGRAD_NT: experiment switch (1, 2 or 3 column tiles per block)
+    if (force_nt < 0) {
+      const char* e = getenv("WM_WGRAD_NT");
+      force_nt = e ? atoi(e) : 0;
+    }
+    if (force_nt == 3 && coltiles % 3 == 0) { nt = 3; return; }
+    if (force_nt == 2 && coltiles % 2 == 0) { nt = 2; return; }
+    if (force_nt == 1) { nt = 1; return; }
+    // column tiles per block, measured per ResNet-18 shape at batch 512 (profiles/r01_conv_layers_v3.txt):
+    // three taps per block where the dY tile is the larger share of the traffic (C <= 128 with K = 128)
+    // and for the 512-channel layers, two for 256 channels, one for the stride-2 128 -> 256 layer
+    nt = (coltiles % 2 == 0 && C > 128) ? 2 : 1;
+    if (R * S == 9) {
+      if (C <= 128 && K == 128) nt = 3;
+      else if (C == 128) nt = 1;
+      else if (C >= 512) nt = 3;
+    }
+    if (nt == 3 && coltiles % 3 != 0) nt = 1;
+    if (nt == 2 && coltiles % 2 != 0) nt = 1;
+    return;
+  }
+  bmo = 64;
+  nt = coltiles % 3 == 0 ? 3 : 1;
 }
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
@@ -1148,7 +1363,7 @@ static int conv_check(int N, int H, int W, int C, int K, int R, int S, int P, in
 }
 
 static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int R,
-                         int S, int P, int Q, int stride, int pad, float* stat, int stat_nb, int stat_rpg,
+                         int S, int P, int Q, int stride, int pad, unsigned long long* stat, int stat_nb, int stat_rpg,
                          void* stream, const float* bias = nullptr, const void* residual = nullptr,
                          void* pre_out = nullptr);
 
@@ -1165,16 +1380,17 @@ extern "C" int wm_conv2d_fwd_bias_res(const void* x, const void* w_krsc, const f
 }
 
 extern "C" int wm_conv2d_fwd_stats(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C,
-                                   int K, int R, int S, int P, int Q, int stride, int pad, float* stat_part,
+                                   int K, int R, int S, int P, int Q, int stride, int pad, void* stat_part,
                                    int stat_buckets, int rows_per_group, void* stream) {
   WM_REQUIRE(stat_part && stat_buckets > 0 && rows_per_group > 0, WM_EINVAL);
   WM_REQUIRE(rows_per_group % 128 == 0 && ((long long)N * P * Q) % rows_per_group == 0, WM_EUNSUPPORTED);
-  return conv_fwd_impl(x, w_krsc, y, N, H, W, C, K, R, S, P, Q, stride, pad, stat_part, stat_buckets,
-                       rows_per_group, stream);
+  WM_REQUIRE((reinterpret_cast<uintptr_t>(stat_part) & 7) == 0, WM_EALIGN);
+  return conv_fwd_impl(x, w_krsc, y, N, H, W, C, K, R, S, P, Q, stride, pad, static_cast<unsigned long long*>(stat_part),
+                       stat_buckets, rows_per_group, stream);
 }
 
 static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int R,
-                         int S, int P, int Q, int stride, int pad, float* stat, int stat_nb, int stat_rpg,
+                         int S, int P, int Q, int stride, int pad, unsigned long long* stat, int stat_nb, int stat_rpg,
                          void* stream, const float* bias, const void* residual, void* pre_out) {
   WM_REQUIRE(pre_out == nullptr || (residual == nullptr && R == 1 && S == 1), WM_EUNSUPPORTED);
   WM_REQUIRE(x && w_krsc && y, WM_EINVAL);
@@ -1195,6 +1411,8 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   a.pre_in = nullptr;
   a.pre_out = static_cast<uint16_t*>(pre_out);
   a.act = pre_out != nullptr ? 1 : 0;
+  a.bn_y = a.bn_x = nullptr;
+  a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (C == 16) {
     WM_REQUIRE(bias == nullptr && residual == nullptr, WM_EUNSUPPORTED);
@@ -1228,9 +1446,18 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   return K % 128 == 0 ? launch_igemm<128, 128, 8, 0>(a, st) : launch_igemm<128, 64, 8, 0>(a, st);
 }
 
+struct BnbArgs {  // BatchNorm-backward epilogue (ConvArgs: bn_*)
+  const void* bn_y;
+  const void* bn_x;
+  const float *mean, *invstd, *gamma, *beta;
+  int G;
+  unsigned long long* stat;
+  int stat_nb;
+};
+
 static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const void* residual, int N, int H,
                            int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, void* stream,
-                           const void* pre_in = nullptr);
+                           const void* pre_in = nullptr, const BnbArgs* bnb = nullptr);
 
 // Linear + bias + GELU in one launch (ViT MLP fc1): pre = x W^T + bias -> pre_out (bf16, saved for the backward
 // pass), gelu(pre) -> y.
@@ -1263,9 +1490,36 @@ extern "C" int wm_conv2d_dgrad_add(const void* dy, const void* w_crsk, const voi
   return conv_dgrad_impl(dy, w_crsk, dx, residual, N, H, W, C, K, R, S, P, Q, stride, pad, stream);
 }
 
+// Can the BatchNorm-backward epilogue serve this dgrad?  Every 128-row tile must lie inside one statistics group
+// (stride 2: inside one group of one parity class) and the kernel must be one of the BNB instantiations.
+extern "C" int wm_conv2d_dgrad_bnstat_ok(int N, int H, int W, int C, int K, int R, int S, int P, int Q, int stride,
+                                         int pad, int G) {
+  if (conv_check(N, H, W, C, K, R, S, P, Q, stride, pad) != WM_OK || C % 64 != 0 || G <= 0 || N % G != 0) return 0;
+  const long long rows = (long long)N * H * W;
+  if (stride == 1) return (rows / G) % 128 == 0 ? 1 : 0;
+  if (H % 2 || W % 2) return 0;
+  const long long cls = (long long)N * (H / 2) * (W / 2);
+  return (cls % 128 == 0 && (cls / G) % 128 == 0) ? 1 : 0;
+}
+
+extern "C" int wm_conv2d_dgrad_bnstat(const void* dy, const void* w_crsk, const void* residual, void* dx, int N, int H,
+                                      int W, int C, int K, int R, int S, int P, int Q, int stride, int pad,
+                                      const void* bn_y, const void* relu_x, const float* gamma, const float* beta,
+                                      const float* save_mean, const float* save_invstd, int G, void* stat_part,
+                                      int stat_buckets, void* stream) {
+  WM_REQUIRE(bn_y && save_mean && save_invstd && stat_part && stat_buckets > 0, WM_EINVAL);
+  WM_REQUIRE(relu_x || (gamma && beta), WM_EINVAL);
+  WM_REQUIRE(wm_conv2d_dgrad_bnstat_ok(N, H, W, C, K, R, S, P, Q, stride, pad, G), WM_EUNSUPPORTED);
+  WM_REQUIRE(aligned16(bn_y) && aligned16(save_mean) && aligned16(save_invstd) && (relu_x == nullptr || aligned16(relu_x)) &&
+                 (residual == nullptr || aligned16(residual)) && (reinterpret_cast<uintptr_t>(stat_part) & 7) == 0,
+             WM_EALIGN);
+  BnbArgs b{bn_y, relu_x, save_mean, save_invstd, gamma, beta, G, static_cast<unsigned long long*>(stat_part), stat_buckets};
+  return conv_dgrad_impl(dy, w_crsk, dx, residual, N, H, W, C, K, R, S, P, Q, stride, pad, stream, nullptr, &b);
+}
+
 static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const void* residual, int N, int H,
                            int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, void* stream,
-                           const void* pre_in) {
+                           const void* pre_in, const BnbArgs* bnb) {
   WM_REQUIRE(dy && w_crsk && dx, WM_EINVAL);
   WM_REQUIRE(pre_in == nullptr || (residual == nullptr && R == 1 && S == 1 && stride == 1 && aligned16(pre_in)), WM_EUNSUPPORTED);
   const int rc = conv_check(N, H, W, C, K, R, S, P, Q, stride, pad);
@@ -1289,6 +1543,22 @@ static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const v
   a.pre_in = static_cast<const uint16_t*>(pre_in);
   a.pre_out = nullptr;
   a.act = pre_in != nullptr ? 2 : 0;
+  a.bn_y = a.bn_x = nullptr;
+  a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr;
+  if (bnb != nullptr) {
+    WM_REQUIRE(pre_in == nullptr, WM_EUNSUPPORTED);
+    a.bn_y = static_cast<const uint16_t*>(bnb->bn_y);
+    a.bn_x = static_cast<const uint16_t*>(bnb->bn_x);
+    a.bn_mean = bnb->mean; a.bn_invstd = bnb->invstd; a.bn_gamma = bnb->gamma; a.bn_beta = bnb->beta;
+    a.stat = bnb->stat; a.stat_nb = bnb->stat_nb;
+    if (stride == 1) {
+      a.stat_rpg = (int)((long long)N * H * W / bnb->G);
+      if (conv_patch_ok(a)) return launch_patch<1, true>(a, st);
+      return C % 128 == 0 ? launch_igemm<128, 128, 8, 3, false, true>(a, st) : launch_igemm<128, 64, 8, 3, false, true>(a, st);
+    }
+    a.stat_rpg = (int)((long long)N * (H / 2) * (W / 2) / bnb->G);
+    return C % 128 == 0 ? launch_igemm<128, 128, 8, 2, false, true>(a, st) : launch_igemm<128, 64, 8, 2, false, true>(a, st);
+  }
   if (pre_in != nullptr)
     return C % 128 == 0 ? launch_igemm<128, 128, 8, 3, true>(a, st) : launch_igemm<128, 64, 8, 3, true>(a, st);
   if (conv_patch_ok(a)) return launch_patch<1>(a, st);
@@ -1329,32 +1599,27 @@ extern "C" int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_krs
   a.stride = stride; a.pad = pad; a.M = N * P * Q;
   a.chunks_per_split = 0; a.total_chunks = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const int coltiles = R * S * C / 64;
-  if (C == 16) {  // stem: the 4 kernel rows together
-    if (K % 128 == 0) return coltiles % 2 == 0 ? launch_wgrad<128, 2, 2>(a, st) : launch_wgrad<128, 2, 1>(a, st);
-    return coltiles % 4 == 0 ? launch_wgrad<64, 2, 4>(a, st) : launch_wgrad<64, 2, 1>(a, st);
+  int bmo, cpt, nt;
+  wgrad_config(C, K, R, S, bmo, cpt, nt);
+  if (cpt == 2) {
+    if (bmo == 128) return nt == 2 ? launch_wgrad<128, 2, 2>(a, st) : launch_wgrad<128, 2, 1>(a, st);
+    return nt == 4 ? launch_wgrad<64, 2, 4>(a, st) : launch_wgrad<64, 2, 1>(a, st);
   }
-  if (K % 128 == 0) {
-    static int force_nt = -1;  // WM_WGRAD_NT: experiment switch (1, 2 or 3 column tiles per block)
-    if (force_nt < 0) {
-      const char* e = getenv("WM_WGRAD_NT");
-      force_nt = e ? atoi(e) : 0;
-    }
-    if (force_nt == 3 && coltiles % 3 == 0) return launch_wgrad<128, 8, 3>(a, st);
-    if (force_nt == 2 && coltiles % 2 == 0) return launch_wgrad<128, 8, 2>(a, st);
-    if (force_nt == 1) return launch_wgrad<128, 8, 1>(a, st);
-    // column tiles per block, measured per ResNet-18 shape at batch 512 (profiles/r01_conv_layers_v3.txt):
-    // three taps per block where the dY tile is the larger share of the traffic (C <= 128 with K = 128)
-    // and for the 512-channel layers, two for 256 channels, one for the stride-2 128 -> 256 layer
-    int nt = (coltiles % 2 == 0 && C > 128) ? 2 : 1;
-    if (R * S == 9) {
-      if (C <= 128 && K == 128) nt = 3;
-      else if (C == 128) nt = 1;
-      else if (C >= 512) nt = 3;
-    }
-    if (nt == 3 && coltiles % 3 == 0) return launch_wgrad<128, 8, 3>(a, st);
-    if (nt == 2 && coltiles % 2 == 0) return launch_wgrad<128, 8, 2>(a, st);
+  if (bmo == 128) {
+    if (nt == 3) return launch_wgrad<128, 8, 3>(a, st);
+    if (nt == 2) return launch_wgrad<128, 8, 2>(a, st);
     return launch_wgrad<128, 8, 1>(a, st);
   }
-  return coltiles % 3 == 0 ? launch_wgrad<64, 8, 3>(a, st) : launch_wgrad<64, 8, 1>(a, st);
+  return nt == 3 ? launch_wgrad<64, 8, 3>(a, st) : launch_wgrad<64, 8, 1>(a, st);
+}
+
+extern "C" int wm_conv2d_wgrad_splits(int N, int H, int W, int C, int K, int R, int S, int P, int Q, int stride, int pad) {
+  const int rc = conv_check(N, H, W, C, K, R, S, P, Q, stride, pad);
+  if (rc != WM_OK) return rc;
+  WgradArgs a{};
+  a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.P = P; a.Q = Q;
+  int bmo, cpt, nt, nsplit, cps, tc;
+  wgrad_config(C, K, R, S, bmo, cpt, nt);
+  wgrad_plan(a, bmo, nt, nsplit, cps, tc);
+  return nsplit;
 }

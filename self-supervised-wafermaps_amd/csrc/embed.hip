@@ -171,8 +171,8 @@ __global__ __launch_bounds__(256) void ntxent_fwd_kernel(const float* __restrict
 }
 
 // blockIdx.y = column split (tiles_per_split column tiles each): with one block per 32 local rows the
-// 512 x 512 problem of the headline configuration ran on 16 CUs for 160 us.  Split blocks add their
-// partial row gradients into a zeroed dzn with f32 atomics (nsplit == 1: plain stores, deterministic).
+// 512 x 512 problem of the headline configuration ran on 16 CUs for 160 us.  Split blocks store their
+// partial row gradients into slab blockIdx.y of a workspace; ntxent_bwd_reduce sums the slabs in order.
 __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
     const float* __restrict__ zn, const float* __restrict__ zall,
     const float* __restrict__ lse_all, int b_local, int b_global, int rank_offset, int d,
@@ -251,18 +251,25 @@ __global__ __launch_bounds__(256) void ntxent_bwd_kernel(
       if (u < nu) {
         float4 o = out[u];
         o.x *= sc; o.y *= sc; o.z *= sc; o.w *= sc;
-        float* dst = dzn + (size_t)lr * d + gsel * 4 + u * 32;
-        if (nsplit == 1) {
-          *reinterpret_cast<float4*>(dst) = o;
-        } else {
-          atomicAdd(dst, o.x);
-          atomicAdd(dst + 1, o.y);
-          atomicAdd(dst + 2, o.z);
-          atomicAdd(dst + 3, o.w);
-        }
+        // nsplit > 1: dzn is the partial-sum workspace [nsplit][2 b_local][d]; ntxent_bwd_reduce adds the splits in
+        // order (no atomics: the gradient is bit-reproducible)
+        float* dst = dzn + ((size_t)blockIdx.y * nlocal + lr) * d + gsel * 4 + u * 32;
+        *reinterpret_cast<float4*>(dst) = o;
       }
     }
   }
+}
+
+__global__ __launch_bounds__(256) void ntxent_bwd_reduce(const float4* __restrict__ part, int nsplit, long long n4,
+                                                         float4* __restrict__ out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = part[i];
+  for (int sp = 1; sp < nsplit; ++sp) {
+    const float4 t = part[(size_t)sp * n4 + i];
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  out[i] = v;
 }
 
 }  // namespace
@@ -334,9 +341,26 @@ extern "C" int wm_ntxent_fwd(const float* zn, const float* zall, int b_local, in
   return WM_OK;
 }
 
+static void nx_bwd_plan(int b_local, int b_global, int& rowtiles, int& nsplit, int& tiles_per_split) {
+  rowtiles = wm_cdiv(2 * b_local, NX_RT);
+  const int coltiles = wm_cdiv(2 * b_global, NX_CT);
+  nsplit = 256 / rowtiles;  // about one block per CU
+  if (nsplit < 1) nsplit = 1;
+  if (nsplit > coltiles) nsplit = coltiles;
+  tiles_per_split = wm_cdiv(coltiles, nsplit);
+  nsplit = wm_cdiv(coltiles, tiles_per_split);
+}
+
+extern "C" size_t wm_ntxent_bwd_workspace_bytes(int b_local, int b_global, int d) {
+  if (b_local <= 0 || b_global < b_local || d <= 0) return 0;
+  int rowtiles, nsplit, tps;
+  nx_bwd_plan(b_local, b_global, rowtiles, nsplit, tps);
+  return nsplit > 1 ? (size_t)nsplit * 2 * b_local * d * sizeof(float) : 16;
+}
+
 extern "C" int wm_ntxent_bwd(const float* zn, const float* zall, const float* lse_all, int b_local,
                              int b_global, int rank_offset, int d, float temperature,
-                             float grad_scale, float* dzn, void* stream) {
+                             float grad_scale, float* dzn, void* workspace, size_t workspace_bytes, void* stream) {
   const int rc = nx_check(zn, zall, lse_all, dzn, b_local, b_global, rank_offset, d, temperature);
   if (rc != WM_OK) return rc;
   const size_t lds =
@@ -348,22 +372,24 @@ extern "C" int wm_ntxent_bwd(const float* zn, const float* zall, const float* ls
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
-  const int rowtiles = wm_cdiv(2 * b_local, NX_RT), coltiles = wm_cdiv(2 * b_global, NX_CT);
-  int nsplit = 256 / rowtiles;  // about one block per CU
-  if (nsplit < 1) nsplit = 1;
-  if (nsplit > coltiles) nsplit = coltiles;
-  const int tiles_per_split = wm_cdiv(coltiles, nsplit);
-  nsplit = wm_cdiv(coltiles, tiles_per_split);
+  int rowtiles, nsplit, tiles_per_split;
+  nx_bwd_plan(b_local, b_global, rowtiles, nsplit, tiles_per_split);
   hipStream_t st = static_cast<hipStream_t>(stream);
+  float* target = dzn;
   if (nsplit > 1) {
-    // a zero-fill KERNEL, not hipMemsetAsync: as a memset NODE inside the captured training graph this clear
-    // was not reliably applied before the atomics below (profiles/r02_nan_root_cause.md)
-    hipError_t e = wm_zero_async(dzn, (size_t)2 * b_local * d * sizeof(float), st);
-    if (e != hipSuccess) return (int)e;
+    WM_REQUIRE(workspace && workspace_bytes >= wm_ntxent_bwd_workspace_bytes(b_local, b_global, d), WM_EWORKSPACE);
+    WM_REQUIRE((reinterpret_cast<uintptr_t>(workspace) & 15) == 0 && (reinterpret_cast<uintptr_t>(dzn) & 15) == 0, WM_EALIGN);
+    target = static_cast<float*>(workspace);
   }
   ntxent_bwd_kernel<<<dim3(rowtiles, nsplit), 256, lds, st>>>(
-      zn, zall, lse_all, b_local, b_global, rank_offset, d, temperature, grad_scale, tiles_per_split, nsplit, dzn);
+      zn, zall, lse_all, b_local, b_global, rank_offset, d, temperature, grad_scale, tiles_per_split, nsplit, target);
   WM_LAUNCH_CHECK();
+  if (nsplit > 1) {
+    const long long n4 = (long long)2 * b_local * d / 4;
+    ntxent_bwd_reduce<<<wm_cdiv(n4, 256), 256, 0, st>>>(reinterpret_cast<const float4*>(target), nsplit, n4,
+                                                        reinterpret_cast<float4*>(dzn));
+    WM_LAUNCH_CHECK();
+  }
   return WM_OK;
 }
 

@@ -30,7 +30,7 @@ __global__ void weights_prepare(const float* __restrict__ w, int K, int C, int R
   }
 }
 
-__global__ void wgrad_finalize(float* __restrict__ ws, int K, int C, int R, int S,
+__global__ void wgrad_finalize(const float* __restrict__ ws, int nsplit, int K, int C, int R, int S,
                                float* __restrict__ grad, int accumulate) {
   const long long total = (long long)K * C * R * S;
   for (long long t = (long long)blockIdx.x * LT_THREADS + threadIdx.x; t < total;
@@ -42,8 +42,8 @@ __global__ void wgrad_finalize(float* __restrict__ ws, int K, int C, int R, int 
     u /= R;
     const int c = (int)(u % C), k = (int)(u / C);
     const size_t wi = (((size_t)k * R + r) * S + s) * C + c;
-    const float v = ws[wi];
-    ws[wi] = 0.f;  // read-and-clear: the accumulator is ready for the next step's atomics
+    float v = 0.f;
+    for (int sp = 0; sp < nsplit; ++sp) v += ws[(size_t)sp * total + wi];  // slabs in order: bit-reproducible
     grad[t] = accumulate ? grad[t] + v : v;
   }
 }
@@ -63,16 +63,40 @@ __global__ void stem_weights_prepare(const float* __restrict__ w, int K, uint16_
   }
 }
 
-__global__ void stem_wgrad_finalize(float* __restrict__ ws, int K, float* __restrict__ grad,
-                                    int accumulate) {
-  const int total = K * 147;
-  for (int t = blockIdx.x * LT_THREADS + threadIdx.x; t < total; t += gridDim.x * LT_THREADS) {
-    const int s = t % 7, r = (t / 7) % 7, c = (t / 49) % 3, k = t / 147;
-    const int a = (r + 1) >> 1, dh = (r + 1) & 1, b = (s + 1) >> 1, dw = (s + 1) & 1;
-    const int wi = ((k * 4 + a) * 4 + b) * 16 + (dh * 2 + dw) * 3 + c;
-    const float v = ws[wi];
-    ws[wi] = 0.f;  // read-and-clear (the 4 pad channels and the r' = 0 taps are never written)
-    grad[t] = accumulate ? grad[t] + v : v;
+// One block per output channel k: 1024 threads = 4 slab ranges x the 256 space-to-depth positions of k.  Each range is
+// summed in slab order (eight loads in flight), the four partial sums are combined in range order: the result does
+// not depend on scheduling.  (The stem's weight gradient has one column group, so its split count is ~512.)
+__global__ __launch_bounds__(1024) void stem_wgrad_finalize(const float* __restrict__ ws, int nsplit, int K,
+                                                            float* __restrict__ grad, int accumulate) {
+  __shared__ float red[4][256];
+  const int k = blockIdx.x, wi = threadIdx.x & 255, q = threadIdx.x >> 8;
+  const int per = (nsplit + 3) >> 2;
+  const int s0 = q * per, s1 = min(nsplit, s0 + per);
+  const size_t slab = (size_t)K * 256;
+  const float* src = ws + (size_t)k * 256 + wi;
+  float v = 0.f;
+  int sp = s0;
+  for (; sp + 8 <= s1; sp += 8) {
+    float t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = src[(size_t)(sp + u) * slab];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v += t[u];
+  }
+  for (; sp < s1; ++sp) v += src[(size_t)sp * slab];
+  red[q][wi] = v;
+  __syncthreads();
+  if (q == 0) {
+    const float tot = ((red[0][wi] + red[1][wi]) + red[2][wi]) + red[3][wi];
+    const int ch = wi & 15, b = (wi >> 4) & 3, a = wi >> 6;
+    if (ch < 12) {
+      const int c = ch % 3, dw = (ch / 3) & 1, dh = ch / 6;
+      const int r = 2 * a + dh - 1, s = 2 * b + dw - 1;
+      if (r >= 0 && s >= 0) {
+        float* g = grad + ((k * 3 + c) * 7 + r) * 7 + s;
+        *g = accumulate ? *g + tot : tot;
+      }
+    }
   }
 }
 
@@ -181,38 +205,57 @@ __global__ __launch_bounds__(LT_THREADS) void layouts_refresh_batched(const WmLa
   else refresh_tile<1>(d, tk * LB_T, tc * LB_T, tile);
 }
 
+// One (32 x 32 (k, c) tile, tap) of one parameter: sum of its nsplit weight-gradient slabs [K][RS][C], in slab order
+// (fixed: bit-reproducible), added to the OIHW gradient.  Reads are 128-byte rows of every slab; the OIHW side is a
+// strided 4-byte read-modify-write (gradients are a few per cent of the slab bytes).
 template <int RS>
-__device__ __forceinline__ void fold_tile(const WmLayoutDesc& d, int k0, int c0, float (*tile)[LB_T][LB_T + 1]) {
-  const int K = d.K, C = d.C;
-  const int nk = min(LB_T, K - k0), nc = min(LB_T, C - c0);
-  const int rowl = threadIdx.x >> 5, pos = threadIdx.x & 31;
-  for (int u = rowl; u < nk * RS; u += LT_THREADS / 32) {
-    const int k = u / RS, rs = u - k * RS;
-    if (pos < nc) {
-      float* src = d.ws + ((size_t)(k0 + k) * RS + rs) * C + c0 + pos;
-      tile[rs][k][pos] = *src;
-      *src = 0.f;
+__device__ __forceinline__ void fold_tile(const WmLayoutDesc& d, int k0, int c0, int rs) {
+  const int K = d.K, C = d.C, ns = d.nsplit;
+  // thread = (k row, four channels): one 16-byte load per slab, eight slabs in flight; C % 4 == 0 (host-checked)
+  const int k = k0 + ((int)threadIdx.x >> 3), c = c0 + ((int)threadIdx.x & 7) * 4;
+  if (k >= K || c >= C) return;
+  const size_t slab = (size_t)K * RS * C;
+  const float* src = d.ws + ((size_t)k * RS + rs) * C + c;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  int sp = 0;
+  for (; sp + 8 <= ns; sp += 8) {
+    float4 t[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)(sp + u) * slab);
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {  // slab order
+      v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w;
     }
   }
-  __syncthreads();
-  for (int k = rowl; k < nk; k += LT_THREADS / 32) {
-    float* g = d.grad + ((size_t)(k0 + k) * C + c0) * RS;
-    for (int j = pos; j < nc * RS; j += 32) {
-      const int c = j / RS, rs = j - c * RS;
-      g[j] += tile[rs][k][c];
-    }
+  for (; sp < ns; ++sp) {
+    const float4 t = *reinterpret_cast<const float4*>(src + (size_t)sp * slab);
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
   }
+  float* g = d.grad + ((size_t)k * C + c) * RS + rs;
+  g[0] += v.x;
+  g[RS] += v.y;
+  g[2 * RS] += v.z;
+  g[3 * RS] += v.w;
 }
 
-// wgrad accumulators [K][RS][C] f32 -> += OIHW gradients, accumulators cleared (read-and-clear), all parameters.
+// weight-gradient slabs -> += OIHW gradients (and bias slabs -> += bias gradients), all parameters of a backward pass.
 __global__ __launch_bounds__(LT_THREADS) void wgrad_fold_batched(const WmLayoutDesc* __restrict__ descs, int n_desc) {
-  __shared__ float tile[LB_MAX_RS][LB_T][LB_T + 1];
   const int di = lb_find(descs, n_desc, blockIdx.x);
   const WmLayoutDesc d = descs[di];
-  const int t = blockIdx.x - d.tile0;
+  int t = blockIdx.x - d.tile0;
+  const int rs = t % d.RS;
+  t /= d.RS;
   const int tk = t / d.tiles_c, tc = t - tk * d.tiles_c;
-  if (d.RS == 9) fold_tile<9>(d, tk * LB_T, tc * LB_T, tile);
-  else fold_tile<1>(d, tk * LB_T, tc * LB_T, tile);
+  if (d.RS == 9) fold_tile<9>(d, tk * LB_T, tc * LB_T, rs);
+  else fold_tile<1>(d, tk * LB_T, tc * LB_T, rs);
+  if (d.w != nullptr && tc == 0 && rs == 0) {  // bias slabs [nsplit][K] -> bias gradient
+    const int k = tk * LB_T + (int)threadIdx.x;
+    if ((int)threadIdx.x < LB_T && k < d.K) {
+      float v = 0.f;
+      for (int sp = 0; sp < d.nsplit; ++sp) v += d.w[(size_t)sp * d.K + k];
+      reinterpret_cast<float*>(d.krsc)[k] += v;
+    }
+  }
 }
 
 inline int grid_for(long long items) {
@@ -247,12 +290,12 @@ extern "C" int wm_wgrad_fold(const WmLayoutDesc* descs_dev, int n_desc, int tota
   return WM_OK;
 }
 
-extern "C" int wm_wgrad_finalize(float* dw_krsc, int K, int C, int R, int S, float* grad_oihw,
+extern "C" int wm_wgrad_finalize(const float* dw_slabs, int nsplit, int K, int C, int R, int S, float* grad_oihw,
                                  int accumulate, void* stream) {
-  WM_REQUIRE(dw_krsc && grad_oihw, WM_EINVAL);
-  WM_REQUIRE(K > 0 && C > 0 && R > 0 && S > 0, WM_EINVAL);
+  WM_REQUIRE(dw_slabs && grad_oihw, WM_EINVAL);
+  WM_REQUIRE(nsplit > 0 && K > 0 && C > 0 && R > 0 && S > 0, WM_EINVAL);
   wgrad_finalize<<<grid_for((long long)K * C * R * S), LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
-      dw_krsc, K, C, R, S, grad_oihw, accumulate);
+      dw_slabs, nsplit, K, C, R, S, grad_oihw, accumulate);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -265,11 +308,10 @@ extern "C" int wm_stem_weights_prepare(const float* w_oihw, int K, void* w_s2d, 
   return WM_OK;
 }
 
-extern "C" int wm_stem_wgrad_finalize(float* dw_s2d, int K, float* grad_oihw, int accumulate,
+extern "C" int wm_stem_wgrad_finalize(const float* dw_s2d_slabs, int nsplit, int K, float* grad_oihw, int accumulate,
                                       void* stream) {
-  WM_REQUIRE(dw_s2d && grad_oihw && K > 0, WM_EINVAL);
-  stem_wgrad_finalize<<<grid_for((long long)K * 147), LT_THREADS, 0, static_cast<hipStream_t>(stream)>>>(
-      dw_s2d, K, grad_oihw, accumulate);
+  WM_REQUIRE(dw_s2d_slabs && grad_oihw && K > 0 && nsplit > 0, WM_EINVAL);
+  stem_wgrad_finalize<<<K, 1024, 0, static_cast<hipStream_t>(stream)>>>(dw_s2d_slabs, nsplit, K, grad_oihw, accumulate);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

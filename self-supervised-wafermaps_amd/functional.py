@@ -258,6 +258,8 @@ def ntxent_backward(zn: torch.Tensor, zall: torch.Tensor, lse_all: torch.Tensor,
     if lse_all.shape != (2 * b_global,) or lse_all.dtype != torch.float32:
         raise ValueError("ntxent_backward: lse_all must be float32 [2*b_global]")
     dzn = torch.empty_like(zn)
-    check(_lib.load().wm_ntxent_bwd(ptr(zn), ptr(zall), ptr(lse_all), b_local, b_global, rank_offset, d,
-                                    float(temperature), float(grad_scale), ptr(dzn), stream_ptr()), "wm_ntxent_bwd")
+    lib = _lib.load()
+    ws = torch.empty(int(lib.wm_ntxent_bwd_workspace_bytes(b_local, b_global, d)), dtype=torch.uint8, device=zn.device)
+    check(lib.wm_ntxent_bwd(ptr(zn), ptr(zall), ptr(lse_all), b_local, b_global, rank_offset, d, float(temperature),
+                            float(grad_scale), ptr(dzn), ptr(ws), ws.numel(), stream_ptr()), "wm_ntxent_bwd")
     return dzn

@@ -317,9 +317,7 @@ class _CrossCorrBarlow(torch.autograd.Function):
         za, zb = za.to(torch.bfloat16).contiguous(), zb.to(torch.bfloat16).contiguous()
         b, d = za.shape
         lib = _lib.load()
-        raw = torch.zeros((d, d), dtype=torch.float32, device=za.device)
-        check(lib.wm_conv2d_wgrad(ptr(za), ptr(zb), ptr(raw), b, 1, 1, d, d, 1, 1, 1, 1, 1, 0, stream_ptr()),
-              "wm_conv2d_wgrad(cross-correlation)")
+        raw = ops.rows_outer_product(za, zb)  # [d][d] cross-correlation
         loss = torch.zeros(1, dtype=torch.float32, device=za.device)
         draw = torch.empty_like(raw)
         check(lib.wm_barlow_twins_fwd_bwd(ptr(raw), d, scale, lambda_param, 1.0, ptr(loss), ptr(draw), stream_ptr()),
@@ -384,9 +382,7 @@ class _VICRegBranch(torch.autograd.Function):
         vloss = torch.zeros(1, dtype=torch.float32, device=z.device)
         coef = torch.empty(d, dtype=torch.float32, device=z.device)
         check(lib.wm_vicreg_variance(ptr(var), n, d, eps, ptr(vloss), ptr(coef), stream_ptr()), "wm_vicreg_variance")
-        raw = torch.zeros((d, d), dtype=torch.float32, device=z.device)
-        check(lib.wm_conv2d_wgrad(ptr(zc), ptr(zc), ptr(raw), n, 1, 1, d, d, 1, 1, 1, 1, 1, 0, stream_ptr()),
-              "wm_conv2d_wgrad(covariance)")
+        raw = ops.rows_outer_product(zc, zc)  # [d][d] covariance
         closs = torch.zeros(1, dtype=torch.float32, device=z.device)
         draw = torch.empty_like(raw)
         check(lib.wm_barlow_twins_fwd_bwd(ptr(raw), d, 1.0 / (n - 1), 1.0 / d, 0.0, ptr(closs), ptr(draw), stream_ptr()),

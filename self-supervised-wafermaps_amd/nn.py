@@ -51,22 +51,25 @@ class _BatchNorm(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def stats_buffer(self, groups: int):
-        """Persistent zeroed [groups, STAT_BUCKETS, 2, C] buffer for statistics fused into the producing
-        convolution's epilogue (the BN finalize kernel clears it again as it reads it)."""
-        buf = getattr(self, "_stat_buf", None)
+    def stats_buffer(self, groups: int, which: str = "_stat_buf"):
+        """Persistent zeroed statistics buffer (ops.new_stats_buffer) for sums fused into a convolution's epilogue:
+        the producing convolution's forward (batch statistics) or, `which="_stat_buf_bwd"`, the consuming
+        convolution's dgrad (backward sums).  The BN finalize kernels clear it again as they read it."""
+        buf = getattr(self, which, None)
         if buf is None or buf.shape[0] != groups or buf.device != self.weight.device:
-            buf = torch.zeros((groups, ops.STAT_BUCKETS, 2, self.num_features), dtype=torch.float32,
-                              device=self.weight.device)
-            self._stat_buf = buf
+            buf = ops.new_stats_buffer(groups, self.num_features, self.weight.device)
+            setattr(self, which, buf)
         return buf
 
     def forward(self, x, residual=None, relu=False, stats=None):
         # num_batches_tracked (+1 per forward call = + the number of statistics groups) is incremented inside
         # the statistics kernel: 22 one-block torch kernels per ResNet-18 step otherwise
+        bwd = None
+        if self.training and relu and x.dim() == 4 and torch.is_grad_enabled():
+            bwd = self.stats_buffer(ops.current_bn_groups(), "_stat_buf_bwd")
         return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
                               residual=residual, relu=relu, eps=self.eps, momentum=self.momentum, stats=stats,
-                              num_batches_tracked=self.num_batches_tracked)
+                              num_batches_tracked=self.num_batches_tracked, bwd_stats=bwd)
 
 
 class BatchNorm2d(_BatchNorm):

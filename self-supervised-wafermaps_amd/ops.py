@@ -8,6 +8,7 @@ kernel with its backward kernels; there is no CPU fallback.
 from __future__ import annotations
 
 import contextlib
+import os
 from typing import Optional
 
 import torch
@@ -101,6 +102,9 @@ def cut_point(x: torch.Tensor, next_module: str) -> torch.Tensor:
     if _CUTS is None or not (torch.is_grad_enabled() and x.requires_grad):
         return x
     leaf = x.detach().requires_grad_(True)
+    link = getattr(x, "_hip_bn", None)
+    if link is not None:  # the next stage's first convolution still runs this BatchNorm's backward sums: the gradient
+        leaf._hip_bn = link  # it leaves in leaf.grad is handed to x.backward() unchanged
     _CUTS.append((next_module, x, leaf))
     return leaf
 
@@ -176,31 +180,40 @@ _WCACHE = _WeightCache()
 import numpy as _np
 
 LAYOUT_DESC = _np.dtype([("w", "<u8"), ("krsc", "<u8"), ("crsk", "<u8"), ("ws", "<u8"), ("grad", "<u8"), ("K", "<i4"),
-                         ("C", "<i4"), ("RS", "<i4"), ("tiles_c", "<i4"), ("tile0", "<i4"), ("reserved", "<i4")])
+                         ("C", "<i4"), ("RS", "<i4"), ("tiles_c", "<i4"), ("tile0", "<i4"), ("nsplit", "<i4")])
 assert LAYOUT_DESC.itemsize == 64
-_TABLES = {}  # key (tuple of pointers and shapes) -> (device table, n_desc, total_tiles)
+_TABLES = {}  # key (tuple of pointers and shapes) -> [device table, n_desc, total_tiles, pinned]
+_TABLES_MAX = 256
 
 
-def _desc_table(rows, device):
-    """rows: [(w, krsc, crsk, ws, grad, K, C, RS)] of raw pointers / ints -> cached device descriptor table."""
-    key = (device.index, tuple(rows))
+def _desc_table(rows, device, per_tap: bool = False):
+    """rows: [(w, krsc, crsk, ws, grad, K, C, RS, nsplit)] of raw pointers / ints -> cached device descriptor table.
+    per_tap: a block owns (tile, tap) (wm_wgrad_fold) instead of a tile with all its taps (wm_layouts_refresh).
+    A table looked up while a hipGraph is being captured has its device address baked into the graph: it is pinned
+    and never evicted (an evicted table's block would return to the caching allocator and later replays would read
+    recycled memory as pointers and shapes)."""
+    key = (device.index, per_tap, tuple(rows))
     ent = _TABLES.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
     if ent is None:
-        if torch.cuda.is_current_stream_capturing():
+        if capturing:
             raise _lib.WaferHipError("a layout descriptor table would have to be built during hipGraph capture: run "
                                      "one eager step (warm-up) with the same model before capturing")
         arr = _np.zeros(len(rows), dtype=LAYOUT_DESC)
         tile0 = 0
-        for i, (w, krsc, crsk, ws, grad, k, c, rs) in enumerate(rows):
+        for i, (w, krsc, crsk, ws, grad, k, c, rs, ns) in enumerate(rows):
             tc = (c + 31) // 32
-            arr[i] = (w, krsc, crsk, ws, grad, k, c, rs, tc, tile0, 0)
-            tile0 += ((k + 31) // 32) * tc
+            arr[i] = (w, krsc, crsk, ws, grad, k, c, rs, tc, tile0, ns)
+            tile0 += ((k + 31) // 32) * tc * (rs if per_tap else 1)
         dev_tab = torch.from_numpy(arr.view(_np.uint8).reshape(-1).copy()).to(device)
-        if len(_TABLES) > 64:
-            _TABLES.clear()
-        ent = (dev_tab, len(rows), tile0)
+        if len(_TABLES) >= _TABLES_MAX:
+            for old_key in [kk for kk, vv in _TABLES.items() if not vv[3]][: _TABLES_MAX // 2]:
+                del _TABLES[old_key]
+        ent = [dev_tab, len(rows), tile0, False]
         _TABLES[key] = ent
-    return ent
+    if capturing:
+        ent[3] = True
+    return ent[0], ent[1], ent[2]
 
 
 def refresh_layouts(params) -> int:
@@ -225,7 +238,7 @@ def refresh_layouts(params) -> int:
         if r * s not in (1, 9) or not p.is_contiguous() or p.dtype != torch.float32:
             continue
         krsc, crsk = ent[1], ent[2]
-        rows.append((p.data_ptr(), ptr(krsc), ptr(crsk), 0, 0, k, c, r * s))
+        rows.append((p.data_ptr(), ptr(krsc), ptr(crsk), 0, 0, k, c, r * s, 0))
         todo.append((p, kind, krsc, crsk))
         dev = p.device
     if not rows:
@@ -237,37 +250,136 @@ def refresh_layouts(params) -> int:
     return len(rows)
 
 
-_PENDING_FOLDS = []   # (accumulator, arena gradient slot, K, C, RS) registered by conv backward nodes of one pass
+# ---- weight gradients: split-K slabs (no atomics) -> one batched, ordered fold per backward pass
+_PENDING_FOLDS = []   # (weight, slabs, nsplit, grad slot, K, C, RS, bias slabs, bias grad slot) of the running pass
+_FOLD_QUEUED = False  # the end-of-backward callback of the running pass is registered
+_SPLITS = {}
 
 
-def _queue_fold(ws: torch.Tensor, slot: torch.Tensor, k: int, c: int, rs: int) -> None:
-    if not _PENDING_FOLDS:
+def wgrad_splits(n, h, w, c, k, r, s, p, q, stride, pad) -> int:
+    """Number of pixel-range splits (= slabs) wm_conv2d_wgrad uses for this geometry."""
+    key = (n, h, w, c, k, r, s, p, q, stride, pad)
+    v = _SPLITS.get(key)
+    if v is None:
+        v = int(_lib.load().wm_conv2d_wgrad_splits(n, h, w, c, k, r, s, p, q, stride, pad))
+        if v <= 0:
+            check(v if v < 0 else _lib.WM_EUNSUPPORTED, "wm_conv2d_wgrad_splits")
+        _SPLITS[key] = v
+    return v
+
+
+def _slab_buffers(owner: torch.Tensor, nsplit: int, numel: int, bias_k: int = 0):
+    """Persistent slab buffers of one parameter: f32 [nsplit * numel] (+ [nsplit * bias_k]).  Every wgrad launch
+    overwrites all of its slabs, so nothing is ever zeroed.  A parameter used by several wgrad launches of ONE backward
+    pass (shared weights) gets one buffer per launch: the fold at the end of the pass reads them all."""
+    idx = getattr(owner, "_hip_pending", 0)
+    bufs = getattr(owner, "_hip_wgrad_slabs", None)
+    if bufs is None:
+        bufs = owner._hip_wgrad_slabs = []
+    while len(bufs) <= idx:
+        bufs.append(None)
+    ent = bufs[idx]
+    if (ent is None or ent[0].numel() != nsplit * numel or ent[0].device != owner.device
+            or (bias_k > 0 and (ent[1] is None or ent[1].numel() != nsplit * bias_k))):
+        ent = (torch.empty(nsplit * numel, dtype=torch.float32, device=owner.device),
+               torch.empty(nsplit * bias_k, dtype=torch.float32, device=owner.device) if bias_k > 0 else None)
+        bufs[idx] = ent
+    return ent
+
+
+def wgrad(dy, x, owner, n, h, w, c, k, r, s, p, q, stride, pad, bias_k: int = 0, name: str = "conv_wgrad"):
+    """Launch the weight-gradient kernel of one layer into `owner`'s slab buffer.
+    Returns (slabs, bias slabs or None, nsplit)."""
+    ns = wgrad_splits(n, h, w, c, k, r, s, p, q, stride, pad)
+    slabs, bslabs = _slab_buffers(owner, ns, k * r * s * c, bias_k)
+    lib = _lib.load()
+    if bias_k > 0:
+        check(_run(name, 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_wgrad_bias, ptr(dy), ptr(x), ptr(slabs), ptr(bslabs),
+                   n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_wgrad_bias")
+    else:
+        check(_run(name, 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_wgrad, ptr(dy), ptr(x), ptr(slabs), n, h, w, c, k, r,
+                   s, p, q, stride, pad, stream_ptr()), "wm_conv2d_wgrad")
+    return slabs, bslabs, ns
+
+
+def rows_outer_product(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """sum over rows n of a[n][:] (x) b[n][:] for bf16 a [N, K], b [N, C] -> float32 [K, C]: the weight-gradient GEMM
+    as a plain matrix product (cross-correlation / covariance matrices of the Barlow Twins and VICReg losses)."""
+    n, k = a.shape
+    c = b.shape[1]
+    ns = wgrad_splits(n, 1, 1, c, k, 1, 1, 1, 1, 1, 0)
+    slabs = torch.empty(ns * k * c, dtype=torch.float32, device=a.device)
+    lib = _lib.load()
+    check(lib.wm_conv2d_wgrad(ptr(a), ptr(b), ptr(slabs), n, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()), "wm_conv2d_wgrad")
+    out = torch.empty((k, c), dtype=torch.float32, device=a.device)
+    check(lib.wm_wgrad_finalize(ptr(slabs), ns, k, c, 1, 1, ptr(out), 0, stream_ptr()), "wm_wgrad_finalize")
+    return out
+
+
+def wgrad_deliver(weight, slabs, ns, k, c, r, s, bias=None, bslabs=None):
+    """Turn the slabs of one wgrad launch into gradients: queued for the pass's batched fold when a fused optimiser owns
+    the gradient slot (returns None for that gradient), else summed now into a new tensor.  Returns (dw, dbias)."""
+    lib = _lib.load()
+    slot = _arena_grad(weight)
+    bslot = _arena_grad(bias) if bias is not None else None
+    dw = db = None
+    fold_w = slot is not None and r * s in (1, 9) and c % 4 == 0
+    if fold_w:
+        _queue_fold(weight, slabs, ns, slot, k, c, r * s, bslabs if bslot is not None else None, bslot)
+    else:
+        tgt = slot
+        if tgt is None:
+            dw = tgt = torch.empty((k, c, r, s) if weight.dim() == 4 else (k, c), dtype=torch.float32, device=slabs.device)
+        check(lib.wm_wgrad_finalize(ptr(slabs), ns, k, c, r, s, ptr(tgt), int(slot is not None), stream_ptr()),
+              "wm_wgrad_finalize")
+    if bias is not None and bslabs is not None and not (fold_w and bslot is not None):
+        tgt = bslot
+        if tgt is None:
+            db = tgt = torch.empty((k,), dtype=torch.float32, device=slabs.device)
+        check(lib.wm_wgrad_finalize(ptr(bslabs), ns, k, 1, 1, 1, ptr(tgt), int(bslot is not None), stream_ptr()),
+              "wm_wgrad_finalize(bias)")
+    return dw, db
+
+
+def _queue_fold(weight, slabs, ns, slot, k, c, rs, bslabs=None, bslot=None) -> None:
+    global _FOLD_QUEUED
+    if not _FOLD_QUEUED:
         # runs when the current backward pass completes, on the caller's stream: after loss.backward() returns,
         # every p.grad is complete -- one fold launch per backward pass instead of one per convolution
         torch.autograd.Variable._execution_engine.queue_callback(fold_wgrads)
-    _PENDING_FOLDS.append((ws, slot, k, c, rs))
+        _FOLD_QUEUED = True
+    _PENDING_FOLDS.append((weight, slabs, ns, slot, k, c, rs, bslabs, bslot))
+    weight._hip_pending = getattr(weight, "_hip_pending", 0) + 1
+
+
+def drop_pending_folds() -> None:
+    """Forget folds queued by a backward pass that did not complete (an exception inside backward: the engine runs no
+    end-of-pass callback then).  Called by the optimisers' zero_grad(): the stale entries' slabs are simply overwritten
+    by the next pass, and the next pass registers its callback again."""
+    global _FOLD_QUEUED
+    for ent in _PENDING_FOLDS:
+        ent[0]._hip_pending = 0
+    _PENDING_FOLDS.clear()
+    _FOLD_QUEUED = False
 
 
 def fold_wgrads() -> None:
-    """Add the pending weight-gradient accumulators ([K][R][S][C] f32, filled by conv_wgrad's atomics) into their
-    OIHW gradient slots and clear them: wm_wgrad_fold, one launch."""
+    """Sum the pending weight-gradient slabs ([nsplit][K][R][S][C] f32, in slab order) into their OIHW gradient slots
+    (and bias slabs into bias gradients): wm_wgrad_fold, one launch."""
+    global _FOLD_QUEUED
+    _FOLD_QUEUED = False
     if not _PENDING_FOLDS:
         return
-    rows = tuple((0, 0, 0, ws.data_ptr(), slot.data_ptr(), k, c, rs) for ws, slot, k, c, rs in _PENDING_FOLDS)
-    dev = _PENDING_FOLDS[0][0].device
-    _PENDING_FOLDS.clear()
-    tab, n, tiles = _desc_table(rows, dev)
+    try:
+        rows = tuple((bs.data_ptr() if bs is not None else 0, bg.data_ptr() if bg is not None else 0, 0, sl.data_ptr(),
+                      slot.data_ptr(), k, c, rs, ns) for _, sl, ns, slot, k, c, rs, bs, bg in _PENDING_FOLDS)
+        dev = _PENDING_FOLDS[0][1].device
+    finally:
+        for ent in _PENDING_FOLDS:
+            ent[0]._hip_pending = 0
+        _PENDING_FOLDS.clear()
+    tab, n, tiles = _desc_table(rows, dev, per_tap=True)
     check(_lib.load().wm_wgrad_fold(ptr(tab), n, tiles, stream_ptr()), "wm_wgrad_fold")
-
-
-def _wgrad_accumulator(weight: torch.Tensor, shape) -> torch.Tensor:
-    """Persistent f32 [K][R][S][C] accumulator of one parameter (zeroed once; wm_wgrad_finalize
-    clears it as it reads it)."""
-    ws = getattr(weight, "_hip_wgrad_ws", None)
-    if ws is None or tuple(ws.shape) != tuple(shape) or ws.device != weight.device:
-        ws = torch.zeros(shape, dtype=torch.float32, device=weight.device)
-        weight._hip_wgrad_ws = ws
-    return ws
 
 
 def _arena_grad(p: torch.Tensor):
@@ -280,7 +392,23 @@ def _arena_grad(p: torch.Tensor):
     return None
 
 
-STAT_BUCKETS = 64  # partial-sum buckets per statistics group in the fused conv epilogue (16 .. 128 measured: no difference)
+STAT_BUCKETS = 64  # most partial-sum buckets per statistics group in the fused conv epilogues (buffer size)
+
+
+def stat_buckets(rows_per_group: int) -> int:
+    """Buckets actually used for a tensor of `rows_per_group` rows per statistics group: ~16 tiles of 128 rows per
+    bucket, a power of two in 4 .. STAT_BUCKETS (the finalize kernel reads and clears every bucket: 64 buckets of a
+    512-channel layer would be 2 MB per BatchNorm, for 98 tiles)."""
+    nb = 4
+    while nb < STAT_BUCKETS and nb * 2 * 16 * 128 <= rows_per_group:
+        nb *= 2
+    return nb
+
+
+def new_stats_buffer(groups: int, channels: int, device) -> torch.Tensor:
+    """Zeroed int64 [groups, STAT_BUCKETS, 2 statistics, 2 (hi, lo), C]: exact fixed-point partial sums
+    (include/wafer_hip.h, wm_conv2d_fwd_stats); the finalize kernels clear what they read."""
+    return torch.zeros((groups, STAT_BUCKETS, 2, 2, channels), dtype=torch.int64, device=device)
 
 
 def stats_fusable(rows: int, groups: int) -> bool:
@@ -289,13 +417,31 @@ def stats_fusable(rows: int, groups: int) -> bool:
     return groups > 0 and rows % groups == 0 and (rows // groups) % 128 == 0
 
 
+class BnLink:
+    """Rides on the OUTPUT tensor of a training-mode BatchNorm + ReLU (attribute `_hip_bn`): what the convolution that
+    consumes it needs to run that BatchNorm's backward reduction, and the ReLU's backward, inside its own dgrad
+    epilogue (wm_conv2d_dgrad_bnstat).  The convolution's backward fills `g_*` and sets `ready`; the BatchNorm's
+    backward checks that the gradient it receives is exactly that tensor (same storage, unmodified: no other consumer
+    contributed) and then skips its reduction pass, its mask and the dz copy (wm_bn_train_bwd_from_stats)."""
+
+    __slots__ = ("y", "mean", "invstd", "gamma", "beta", "groups", "has_res", "stats", "ready", "g_ptr", "g_version")
+
+    def __init__(self, y, mean, invstd, gamma, beta, groups, has_res, stats):
+        self.y, self.mean, self.invstd, self.gamma, self.beta = y, mean, invstd, gamma, beta
+        self.groups, self.has_res, self.stats = groups, has_res, stats
+        self.ready, self.g_ptr, self.g_version = False, 0, -1
+
+
+_BN_FUSE_BWD = os.environ.get("WM_BN_FUSE_BWD", "1") != "0"  # A/B switch: 0 keeps the separate reduction pass
+
+
 def _out_hw(h, w, r, s, stride, pad):
     return (h + 2 * pad - r) // stride + 1, (w + 2 * pad - s) // stride + 1
 
 
 class _Conv2d(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, stride, pad, stats=None, groups=1, pass_input=False):
+    def forward(ctx, x, weight, stride, pad, stats=None, groups=1, pass_input=False, link=None):
         _need_cuda(x, "conv2d")
         x = _as_nhwc(x)
         n, c, h, w = x.shape
@@ -308,7 +454,7 @@ class _Conv2d(torch.autograd.Function):
         y = _empty_nhwc(n, k, p, q, x.device)
         if stats is not None and stats_fusable(n * p * q, groups):
             check(_run("conv_fwd", 2.0 * n * p * q * k * r * s * c, _lib.load().wm_conv2d_fwd_stats, ptr(x), ptr(krsc),
-                       y.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, ptr(stats), STAT_BUCKETS,
+                       y.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, ptr(stats), stat_buckets(n * p * q // groups),
                        n * p * q // groups, stream_ptr()), "wm_conv2d_fwd_stats")
         else:
             check(_run("conv_fwd", 2.0 * n * p * q * k * r * s * c, _lib.load().wm_conv2d_fwd, ptr(x), ptr(krsc),
@@ -316,6 +462,7 @@ class _Conv2d(torch.autograd.Function):
         ctx.save_for_backward(x)
         ctx.weight = weight
         ctx.geom = (n, h, w, c, k, r, s, p, q, stride, pad)
+        ctx.link = link if (_BN_FUSE_BWD and link is not None and link.y.shape == x.shape) else None
         if pass_input:
             # second output: the input itself (identity).  Its gradient comes back to THIS backward,
             # which adds it inside the dgrad epilogue instead of leaving a separate add to autograd.
@@ -335,6 +482,19 @@ class _Conv2d(torch.autograd.Function):
             dx = _empty_nhwc(n, c, h, w, dy.device)
             if dres is not None:
                 dres = _as_nhwc(dres)
+            link = ctx.link
+            if (link is not None and not link.ready and getattr(link.stats, "_hip_busy", None) is None
+                    and lib.wm_conv2d_dgrad_bnstat_ok(n, h, w, c, k, r, s, p, q, stride, pad, link.groups)):
+                # the input was relu(BN(link.y) (+ shortcut)): ReLU backward + that BatchNorm's backward sums in the epilogue
+                rows_pg = n * h * w // link.groups
+                check(_run("conv_dgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_dgrad_bnstat, dy.data_ptr(), ptr(crsk),
+                           dres.data_ptr() if dres is not None else 0, dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad,
+                           link.y.data_ptr(), x.data_ptr() if link.has_res else 0, ptr(link.gamma), ptr(link.beta),
+                           ptr(link.mean), ptr(link.invstd), link.groups, ptr(link.stats), stat_buckets(rows_pg),
+                           stream_ptr()), "wm_conv2d_dgrad_bnstat")
+                link.ready, link.g_ptr, link.g_version = True, dx.data_ptr(), dx._version
+                link.stats._hip_busy = True
+            elif dres is not None:
                 check(_run("conv_dgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_dgrad_add, dy.data_ptr(),
                            ptr(crsk), dres.data_ptr(), dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad,
                            stream_ptr()), "wm_conv2d_dgrad_add")
@@ -342,26 +502,17 @@ class _Conv2d(torch.autograd.Function):
                 check(_run("conv_dgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_dgrad, dy.data_ptr(), ptr(crsk),
                            dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_dgrad")
         if ctx.needs_input_grad[1]:
-            ws = _wgrad_accumulator(weight, (k, r, s, c))
-            check(_run("conv_wgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_wgrad, dy.data_ptr(), x.data_ptr(),
-                       ptr(ws), n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_wgrad")
-            slot = _arena_grad(weight)
-            if slot is not None and r * s in (1, 9):
-                _queue_fold(ws, slot, k, c, r * s)   # folded with every other convolution's at the end of the pass
-            elif slot is not None:
-                check(lib.wm_wgrad_finalize(ptr(ws), k, c, r, s, ptr(slot), 1, stream_ptr()), "wm_wgrad_finalize")
-            else:
-                dw = torch.empty((k, c, r, s), dtype=torch.float32, device=dy.device)
-                check(lib.wm_wgrad_finalize(ptr(ws), k, c, r, s, ptr(dw), 0, stream_ptr()), "wm_wgrad_finalize")
-        return dx, dw, None, None, None, None, None
+            slabs, _, ns = wgrad(dy, x, weight, n, h, w, c, k, r, s, p, q, stride, pad)
+            dw, _ = wgrad_deliver(weight, slabs, ns, k, c, r, s)
+        return dx, dw, None, None, None, None, None, None
 
 
 def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0,
            stats: Optional[torch.Tensor] = None, groups: int = 1) -> torch.Tensor:
     """bias-free conv2d; x bf16 NHWC (converted if not), weight float32 [K, C, R, S].
-    `stats`: zeroed float32 [groups, STAT_BUCKETS, 2, K] buffer into which the epilogue accumulates the
-    BatchNorm statistics of the output (used when `stats_fusable(rows, groups)`)."""
-    return _Conv2d.apply(x, weight, int(stride), int(padding), stats, int(groups), False)
+    `stats`: zeroed buffer (new_stats_buffer) into which the epilogue accumulates the BatchNorm statistics of the
+    output (used when `stats_fusable(rows, groups)`)."""
+    return _Conv2d.apply(x, weight, int(stride), int(padding), stats, int(groups), False, getattr(x, "_hip_bn", None))
 
 
 def conv2d_passthrough(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0,
@@ -369,7 +520,7 @@ def conv2d_passthrough(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, p
     """conv2d that also hands back its input as a second (identity) output: use that output for the
     residual path of a block, and the gradient of the shortcut is added inside the dgrad kernel's
     epilogue (wm_conv2d_dgrad_add) instead of by a separate elementwise kernel."""
-    return _Conv2d.apply(x, weight, int(stride), int(padding), stats, int(groups), True)
+    return _Conv2d.apply(x, weight, int(stride), int(padding), stats, int(groups), True, getattr(x, "_hip_bn", None))
 
 
 class _StemConv(torch.autograd.Function):
@@ -404,8 +555,8 @@ class _StemConv(torch.autograd.Function):
         y = _empty_nhwc(n, k, h2, w2, x.device)
         if stats is not None and stats_fusable(n * h2 * w2, groups):
             check(_run("conv_fwd", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_fwd_stats, ptr(xs), ptr(ws2d), y.data_ptr(),
-                       n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2, ptr(stats), STAT_BUCKETS, n * h2 * w2 // groups,
-                       stream_ptr()), "wm_conv2d_fwd_stats(stem)")
+                       n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2, ptr(stats), stat_buckets(n * h2 * w2 // groups),
+                       n * h2 * w2 // groups, stream_ptr()), "wm_conv2d_fwd_stats(stem)")
         else:
             check(_run("conv_fwd", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_fwd, ptr(xs), ptr(ws2d), y.data_ptr(), n, h2,
                        w2, 16, k, 4, 4, h2, w2, 1, 2, stream_ptr()), "wm_conv2d_fwd(stem)")
@@ -420,15 +571,13 @@ class _StemConv(torch.autograd.Function):
         n, h2, w2, k = ctx.geom
         dy = _as_nhwc(dy)
         lib = _lib.load()
-        ws = _wgrad_accumulator(ctx.weight, (k, 4, 4, 16))
-        check(_run("conv_wgrad", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_wgrad, dy.data_ptr(), ptr(xs), ptr(ws), n, h2,
-                   w2, 16, k, 4, 4, h2, w2, 1, 2, stream_ptr()), "wm_conv2d_wgrad(stem)")
+        slabs, _, ns = wgrad(dy, xs, ctx.weight, n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2)
         slot = _arena_grad(ctx.weight)
         if slot is not None:
-            check(lib.wm_stem_wgrad_finalize(ptr(ws), k, ptr(slot), 1, stream_ptr()), "wm_stem_wgrad_finalize")
+            check(lib.wm_stem_wgrad_finalize(ptr(slabs), ns, k, ptr(slot), 1, stream_ptr()), "wm_stem_wgrad_finalize")
             return None, None, None, None
         dw = torch.empty((k, 3, 7, 7), dtype=torch.float32, device=dy.device)
-        check(lib.wm_stem_wgrad_finalize(ptr(ws), k, ptr(dw), 0, stream_ptr()), "wm_stem_wgrad_finalize")
+        check(lib.wm_stem_wgrad_finalize(ptr(slabs), ns, k, ptr(dw), 0, stream_ptr()), "wm_stem_wgrad_finalize")
         return None, dw, None, None
 
 
@@ -470,7 +619,7 @@ def _as_act(x: torch.Tensor) -> torch.Tensor:
 class _BatchNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, y, residual, gamma, beta, running_mean, running_var, training, groups, eps, momentum, relu,
-                stats=None, counter=None):
+                stats=None, counter=None, bwd_stats=None):
         _need_cuda(y, "batch_norm")
         y = _as_act(y)
         if residual is not None:
@@ -481,6 +630,7 @@ class _BatchNorm(torch.autograd.Function):
         lib = _lib.load()
         out = torch.empty_like(y)
         ws = _bn_workspace(rows, c, groups if training else 1, y.device)
+        ctx.link = None
         if training:
             if rows % groups:
                 raise ValueError("batch_norm: rows not divisible by groups")
@@ -491,8 +641,8 @@ class _BatchNorm(torch.autograd.Function):
                                                      ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                                      ptr(counter), rows, c,
                                                      groups, eps, momentum, int(relu), ptr(mean), ptr(invstd),
-                                                     out.data_ptr(), ptr(stats), STAT_BUCKETS, ptr(ws), ws.numel(),
-                                                     stream_ptr()), "wm_bn_train_fwd_from_stats")
+                                                     out.data_ptr(), ptr(stats), stat_buckets(rows // groups), ptr(ws),
+                                                     ws.numel(), stream_ptr()), "wm_bn_train_fwd_from_stats")
             else:
                 check(lib.wm_bn_train_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma),
                                           ptr(beta), ptr(running_mean), ptr(running_var), ptr(counter), rows, c, groups, eps,
@@ -503,6 +653,9 @@ class _BatchNorm(torch.autograd.Function):
             ctx.save_for_backward(y, out if (relu and not mask_from_y) else None, mean, invstd)
             ctx.affine = (gamma, beta)
             ctx.meta = (rows, c, groups, relu, residual is not None, mask_from_y)
+            if (bwd_stats is not None and relu and y.dim() == 4 and gamma is not None and beta is not None
+                    and stats_fusable(rows, groups) and ctx.needs_input_grad[0]):
+                ctx.link = BnLink(y, mean, invstd, gamma, beta, groups, residual is not None, bwd_stats)
         else:
             check(lib.wm_bn_eval_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma), ptr(beta),
                                      ptr(running_mean), ptr(running_var), rows, c, eps, int(relu), out.data_ptr(),
@@ -520,30 +673,55 @@ class _BatchNorm(torch.autograd.Function):
         dout = _as_act(dout)
         lib = _lib.load()
         dy = torch.empty_like(y)
-        dz = torch.empty_like(y) if has_res else None
         sg, sb = _arena_grad(gamma), _arena_grad(beta)
         direct = sg is not None and sb is not None
         dgamma = sg if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
         dbeta = sb if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
         ws = _bn_workspace(rows, c, groups, y.device)
-        check(lib.wm_bn_train_bwd(y.data_ptr(), dout.data_ptr(), out.data_ptr() if (relu and not mask_from_y) else 0,
-                                  int(mask_from_y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), rows, c, groups,
-                                  ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(), dz.data_ptr() if has_res else 0,
-                                  ptr(ws), ws.numel(), stream_ptr()), "wm_bn_train_bwd")
+        link = ctx.link
+        fused = False
+        if link is not None and link.ready:
+            link.ready = False
+            link.stats._hip_busy = None
+            if dout.data_ptr() == link.g_ptr and dout._version == link.g_version:
+                # the consuming convolution's dgrad epilogue already applied the ReLU mask to this gradient and
+                # accumulated its sums: finalize + ONE pass; the shortcut's gradient is the masked gradient itself
+                check(lib.wm_bn_train_bwd_from_stats(y.data_ptr(), dout.data_ptr(), ptr(gamma), ptr(beta), ptr(mean),
+                                                     ptr(invstd), rows, c, groups, ptr(dgamma), ptr(dbeta), int(direct),
+                                                     dy.data_ptr(), ptr(link.stats), stat_buckets(rows // groups), ptr(ws),
+                                                     ws.numel(), stream_ptr()), "wm_bn_train_bwd_from_stats")
+                dz = dout if has_res else None
+                fused = True
+            else:
+                # another consumer's gradient was accumulated on top: the sums in the buffer are not this tensor's.
+                # Discard them; the general path below re-applies the mask (idempotent) and reduces again.
+                link.stats.zero_()
+        if not fused:
+            dz = torch.empty_like(y) if has_res else None
+            check(lib.wm_bn_train_bwd(y.data_ptr(), dout.data_ptr(), out.data_ptr() if (relu and not mask_from_y) else 0,
+                                      int(mask_from_y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), rows, c, groups,
+                                      ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(), dz.data_ptr() if has_res else 0,
+                                      ptr(ws), ws.numel(), stream_ptr()), "wm_bn_train_bwd")
         if direct:
-            return dy, dz, None, None, None, None, None, None, None, None, None, None, None
-        return dy, dz, dgamma, dbeta, None, None, None, None, None, None, None, None, None
+            return (dy, dz) + (None,) * 12
+        return (dy, dz, dgamma, dbeta) + (None,) * 10
 
 
 def batch_norm(y, gamma, beta, running_mean, running_var, training: bool, residual=None, relu: bool = False,
                eps: float = 1e-5, momentum: float = 0.1, groups: Optional[int] = None, stats=None,
-               num_batches_tracked=None):
+               num_batches_tracked=None, bwd_stats=None):
     """out = relu?(BN(y) (+ residual)) on bf16 [N,C,H,W] (NHWC) or [B,C].  `stats`: the buffer the
     producing conv2d(..., stats=) accumulated into (same `groups`).  `num_batches_tracked` (int64 scalar
-    tensor): incremented by `groups` inside the statistics kernel when training."""
+    tensor): incremented by `groups` inside the statistics kernel when training.  `bwd_stats`: a second buffer of the
+    same kind; when given (training, ReLU, 4-D), the output carries a BnLink and the convolution that consumes it runs
+    this BatchNorm's backward reduction in its dgrad epilogue."""
     g = current_bn_groups() if groups is None else groups
-    return _BatchNorm.apply(y, residual, gamma, beta, running_mean, running_var, bool(training), int(g), float(eps),
-                            float(momentum), bool(relu), stats, num_batches_tracked)
+    out = _BatchNorm.apply(y, residual, gamma, beta, running_mean, running_var, bool(training), int(g), float(eps),
+                           float(momentum), bool(relu), stats, num_batches_tracked, bwd_stats)
+    link = getattr(out.grad_fn, "link", None) if out.grad_fn is not None else None
+    if link is not None:
+        out._hip_bn = link
+    return out
 
 
 class _BnReluMaxPool(torch.autograd.Function):
@@ -569,7 +747,7 @@ class _BnReluMaxPool(torch.autograd.Function):
             check(lib.wm_bn_train_stats(y.data_ptr(), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                         ptr(counter), rows, c, g,
                                         eps, momentum, ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                        ptr(stats) if fused else 0, STAT_BUCKETS, ptr(ws), ws.numel(), stream_ptr()),
+                                        ptr(stats) if fused else 0, stat_buckets(rows // g), ptr(ws), ws.numel(), stream_ptr()),
                   "wm_bn_train_stats")
             ctx.save_for_backward(y, mean, invstd)
         else:
@@ -713,11 +891,8 @@ class _Linear(torch.autograd.Function):
             check(_run("gemm_dgrad", 2.0 * b * c * k, lib.wm_conv2d_dgrad, ptr(dy), ptr(crsk), ptr(dx), b, 1, 1, c, k, 1, 1,
                        1, 1, 1, 0, stream_ptr()), "wm_conv2d_dgrad(linear)")
         if ctx.needs_input_grad[1]:
-            slot = _arena_grad(weight)  # [K][1][1][C] == [K][C]: the atomics can land in the arena itself
-            tgt = slot if slot is not None else torch.zeros((k, c), dtype=torch.float32, device=dy.device)
-            check(_run("gemm_wgrad", 2.0 * b * c * k, lib.wm_conv2d_wgrad, ptr(dy), ptr(x), ptr(tgt), b, 1, 1, c, k, 1, 1,
-                       1, 1, 1, 0, stream_ptr()), "wm_conv2d_wgrad(linear)")
-            dw = None if slot is not None else tgt
+            slabs, _, ns = wgrad(dy, x, weight, b, 1, 1, c, k, 1, 1, 1, 1, 1, 0, name="gemm_wgrad")
+            dw, _ = wgrad_deliver(weight, slabs, ns, k, c, 1, 1)
         return dx, dw
 
 

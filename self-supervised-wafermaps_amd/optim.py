@@ -126,12 +126,14 @@ class SGD(_ArenaStateMixin, torch.optim.Optimizer):
         return [a.grads for a in self._arenas]
 
     def zero_grad(self, set_to_none: bool = False) -> None:
+        ops.drop_pending_folds()  # (a backward pass that raised leaves its queue behind: ADVICE r2)
         for a in self._arenas:
             a.grads.zero_()
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        ops.fold_wgrads()  # no-op unless a backward pass ended without its end-of-pass callback
         lib = _lib.load()
         for group, arena, hyper, i in zip(self.param_groups, self._arenas, self._hyper, range(len(self._arenas))):
             h = (float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]), self.grad_scale)
@@ -173,12 +175,14 @@ class AdamW(_ArenaStateMixin, torch.optim.Optimizer):
         return [a.grads for a in self._arenas]
 
     def zero_grad(self, set_to_none: bool = False) -> None:
+        ops.drop_pending_folds()  # (a backward pass that raised leaves its queue behind: ADVICE r2)
         for a in self._arenas:
             a.grads.zero_()
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        ops.fold_wgrads()  # no-op unless a backward pass ended without its end-of-pass callback
         lib = _lib.load()
         for i, (group, arena, hyper) in enumerate(zip(self.param_groups, self._arenas, self._hyper)):
             self._steps[i] += 1
@@ -225,12 +229,14 @@ class LARS(_ArenaStateMixin, torch.optim.Optimizer):
         return [a.grads for a in self._arenas]
 
     def zero_grad(self, set_to_none: bool = False) -> None:
+        ops.drop_pending_folds()  # (a backward pass that raised leaves its queue behind: ADVICE r2)
         for a in self._arenas:
             a.grads.zero_()
 
     @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
+        ops.fold_wgrads()  # no-op unless a backward pass ended without its end-of-pass callback
         lib = _lib.load()
         for group, arena, hyper, (seg, n), norms in zip(self.param_groups, self._arenas, self._hyper, self._seg,
                                                         self._norms):

@@ -203,14 +203,9 @@ class _LinearBias(torch.autograd.Function):
                            c, k, 1, 1, 1, 1, 1, 0, stream_ptr()), "wm_conv2d_dgrad(linear)")
         want_b = bias is not None and bias.requires_grad
         if ctx.needs_input_grad[1] or want_b:
-            db = None
-            if want_b:
-                db, db_ret = _grad_target(bias)
-            slot = _arena_grad(weight)
-            tgt = slot if slot is not None else torch.zeros((k, c), dtype=torch.float32, device=dout.device)
-            check(ops._run("gemm_wgrad", 2.0 * rows * c * k, lib.wm_conv2d_wgrad_bias, ptr(dout), ptr(x), ptr(tgt), ptr(db),
-                           rows, 1, 1, c, k, 1, 1, 1, 1, 1, 0, stream_ptr()), "wm_conv2d_wgrad_bias(linear)")
-            dw = None if slot is not None else tgt
+            slabs, bslabs, ns = ops.wgrad(dout, x, weight, rows, 1, 1, c, k, 1, 1, 1, 1, 1, 0, bias_k=k if want_b else 0,
+                                          name="gemm_wgrad")
+            dw, db_ret = ops.wgrad_deliver(weight, slabs, ns, k, c, 1, 1, bias if want_b else None, bslabs)
         return dx, dw, db_ret, (dout if ctx.has_res else None)
 
 
@@ -296,14 +291,10 @@ class _MlpGelu(torch.autograd.Function):
         rets = {}
 
         def wgrad(dout, inp, w, b, kk, cc, tag):
-            db = db_ret = None
-            if b.requires_grad:
-                db, db_ret = _grad_target(b)
-            slot = _arena_grad(w)
-            tgt = slot if slot is not None else torch.zeros((kk, cc), dtype=torch.float32, device=dy.device)
-            check(ops._run("gemm_wgrad", 2.0 * rows * cc * kk, lib.wm_conv2d_wgrad_bias, ptr(dout), ptr(inp), ptr(tgt),
-                           ptr(db), rows, 1, 1, cc, kk, 1, 1, 1, 1, 1, 0, stream_ptr()), "wm_conv2d_wgrad_bias(mlp)")
-            rets[tag] = (None if slot is not None else tgt, db_ret)
+            want_b = b.requires_grad
+            slabs, bslabs, ns = ops.wgrad(dout, inp, w, rows, 1, 1, cc, kk, 1, 1, 1, 1, 1, 0, bias_k=kk if want_b else 0,
+                                          name="gemm_wgrad")
+            rets[tag] = ops.wgrad_deliver(w, slabs, ns, kk, cc, 1, 1, b if want_b else None, bslabs)
 
         wgrad(dy, h, w2, b2, out, hid, "fc2")
         _, c2 = ops._WCACHE.get(w2, kind="linear", need_crsk=True)
@@ -446,15 +437,14 @@ class _PatchEmbed(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dy = _bf16_rows(dy)
             lib = _lib.load()
-            ws = ops._wgrad_accumulator(weight, (d, p, p, 3))
-            check(lib.wm_conv2d_wgrad(ptr(dy), ptr(rows), ptr(ws), m, 1, 1, k, d, 1, 1, 1, 1, 1, 0, stream_ptr()),
-                  "wm_conv2d_wgrad(patch_embed)")
+            # rows [m][k = p*p*3] x dy [m][d] as a 1 x 1 convolution; the slabs are [d][p][p][3] = KRSC of the patch filter
+            slabs, _, ns = ops.wgrad(dy, rows, weight, m, 1, 1, k, d, 1, 1, 1, 1, 1, 0, name="gemm_wgrad")
             slot = _arena_grad(weight)
             if slot is not None:
-                check(lib.wm_wgrad_finalize(ptr(ws), d, 3, p, p, ptr(slot), 1, stream_ptr()), "wm_wgrad_finalize")
+                check(lib.wm_wgrad_finalize(ptr(slabs), ns, d, 3, p, p, ptr(slot), 1, stream_ptr()), "wm_wgrad_finalize")
             else:
                 dw = torch.empty((d, 3, p, p), dtype=torch.float32, device=dy.device)
-                check(lib.wm_wgrad_finalize(ptr(ws), d, 3, p, p, ptr(dw), 0, stream_ptr()), "wm_wgrad_finalize")
+                check(lib.wm_wgrad_finalize(ptr(slabs), ns, d, 3, p, p, ptr(dw), 0, stream_ptr()), "wm_wgrad_finalize")
         return None, dw
 
 

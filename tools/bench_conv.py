@@ -49,7 +49,8 @@ def main():
         y = torch.randn(N, P, Q, K, generator=g, device=dev).bfloat16()
         wk = (torch.randn(K, R, R, C, generator=g, device=dev) * 0.05).bfloat16()
         wc = (torch.randn(C, R, R, K, generator=g, device=dev) * 0.05).bfloat16()
-        dw = torch.zeros(K, R, R, C, device=dev)
+        ns = int(lib.wm_conv2d_wgrad_splits(N, H, W, C, K, R, R, P, Q, stride, pad))
+        dw = torch.empty(max(ns, 1), K, R, R, C, device=dev)  # split-K slabs
         dx = torch.empty_like(x)
         geom = (N, H, W, C, K, R, R, P, Q, stride, pad)
         flops = 2.0 * N * P * Q * K * R * R * C

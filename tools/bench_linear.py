@@ -45,8 +45,9 @@ def main():
         wk = (torch.randn(K, C, generator=g, device=dev) * 0.05).bfloat16()
         wc = (torch.randn(C, K, generator=g, device=dev) * 0.05).bfloat16()
         bias = torch.randn(K, generator=g, device=dev)
-        dw = torch.zeros(K, C, device=dev)
-        db = torch.zeros(K, device=dev)
+        ns = int(lib.wm_conv2d_wgrad_splits(rows, 1, 1, C, K, 1, 1, 1, 1, 1, 0))
+        dw = torch.empty(max(ns, 1), K, C, device=dev)  # split-K slabs
+        db = torch.empty(max(ns, 1), K, device=dev)
         dx = torch.empty_like(x)
         geom = (rows, 1, 1, C, K, 1, 1, 1, 1, 1, 0)
         flops = 2.0 * rows * C * K
