@@ -51,6 +51,8 @@ HBM_PEAK_GBS = 8000.0           # HBM3E, same table
 # below, not a live one.  Algorithmic bytes (every operand once): 230 MB per launch.
 CONV_TRAFFIC_BYTES_PER_LAUNCH = 510.1e6
 CONV_TRAFFIC_SOURCE = "profiles/r02_hbm_traffic_simclr_r18_v2.md (rocprofv3 --pmc, separate passes; 260 launches of 4 steps)"
+# the same for the transformer workloads: {workload: (bytes per GEMM / attention launch, source)}; filled from PMC passes
+VIT_TRAFFIC = {}
 R18_GFLOP_PER_SAMPLE = 21.76    # ResNet-18 fwd 3.627 GFLOP x 3 (fwd+bwd) x 2 views
 KNN_N, KNN_D, KNN_K = 811457, 128, 8
 
@@ -447,96 +449,120 @@ def main():
     from ssl_wafermap_amd.models import SimCLR
     from ssl_wafermap_amd.transforms import BaseViewTransform
 
+    def run_training(workload, B, warmup, steps, roof_steps, keep=False):
+        """One training workload: (warm-up, hipGraph capture, W + K replayed steps between fences, `roof_steps` eager
+        steps with HIP-event brackets around the MFMA launches) -> (result dict, dataset or None)."""
+        simclr = workload == "simclr_r18"
+        torch.manual_seed(0)
+        if simclr:
+            wafers, labels = synthetic_wafers(4096, seed=1234 + rank)
+            ds = WaferMapDataset(wafers, labels, transform=BaseViewTransform(), device=dev)
+            model = SimCLR(None, 9, batch_size=B * world, max_epochs=150, gather_distributed=False)
+            gflop, label = R18_GFLOP_PER_SAMPLE, ("SimCLR ResNet-18, 256 wafers/GPU/step, two 3x224x224 views, NT-Xent in-batch "
+                                                  "negatives, SGD (BASELINE.json configs[1])")
+            FMT, metric = "s2d_bf16", "imgs/sec (SimCLR ResNet18, bs=256, 224^2)"
+        else:
+            ds, model, gflop, label = make_vit_workload(workload, dev, B, world)
+            FMT, metric = "nhwc_bf16", f"imgs/sec ({workload})"
+        model = model.to(dev).train()
+        (opt,), _ = model.configure_optimizers()
+        sync = wdist.GradSync(opt)
+        wdist.broadcast_state(model, opt)
+        rng = np.random.default_rng(rank)
+
+        def eager_step(i):
+            idx = (np.arange(B) + i * B) % len(ds)
+            batch = ds.get_batch(idx, rng, fmt=FMT)
+            opt.zero_grad()
+            loss = model.training_step(batch, i)
+            loss.backward()
+            sync.start()
+            sync.wait()
+            opt.step()
+            return loss
+
+        graphed = None
+        for i in range(min(max(warmup, 1), 3)):
+            eager_step(i)
+        if not args.no_graph:
+            ok = 1
+            try:
+                stages = bool(getattr(model, "backward_stages", False)) and world > 1 and not args.no_overlap
+                graphed = GraphedTrainStep(model, opt, ds, B, fmt=FMT, stages=stages).capture(np.arange(B), rng, sync)
+            except Exception as e:  # capture is an optimisation: report and continue eagerly
+                print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
+                graphed, ok = None, 0
+                # a failed capture leaves torch's side stream current (torch.cuda.graph's exit raised before restoring it)
+                torch.cuda.set_stream(torch.cuda.default_stream(dev))
+            if world > 1:
+                # every rank must take the same path: a rank replaying staged graphs and a rank stepping eagerly would
+                # issue different collectives (ADVICE r2)
+                flag = torch.tensor([ok], dtype=torch.int32, device=dev)
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+                if int(flag.item()) == 0:
+                    graphed = None
+
+        def step(i):
+            if graphed is None:
+                return eager_step(i)
+            return graphed.step((np.arange(B) + i * B) % len(ds), rng, sync)
+
+        dt, gpu_ms, loss = timed(step, warmup, steps)
+        final_loss = check_finite(loss)
+
+        # ---- after the timed region: host-side preparation cost of a step, and eager steps with event brackets
+        t0 = time.perf_counter()
+        for i in range(20):
+            ds.transform.sample(ds.store, (np.arange(B) + i * B) % len(ds), rng)
+        host_prepare_ms = (time.perf_counter() - t0) / 20 * 1e3
+        roof = None
+        if not args.no_kernel_timer and roof_steps > 0:
+            timer = ops.KernelTimer()
+            ops.TIMER = timer
+            for j in range(roof_steps):
+                check_finite(eager_step(warmup + steps + j))
+            ops.TIMER = None
+            torch.cuda.synchronize()
+            if simclr:
+                roof = roofline_from(timer, roof_steps, "conv_igemm + conv3x3_patch + conv_wgrad (implicit-GEMM, bf16 MFMA)",
+                                     CONV_TRAFFIC_BYTES_PER_LAUNCH, CONV_TRAFFIC_SOURCE)
+            else:
+                roof = roofline_from(timer, roof_steps, "Linear GEMMs (conv_igemm 1x1 fwd / dgrad, conv_wgrad) + attn_fwd / attn_bwd, bf16 MFMA",
+                                     VIT_TRAFFIC.get(workload, (None, None))[0], VIT_TRAFFIC.get(workload, (None, None))[1])
+        imgs = B * world * steps
+        value = imgs / dt
+        res = {
+            "metric": metric, "value": round(value, 2), "unit": "imgs/sec", "n_gpus": world, "steps": steps,
+            "warmup": warmup, "ms_per_step": round(1e3 * dt / steps, 3), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "config": {"workload": label, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
+                       "hip_graph": graphed is not None,
+                       "backward_stage_graphs": len(graphed.graphs) if graphed is not None else 0,
+                       "model_tflop_per_step_per_gpu": round(gflop * B / 1e3, 3),
+                       "model_mfma_frac": round(value / world * gflop / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)},
+            "final_loss": round(final_loss, 4),
+            "gpu_ms_per_step": round(gpu_ms, 3),          # HIP events around the K steps on the launch stream
+            "host_prepare_ms_per_step": round(host_prepare_ms, 3),  # drawing + checking the step's augmentation decisions
+            "roofline": roof,
+        }
+        del graphed
+        model = opt = sync = None
+        torch.cuda.empty_cache()
+        return res, (ds if keep else None)
+
     simclr = args.workload == "simclr_r18"
     B = args.batch or (256 if simclr else 64)
-    torch.manual_seed(0)
-    if simclr:
-        wafers, labels = synthetic_wafers(4096, seed=1234 + rank)
-        ds = WaferMapDataset(wafers, labels, transform=BaseViewTransform(), device=dev)
-        model = SimCLR(None, 9, batch_size=B * world, max_epochs=150, gather_distributed=False)
-        gflop, label = R18_GFLOP_PER_SAMPLE, ("SimCLR ResNet-18, 256 wafers/GPU/step, two 3x224x224 views, NT-Xent in-batch "
-                                              "negatives, SGD (BASELINE.json configs[1])")
-        FMT, metric = "s2d_bf16", "imgs/sec (SimCLR ResNet18, bs=256, 224^2)"
-    else:
-        ds, model, gflop, label = make_vit_workload(args.workload, dev, B, world)
-        FMT, metric = "nhwc_bf16", f"imgs/sec ({args.workload})"
-    model = model.to(dev).train()
-    (opt,), _ = model.configure_optimizers()
-    sync = wdist.GradSync(opt)
-    wdist.broadcast_state(model, opt)
-    rng = np.random.default_rng(rank)
-
-    def eager_step(i):
-        idx = (np.arange(B) + i * B) % len(ds)
-        batch = ds.get_batch(idx, rng, fmt=FMT)
-        opt.zero_grad()
-        loss = model.training_step(batch, i)
-        loss.backward()
-        sync.start()
-        sync.wait()
-        opt.step()
-        return loss
-
-    graphed = None
-    for i in range(min(args.warmup, 3)):
-        eager_step(i)
-    if not args.no_graph:
-        try:
-            stages = bool(getattr(model, "backward_stages", False)) and world > 1 and not args.no_overlap
-            graphed = GraphedTrainStep(model, opt, ds, B, fmt=FMT, stages=stages).capture(np.arange(B), rng, sync)
-        except Exception as e:  # capture is an optimisation: report and continue eagerly
-            print(f"[bench] hipGraph capture failed, running eagerly: {type(e).__name__}: {e}", file=sys.stderr)
-            graphed = None
-            # a failed capture leaves torch's side stream current (torch.cuda.graph's exit raised before restoring it)
-            torch.cuda.set_stream(torch.cuda.default_stream(dev))
-
-    def step(i):
-        if graphed is None:
-            return eager_step(i)
-        return graphed.step((np.arange(B) + i * B) % len(ds), rng, sync)
-
-    dt, gpu_ms, loss = timed(step, args.warmup, args.steps)
-    final_loss = check_finite(loss)
-
-    # ---- after the timed region: host-side preparation cost of a step, and ONE eager step with event brackets
-    t0 = time.perf_counter()
-    for i in range(20):
-        p = ds.transform.sample(ds.store, (np.arange(B) + i * B) % len(ds), rng)
-    host_prepare_ms = (time.perf_counter() - t0) / 20 * 1e3
-    roof = None
-    if not args.no_kernel_timer:
-        timer = ops.KernelTimer()
-        ops.TIMER = timer
-        check_finite(eager_step(args.warmup + args.steps))
-        ops.TIMER = None
-        torch.cuda.synchronize()
-        if simclr:
-            roof = roofline_from(timer, 1, "conv_igemm + conv3x3_patch + conv_wgrad (implicit-GEMM, bf16 MFMA)",
-                                 CONV_TRAFFIC_BYTES_PER_LAUNCH, CONV_TRAFFIC_SOURCE)
-        else:
-            roof = roofline_from(timer, 1, "Linear GEMMs (conv_igemm 1x1 fwd / dgrad, conv_wgrad) + attn_fwd / attn_bwd, bf16 MFMA")
-
-    imgs = B * world * args.steps
-    value = imgs / dt
-    out = {
-        "metric": metric, "value": round(value, 2), "unit": "imgs/sec", "n_gpus": world, "steps": args.steps,
-        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": label, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
-                   "hip_graph": graphed is not None,
-                   "backward_stage_graphs": len(graphed.graphs) if graphed is not None else 0,
-                   "model_tflop_per_step_per_gpu": round(gflop * B / 1e3, 3),
-                   "model_mfma_frac": round(value / world * gflop / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)},
-        "final_loss": round(final_loss, 4),
-        "gpu_ms_per_step": round(gpu_ms, 3),          # HIP events around the K steps on the launch stream
-        "host_prepare_ms_per_step": round(host_prepare_ms, 3),  # drawing + checking the step's augmentation decisions
-        "roofline": roof,
-    }
+    out, ds = run_training(args.workload, B, args.warmup, args.steps, 0 if args.no_kernel_timer else 3, keep=simclr)
     if world == 1 and simclr and not args.no_secondary:
-        del graphed
-        model = opt = None
-        torch.cuda.empty_cache()
         out["augment"] = augment_object(dev, ds, B)
+        del ds
+        torch.cuda.empty_cache()
+        # the transformer workload of the north-star (BASELINE configs[2]) inside the default line: DINO ViT-Tiny/16,
+        # 64 wafers, a short replayed run + the GEMM / attention roofline of eager steps
+        vit, _ = run_training("dino_vit_tiny", 64, 3, 10, 2)
+        out["vit"] = {"workload": vit["config"]["workload"], "imgs_per_sec": vit["value"], "ms_per_step": vit["ms_per_step"],
+                      "steps": vit["steps"], "hip_graph": vit["config"]["hip_graph"], "final_loss": vit["final_loss"],
+                      "model_mfma_frac": vit["config"]["model_mfma_frac"], "roofline": vit["roofline"]}
         out["knn"] = knn_object(dev)
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()

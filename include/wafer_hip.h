@@ -202,12 +202,12 @@ int wm_ntxent_bwd(const float* zn, const float* zall, const float* lse_all, int 
 int wm_conv2d_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
                   int R, int S, int P, int Q, int stride, int pad, void* stream);
 /* The same convolution, also accumulating the per-channel (sum, sum of squares) of its bf16 outputs
- * into stat_part: int64 [G][stat_buckets][2 statistics][2 (hi, lo)][K] (G = N*P*Q / rows_per_group row groups,
- * bucket = tile % stat_buckets).  A tile's f32 partial sum p is split exactly into hi = rint(p * 2^8) and
- * lo = rint((p - hi * 2^-8) * 2^48) and both are added with 64-bit INTEGER atomics, so a bucket holds the exact sum
- * of the partials whatever the arrival order: the statistics (and everything downstream) are bit-reproducible from
- * run to run.  rows_per_group % 128 == 0.  stat_part must be zero on entry; wm_bn_train_fwd_from_stats clears it again
- * as it reads it. */
+ * into stat_part: int64 [G][stat_buckets][2 statistics][K] (G = N*P*Q / rows_per_group row groups, bucket = tile %
+ * stat_buckets).  A tile's f32 partial sum p is added as the integer rint(p * 2^24) with a 64-bit INTEGER atomic
+ * (associative), so a bucket holds the same value whatever the arrival order: the statistics (and everything
+ * downstream) are bit-reproducible from run to run.  |bucket sum| < 5.5e11, resolution 6e-8.
+ * rows_per_group % 128 == 0.  stat_part must be zero on entry; wm_bn_train_fwd_from_stats clears it again as it
+ * reads it. */
 int wm_conv2d_fwd_stats(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
                         int R, int S, int P, int Q, int stride, int pad, void* stat_part,
                         int stat_buckets, int rows_per_group, void* stream);
@@ -224,8 +224,9 @@ int wm_conv2d_dgrad_add(const void* dy, const void* w_crsk, const void* residual
  * scripts/WM811k_benchmark.py:231): the epilogue takes the gradient through the ReLU and accumulates the
  * BatchNorm-backward sums, so that BatchNorm's backward needs no reduction pass and no mask:
  *   g  = (conv_transpose(dy, w) (+ residual)) * mask          -> dx (the MASKED gradient, bf16)
- *   stat_part [G][stat_buckets][2][2][C] int64 += (sum g, sum g * (bn_y - mean) * invstd) per channel
- *        (wm_conv2d_fwd_stats's exact fixed-point form; zero on entry, cleared by wm_bn_train_bwd_from_stats)
+ *   stat_part [G][stat_buckets][2][C] int64 += (sum g, sum g * bn_y) per channel, as rint(p * 2^44)
+ *        (wm_conv2d_fwd_stats's fixed-point form at the scale of gradients: |bucket sum| < 5.2e5, resolution 5.7e-14;
+ *        zero on entry, cleared by wm_bn_train_bwd_from_stats, which forms sum g * xhat from the two)
  * mask = relu_x > 0 when relu_x (the convolution's own forward input, shape of dx) is given; else recomputed from
  * bn_y as bf16(bn_y * gamma * invstd + beta - mean * gamma * invstd) > 0 (a BatchNorm without shortcut).
  * bn_y has the shape of dx; save_mean / save_invstd [G][C] over G equal groups of images.
@@ -274,8 +275,8 @@ int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int S, void* w_
  *   layouts (either may be NULL); RS = R*S in {1, 9}; tiles_c = ceil(C / 32); tile0 = index of the parameter's first
  *   32 x 32 (k, c) tile in the launch; total_tiles = sum over parameters of ceil(K / 32) * tiles_c.
  * wm_wgrad_fold: ws = f32 weight-gradient slabs [nsplit][K][RS][C] (wm_conv2d_wgrad), nsplit slabs summed in order;
- *   grad = f32 OIHW gradient (grad += sum); a block owns (32 x 32 (k, c) tile, one tap): tiles per parameter =
- *   ceil(K / 32) * tiles_c * RS.  Optional bias: w = f32 bias slabs [nsplit][K], krsc = (float*) bias gradient [K]
+ *   grad = f32 OIHW gradient (grad += sum); a block owns (8 x 128 (k, c) tile, one tap): tiles_c = ceil(C / 128),
+ *   tiles per parameter = ceil(K / 8) * tiles_c * RS; C % 4 == 0.  Optional bias: w = f32 bias slabs [nsplit][K], krsc = (float*) bias gradient [K]
  *   (+=), both NULL when absent (crsk unused).
  * Replaces 24-100 wm_weights_prepare / 19 wm_wgrad_finalize launches per training step. */
 typedef struct WmLayoutDesc {
@@ -524,6 +525,15 @@ int wm_adamw_step(float* params, const float* grads, float* exp_avg, float* exp_
                   const float* hyper, void* stream);
 /* lightly update_momentum: ema = ema * m + p * (1 - m). */
 int wm_ema_update(float* ema, const float* params, long long n, float m, void* stream);
+/* out[r][:] = ascending argsort of keys[r][0..S) (S <= 256; ties to the lower index): the token permutation of
+ * lightly.models.utils.random_token_mask (reference scripts/WM811k_benchmark.py:930, MixedWM38_pretrain.py:208). */
+int wm_argsort_rows(const float* keys, int rows, int S, long long* out, void* stream);
+/* y = x * g[column] on bf16 [rows][C] with f32 g[C], and its backward (dx = dy * g, dg = / += column sums of dy * x):
+ * the trainable gain of the weight-normalised last layer of lightly's DINOProjectionHead(norm_last_layer=False)
+ * (reference scripts/WM811k_benchmark.py:553-559). */
+int wm_colscale_fwd(const void* x, const float* g, long long rows, int C, void* y, void* stream);
+int wm_colscale_bwd(const void* x, const float* g, const void* dy, long long rows, int C, void* dx, float* dg,
+                    int accumulate, void* stream);
 
 /* timm.optim.lars.Lars step (BarlowTwins / VICReg in the reference, scripts/WM811k_benchmark.py:383-392,
  * 418-427) over a flat arena: seg_offsets [n_seg + 1] int64 = element offsets of the parameters; per parameter

@@ -196,6 +196,9 @@ SIGNATURES = {
     "wm_standardize": (c_int, [c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "wm_adamw_step": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_void_p, c_void_p]),
     "wm_ema_update": (c_int, [c_void_p, c_void_p, c_longlong, c_float, c_void_p]),
+    "wm_argsort_rows": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "wm_colscale_fwd": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p]),
+    "wm_colscale_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "wm_matmul_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
     "wm_debug_absmax": (c_int, [c_void_p, c_int, c_longlong, c_void_p, c_void_p]),
     "wm_layouts_refresh": (c_int, [c_void_p, c_int, c_int, c_void_p]),

@@ -219,35 +219,31 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restri
 // of what these few-microsecond launches cost (44 of them per SimCLR step).
 __device__ __forceinline__ void finalize_sums2(float* __restrict__ part, int nblk, int g, int ng, int C, int c,
                                                int bl, int cl, double (*red)[2][32][33], double (&s)[2],
-                                               double (&ss)[2], bool clear = false, bool fx = false) {
+                                               double (&ss)[2], bool clear = false, int fx = 0) {  // fx: 0 = f32 partials, else the fixed-point shift
   double a[2] = {0.0, 0.0}, b[2] = {0.0, 0.0};
   if (c < C && fx) {
-    // exact fixed-point buckets of the convolution epilogues (wm_fx_add): int64 [nblk][2][hi, lo][C] per group;
-    // integer sums first (exact), one conversion per lane
+    // fixed-point buckets of the convolution epilogues (wm_fx_add): int64 [nblk][2][C] per group; integer sums first
+    // (exact), one conversion per lane
     long long* fxp = reinterpret_cast<long long*>(part);
-    long long h0[2] = {0, 0}, l0[2] = {0, 0}, h1[2] = {0, 0}, l1[2] = {0, 0};
+    long long t0[2] = {0, 0}, t1[2] = {0, 0};
     for (int k = bl; k < nblk; k += 32) {
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         if (u < ng) {
-          long long* q = fxp + ((size_t)((g + u) * nblk + k) * 4) * C + c;
-          h0[u] += q[0];
-          l0[u] += q[(size_t)C];
-          h1[u] += q[(size_t)2 * C];
-          l1[u] += q[(size_t)3 * C];
+          long long* q = fxp + ((size_t)((g + u) * nblk + k) * 2) * C + c;
+          t0[u] += q[0];
+          t1[u] += q[(size_t)C];
           if (clear) {
             q[0] = 0;
             q[(size_t)C] = 0;
-            q[(size_t)2 * C] = 0;
-            q[(size_t)3 * C] = 0;
           }
         }
       }
     }
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
-      a[u] = wm_fx_value(h0[u], l0[u]);
-      b[u] = wm_fx_value(h1[u], l1[u]);
+      a[u] = wm_fx_value(t0[u], fx);
+      b[u] = wm_fx_value(t1[u], fx);
     }
   } else if (c < C) {
     for (int k = bl; k < nblk; k += 32) {
@@ -315,7 +311,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize(
   for (int g0 = 0; g0 < G; g0 += 2) {
     const int ng = G - g0 < 2 ? G - g0 : 2;
     double s2[2], ss2[2];
-    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s2, ss2, clear != 0, clear != 0);
+    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s2, ss2, clear != 0, clear != 0 ? WM_FX_FWD : 0);
     if (owner) {
       for (int u = 0; u < ng; ++u) {
         const int g = g0 + u;
@@ -427,11 +423,14 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize(
   for (int g0 = 0; g0 < G; g0 += 2) {
     const int ng = G - g0 < 2 ? G - g0 : 2;
     double s1v[2], s2v[2];
-    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s1v, s2v, fx != 0, fx != 0);
+    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s1v, s2v, fx != 0, fx != 0 ? WM_FX_BWD : 0);
     if (owner) {
       for (int u = 0; u < ng; ++u) {
         const int g = g0 + u;
-        const double s1 = s1v[u], s2 = s2v[u];
+        double s1 = s1v[u], s2 = s2v[u];
+        if (fx) {  // the dgrad epilogue accumulated sum g * y: sum g * xhat = invstd * (sum g y - mean * sum g)
+          s2 = (double)invstd[(size_t)g * C + c] * (s2 - (double)mean[(size_t)g * C + c] * s1);
+        }
         tb += s1;
         tg += s2;
         const float is = invstd[(size_t)g * C + c];

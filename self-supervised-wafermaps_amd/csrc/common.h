@@ -169,22 +169,22 @@ __device__ __forceinline__ float wm_gelu_grad(float v) {
 // ---- order-independent (bit-reproducible) accumulation of f32 partial sums across workgroups.
 // f32 atomics add in arrival order, so two runs of one launch differ in the last bits and bf16 roundings downstream
 // flip: BatchNorm statistics were one of the two sources of the 4-10 % run-to-run gradient noise of round 2 (the other:
-// split-K weight gradients).  Here a partial sum p is split EXACTLY into hi = rint(p * 2^8) and lo = rint((p - hi * 2^-8)
-// * 2^48) and both are added with 64-bit INTEGER atomics (associative): the bucket then holds the exact sum of the
-// partials rounded to multiples of 2^-48, whatever the order.  Range |sum| < 2^54, resolution 2^-48 (a partial below
-// 2^-24 loses low bits, one below 2^-49 vanishes): 15 decades, no per-tensor scale to choose.
-// Slot layout of one (group, bucket): [which statistic 0/1][hi, lo][C] int64.
-__device__ __forceinline__ void wm_fx_add(unsigned long long* hi_slot, unsigned long long* lo_slot, float p) {
-  const float ph = rintf(p * 256.f);
-  const float r = p - ph * 0.00390625f;  // exact: p is either a multiple of 2^-8 already (|p| >= 2^16) or ph < 2^24
-  const long long hi = (long long)ph;
-  const long long lo = (long long)rintf(r * 0x1p48f);
-  atomicAdd(hi_slot, (unsigned long long)hi);
-  atomicAdd(lo_slot, (unsigned long long)lo);
+// split-K weight gradients).  Here a partial sum p is added as the 64-bit INTEGER rint(p * 2^shift) (integer addition is
+// associative): the bucket holds the exact sum of the partials rounded to multiples of 2^-shift, whatever the order.
+//   WM_FX_FWD = 24: activations -- |bucket sum| < 2^39 = 5.5e11, resolution 6e-8 (an f32 partial of magnitude >= 1
+//                   carries no finer bits);
+//   WM_FX_BWD = 44: gradients   -- |bucket sum| < 2^19 = 5.2e5, resolution 5.7e-14 (a tile's gradient sum of 1e-6
+//                   keeps full f32 precision; one of 1e-9 keeps 4 digits).
+// (A first build split p exactly into two integers, hi = rint(p 2^8) and lo = the rest * 2^48: scale-free, but twice
+// the atomic instructions -- the 64-channel patch kernels ran 16 % slower, atomics being ~50 ns per wave-instruction
+// and CU.)
+#define WM_FX_FWD 24
+#define WM_FX_BWD 44
+__device__ __forceinline__ void wm_fx_add(unsigned long long* slot, float p, int shift) {
+  const long long v = (long long)rintf(ldexpf(p, shift));
+  atomicAdd(slot, (unsigned long long)v);
 }
-__device__ __forceinline__ double wm_fx_value(long long hi, long long lo) {
-  return (double)hi * 0.00390625 + (double)lo * 0x1p-48;
-}
+__device__ __forceinline__ double wm_fx_value(long long v, int shift) { return ldexp((double)v, -shift); }
 
 static inline int wm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

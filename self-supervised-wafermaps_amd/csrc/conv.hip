@@ -51,13 +51,13 @@ struct ConvArgs {
   int N, SH, SW, SC, DH, DW, DC, R, S, stride, pad, M, nkt;
   // optional fused BatchNorm statistics (forward only): per-channel (sum, sum of squares) of the
   // bf16-rounded outputs, added into bucket (tile % stat_nb) of the tile's row group
-  unsigned long long* stat;  // [G][stat_nb][2][hi, lo][DC] int64 (wm_fx_add: order-independent sums), or NULL
+  unsigned long long* stat;  // [G][stat_nb][2][DC] int64 fixed point (wm_fx_add: order-independent sums), or NULL
   int stat_nb, stat_rpg;
   // optional BatchNorm-BACKWARD epilogue (dgrad only, template flag BNB): this convolution's input was
   // relu(BN(bn_y) (+ shortcut)), so the gradient this kernel produces is the one entering that ReLU.  The epilogue
   // applies the ReLU mask (bn_x > 0 when the convolution's forward input bn_x is given, else recomputed from bn_y as
   // bf16(bn_y * gamma * invstd + beta - mean * gamma * invstd) > 0), stores the MASKED gradient, and accumulates the
-  // BatchNorm backward sums (sum g, sum g * xhat) per channel into `stat`: the separate reduction pass over
+  // BatchNorm backward sums (sum g, sum g * bn_y) per channel into `stat`: the separate reduction pass over
   // (bn_y, gradient, mask) and the mask / dz handling of the BatchNorm backward apply pass disappear.
   const uint16_t* bn_y;
   const uint16_t* bn_x;
@@ -111,53 +111,73 @@ __device__ __forceinline__ void tile_stats_fwd(const uint8_t* tile, int CS, int 
     float t = 0.f;
 #pragma unroll
     for (int q = 0; q < TPC; ++q) t += red[(which * TPC + q) * BNC + cc];
-    wm_fx_add(slot + (size_t)(which * 2) * DC + c_base + cc, slot + (size_t)(which * 2 + 1) * DC + c_base + cc, t);
+    wm_fx_add(slot + (size_t)which * DC + c_base + cc, t, WM_FX_FWD);
   }
 }
 
-// BatchNorm-backward epilogue of a dgrad tile (ConvArgs: bn_*): staged bf16 tile [128 rows][CS bytes] of BNC
-// channels -> (+ residual) -> ReLU mask -> store, and the tile's (sum g, sum g * xhat) into its statistics slot.
-// pix_of(row) = destination pixel of tile row `row`; rows >= valid_rows are skipped.
+// BatchNorm-backward epilogue of a dgrad tile (ConvArgs: bn_*), in two parts.
+// bnb_prefetch (at kernel START): the epilogue's global operands -- the BatchNorm input tile, the residual-gradient
+// tile, the mask source tile, 16 bytes per (thread, pass) each -- are requested with inline-asm loads before the MFMA
+// loop, so their HBM latency passes under the loop instead of at the tail of every block (first build, with the loads
+// in the epilogue: the dgrad launches took 0.7 ms per step longer, as much as the removed reduction passes).
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+template <int BNC>
+struct BnbRegs {
+  static constexpr int NIT = 128 * (BNC / 8) / CV_THREADS;
+  u32x4_t yv[NIT], rv[NIT], xv[NIT];
+  size_t pixs[NIT];
+};
+// Plain (compiler-tracked) loads: the k-loop's asm statements clobber "memory", so hipcc cannot sink these below the
+// loop, and because it tracks them it waits before any copy of their registers.  (Untracked inline-asm loads are NOT
+// safe here: under register pressure hipcc splits the live range -- copies the destination registers before the data
+// has landed -- and the late-landing load then overwrites whatever lives in the old registers.)
+__device__ __forceinline__ void bnb_load16(u32x4_t& dst, const void* p) {
+  dst = *reinterpret_cast<const u32x4_t*>(p);
+}
 template <int BNC, typename PixOf>
-__device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, uint8_t* smem, int CS, int valid_rows, int g, int n0,
-                                             int bucket, int tid, PixOf pix_of) {
+__device__ __forceinline__ void bnb_prefetch(const ConvArgs& a, BnbRegs<BNC>& R, int valid_rows, int n0, int tid,
+                                             PixOf pix_of) {
   constexpr int CPR = BNC / 8;
-  constexpr int NIT = 128 * CPR / CV_THREADS;
+  const int c0 = n0 + (tid % CPR) * 8;
+#pragma unroll
+  for (int it = 0; it < BnbRegs<BNC>::NIT; ++it) {
+    const int row = (tid + it * CV_THREADS) / CPR;
+    const size_t pix = pix_of(row < valid_rows ? row : 0);  // (rows past the end: a valid address, value unused)
+    R.pixs[it] = pix;
+    bnb_load16(R.yv[it], a.bn_y + pix * a.DC + c0);
+    if (a.res != nullptr) bnb_load16(R.rv[it], a.res + pix * a.DC + c0);
+    if (a.bn_x != nullptr) bnb_load16(R.xv[it], a.bn_x + pix * a.DC + c0);
+  }
+}
+
+// bnb_epilogue: staged bf16 tile [128 rows][CS bytes] of BNC channels -> (+ residual) -> ReLU mask -> store, and the
+// tile's (sum g, sum g * bn_y) into its statistics slot.  Rows >= valid_rows are skipped.
+template <int BNC>
+__device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, const BnbRegs<BNC>& R, uint8_t* smem, int CS,
+                                             int valid_rows, int g, int n0, int bucket, int tid) {
+  constexpr int CPR = BNC / 8;
+  constexpr int NIT = BnbRegs<BNC>::NIT;
   constexpr int RG = CV_THREADS / CPR;  // threads that share a chunk column
   const int chl = tid % CPR, rg = tid / CPR;
   const int c0 = n0 + chl * 8;
-  float mu[8], is[8], sc[8], sh[8];
-  {
+  // ReLU mask recomputed from the BatchNorm input (no shortcut): bn_y * scale + shift > 0 with the forward's scale and
+  // shift.  (The forward rounds to bf16 before its ReLU; that rounding changes the sign test only for |value| < 2^-133.)
+  const bool remask = a.bn_x == nullptr;
+  float sc[8], sh[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) sc[e] = sh[e] = 0.f;
+  if (remask) {
     const float* pm = a.bn_mean + (size_t)g * a.DC + c0;
     const float* pi = a.bn_invstd + (size_t)g * a.DC + c0;
-    const float4 m0v = *reinterpret_cast<const float4*>(pm), m1v = *reinterpret_cast<const float4*>(pm + 4);
-    const float4 i0v = *reinterpret_cast<const float4*>(pi), i1v = *reinterpret_cast<const float4*>(pi + 4);
-    mu[0] = m0v.x; mu[1] = m0v.y; mu[2] = m0v.z; mu[3] = m0v.w; mu[4] = m1v.x; mu[5] = m1v.y; mu[6] = m1v.z; mu[7] = m1v.w;
-    is[0] = i0v.x; is[1] = i0v.y; is[2] = i0v.z; is[3] = i0v.w; is[4] = i1v.x; is[5] = i1v.y; is[6] = i1v.z; is[7] = i1v.w;
-  }
-  const bool remask = a.bn_x == nullptr;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    sc[e] = sh[e] = 0.f;
-    if (remask) {  // the forward's own arithmetic (bn_fwd_finalize: scale = gamma * invstd, shift = beta - mean * scale)
-      sc[e] = a.bn_gamma[c0 + e] * is[e];
-      sh[e] = a.bn_beta[c0 + e] - mu[e] * sc[e];
+    for (int e = 0; e < 8; ++e) {  // bn_fwd_finalize: scale = gamma * invstd, shift = beta - mean * scale
+      sc[e] = a.bn_gamma[c0 + e] * pi[e];
+      sh[e] = a.bn_beta[c0 + e] - pm[e] * sc[e];
     }
   }
-  size_t pixs[NIT];
-  uint4 yv[NIT], rv[NIT], xv[NIT];
-#pragma unroll
-  for (int it = 0; it < NIT; ++it) {  // every global load of the thread is requested before the first store
-    const int row = (tid + it * CV_THREADS) / CPR;
-    const size_t pix = pix_of(row);
-    pixs[it] = pix;
-    yv[it] = rv[it] = xv[it] = make_uint4(0, 0, 0, 0);
-    if (row < valid_rows) {
-      yv[it] = *reinterpret_cast<const uint4*>(a.bn_y + pix * a.DC + c0);
-      if (a.res != nullptr) rv[it] = *reinterpret_cast<const uint4*>(a.res + pix * a.DC + c0);
-      if (!remask) xv[it] = *reinterpret_cast<const uint4*>(a.bn_x + pix * a.DC + c0);
-    }
-  }
+  // per element: unpack, (+ residual), mask, two running sums (sum g and sum g * y: the finalize kernel turns them
+  // into sum g * xhat = invstd * (sum g y - mean * sum g) in double), pack: ~10 VALU instructions.  The first build
+  // (xhat per element, bf16 round trips for the residual sum and the mask) spent as long here as in the MFMA loop.
   float s1[8], s2[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
@@ -167,9 +187,9 @@ __device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, uint8_t* smem, i
     if (row < valid_rows) {
       const uint4 v4 = *reinterpret_cast<const uint4*>(smem + row * CS + chl * 16);
       const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
-      const uint32_t rr[4] = {rv[it].x, rv[it].y, rv[it].z, rv[it].w};
-      const uint32_t yy[4] = {yv[it].x, yv[it].y, yv[it].z, yv[it].w};
-      const uint32_t xx[4] = {xv[it].x, xv[it].y, xv[it].z, xv[it].w};
+      const uint32_t rr[4] = {R.rv[it][0], R.rv[it][1], R.rv[it][2], R.rv[it][3]};
+      const uint32_t yy[4] = {R.yv[it][0], R.yv[it][1], R.yv[it][2], R.yv[it][3]};
+      const uint32_t xx[4] = {R.xv[it][0], R.xv[it][1], R.xv[it][2], R.xv[it][3]};
       uint32_t o[4];
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
@@ -177,19 +197,20 @@ __device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, uint8_t* smem, i
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
           const int e = q * 2 + h;
-          float v = bf2f((uint16_t)(h ? vv[q] >> 16 : vv[q] & 0xffff));
-          if (a.res != nullptr) v = bf2f(f2bf(v + bf2f((uint16_t)(h ? rr[q] >> 16 : rr[q] & 0xffff))));
-          const float y = bf2f((uint16_t)(h ? yy[q] >> 16 : yy[q] & 0xffff));
-          const bool keep = remask ? bf2f(f2bf(fmaf(y, sc[e], sh[e]))) > 0.f
-                                   : bf2f((uint16_t)(h ? xx[q] >> 16 : xx[q] & 0xffff)) > 0.f;
+          float v = __builtin_bit_cast(float, h ? (vv[q] & 0xffff0000u) : (vv[q] << 16));
+          if (a.res != nullptr) v += __builtin_bit_cast(float, h ? (rr[q] & 0xffff0000u) : (rr[q] << 16));
+          const float y = __builtin_bit_cast(float, h ? (yy[q] & 0xffff0000u) : (yy[q] << 16));
+          // (x is a bf16 pattern: > 0 <=> the 16-bit pattern is a positive non-zero number)
+          const bool keep = remask ? fmaf(y, sc[e], sh[e]) > 0.f
+                                   : __builtin_bit_cast(float, h ? (xx[q] & 0xffff0000u) : (xx[q] << 16)) > 0.f;
           v = keep ? v : 0.f;
           s1[e] += v;
-          s2[e] = fmaf(v, (y - mu[e]) * is[e], s2[e]);
+          s2[e] = fmaf(v, y, s2[e]);
           gv[h] = v;
         }
         o[q] = pack_bf2(gv[0], gv[1]);
       }
-      *reinterpret_cast<uint4*>(a.dst + pixs[it] * a.DC + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+      *reinterpret_cast<uint4*>(a.dst + R.pixs[it] * a.DC + c0) = make_uint4(o[0], o[1], o[2], o[3]);
     }
   }
   __syncthreads();  // every read of the staged tile is over: its LDS carries the cross-thread sums now
@@ -204,8 +225,8 @@ __device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, uint8_t* smem, i
     const int which = tid / BNC, cc = tid % BNC;
     float t = 0.f;
     for (int q = 0; q < RG; ++q) t += red[(which * RG + q) * BNC + cc];
-    unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + bucket) * 4) * a.DC;
-    wm_fx_add(slot + (size_t)(which * 2) * a.DC + n0 + cc, slot + (size_t)(which * 2 + 1) * a.DC + n0 + cc, t);
+    unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + bucket) * 2) * a.DC;
+    wm_fx_add(slot + (size_t)which * a.DC + n0 + cc, t, WM_FX_BWD);
   }
 }
 
@@ -407,6 +428,22 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
     }
   };
 
+  BnbRegs<BNB ? BN : 64> bnb;  // (unused and eliminated unless BNB)
+  if constexpr (BNB) {
+    bnb_prefetch<BN>(a, bnb, a.M - m0, n0, tid, [&](int row) -> size_t {
+      if constexpr (MODE == 2) {  // class-ordered row -> pixel (n, 2 h2 + ph, 2 w2 + pw)
+        const int cls = a.M >> 2;
+        const int pc = m0 / cls;
+        const int m = m0 + row - pc * cls;
+        uint32_t urem2, uw2;
+        const int n = (int)wm_divmod((uint32_t)m, a.d_h2w2, urem2);
+        const int h2 = (int)wm_divmod(urem2, a.d_w2, uw2), w2 = (int)uw2;
+        return ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
+      } else {
+        return (size_t)(m0 + row);
+      }
+    });
+  }
   if (nkt > 0) issue(0, smem_base);
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt have landed
@@ -432,7 +469,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
     if (a.stat != nullptr) {
       // column sums of the staged tile; rows_per_group % BM == 0, so the whole tile belongs to one statistics group
       const int g = m0 / a.stat_rpg;
-      unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 4) * a.DC;
+      unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 2) * a.DC;
       tile_stats_fwd<BN>(cv_smem, CS, a.M - m0, reinterpret_cast<float*>(cv_smem + BM * CS), slot, a.DC, n0, tid);
     }
   }
@@ -444,19 +481,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
     } else {
       g = m0 / a.stat_rpg;
     }
-    bnb_epilogue<BN>(a, cv_smem, CS, a.M - m0, g, n0, (int)(blockIdx.x % a.stat_nb), tid, [&](int row) -> size_t {
-      if constexpr (MODE == 2) {  // class-ordered row -> pixel (n, 2 h2 + ph, 2 w2 + pw)
-        const int cls = a.M >> 2;
-        const int pc = m0 / cls;
-        const int m = m0 + row - pc * cls;
-        uint32_t urem2, uw2;
-        const int n = (int)wm_divmod((uint32_t)m, a.d_h2w2, urem2);
-        const int h2 = (int)wm_divmod(urem2, a.d_w2, uw2), w2 = (int)uw2;
-        return ((size_t)n * a.DH + 2 * h2 + (pc >> 1)) * a.DW + 2 * w2 + (pc & 1);
-      } else {
-        return (size_t)(m0 + row);
-      }
-    });
+    bnb_epilogue<BN>(a, bnb, cv_smem, CS, a.M - m0, g, n0, (int)(blockIdx.x % a.stat_nb), tid);
     return;
   }
   if constexpr (EPI) {
@@ -604,7 +629,7 @@ constexpr int PT_WSTAGES = 3;                 // weight ring: two taps in flight
 constexpr int PT_LDS = PT_PATCH_BYTES + PT_WSTAGES * PT_W_BYTES;
 
 template <int MODE, bool BNB = false>
-__global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
+__global__ __launch_bounds__(CV_THREADS, BNB ? 3 : 1) void conv3x3_patch(const ConvArgs a) {  // BNB: keep three blocks per CU
   constexpr bool DGRAD = MODE != 0;
   static_assert(!BNB || DGRAD, "BatchNorm-backward epilogue: dgrad only");
   extern __shared__ __attribute__((aligned(16))) uint8_t cv_smem[];
@@ -643,6 +668,13 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
                                : conv_zero_page + chunk * 8;
       glds16_at(src, smem_base + j * 1024);
     }
+  }
+  BnbRegs<64> bnb;  // (unused and eliminated unless BNB)
+  if constexpr (BNB) {
+    const size_t porg[2] = {((size_t)tn[0] * a.DH + th0[0]) * a.DW + tw0[0], ((size_t)tn[1] * a.DH + th0[1]) * a.DW + tw0[1]};
+    bnb_prefetch<64>(a, bnb, 128, 0, tid, [&](int row) -> size_t {
+      return porg[row >> 6] + (size_t)((row >> 3) & 7) * a.DW + (row & 7);
+    });
   }
   // ---- weights of one tap: 8 instructions, two per wave (rows rowl, rowl + 32)
   const int rowl = tid >> 3;
@@ -736,16 +768,14 @@ __global__ __launch_bounds__(CV_THREADS) void conv3x3_patch(const ConvArgs a) {
       // column sums of the staged tile; both 8x8 tiles lie in one statistics group (host-checked: an even number of
       // tiles per group)
       const int g = (int)(((long long)tn[0] * a.DH * a.DW) / a.stat_rpg);
-      unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 4) * 64;
+      unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 2) * 64;
       tile_stats_fwd<64>(cv_smem, CS, 128, reinterpret_cast<float*>(cv_smem + 128 * CS), slot, 64, 0, tid);
     }
   }
   const size_t org[2] = {((size_t)tn[0] * a.DH + th0[0]) * a.DW + tw0[0], ((size_t)tn[1] * a.DH + th0[1]) * a.DW + tw0[1]};
   if constexpr (BNB) {
     const int g = (int)(((long long)tn[0] * a.DH * a.DW) / a.stat_rpg);
-    bnb_epilogue<64>(a, cv_smem, CS, 128, g, 0, (int)(blockIdx.x % a.stat_nb), tid, [&](int row) -> size_t {
-      return org[row >> 6] + (size_t)((row >> 3) & 7) * a.DW + (row & 7);
-    });
+    bnb_epilogue<64>(a, bnb, cv_smem, CS, 128, g, 0, (int)(blockIdx.x % a.stat_nb), tid);
     return;
   }
 #pragma unroll
@@ -856,23 +886,13 @@ __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs 
   // pixel fragment: pixel (2 i + dy + r, dx + 2 ks + (fg >> 1)) of the patch, channel half fg & 1
   const uint32_t xbase = (uint32_t)((wm * ST_PIX + dy * ST_PITCH + dx + (fg >> 1)) * 32 + (fg & 1) * 16);
 
-  int st_g = -1;
-  float st_sm = 0.f, st_sq = 0.f;
+  // statistics: every thread owns the LDS slots (row slice, channel) of the two running sums over this block's pairs
+  // (static schedule: pair = blockIdx.x + it * gridDim.x, so the order is fixed); ONE flush after the last pair: a launch
+  // covers a single statistics group (the host launches once per group).  Flushing inside the loop when the group
+  // changes spilled registers (168 VGPRs is the three-blocks-per-CU cap; the weights alone hold 64).
   float* st_red = reinterpret_cast<float*>(cv_smem + 2 * ST_PATCH_BYTES + 128 * ST_CS);  // [2][4][64]
-  auto stat_flush = [&](int g) {  // block-uniform call sites only
-    const int c = tid & 63, part = tid >> 6;
-    __syncthreads();  // (the previous flush's readers are done with st_red)
-    st_red[part * 64 + c] = st_sm;
-    st_red[(4 + part) * 64 + c] = st_sq;
-    __syncthreads();
-    if (tid < 128) {
-      const int which = tid >> 6;
-      const float t = st_red[(which * 4) * 64 + c] + st_red[(which * 4 + 1) * 64 + c] + st_red[(which * 4 + 2) * 64 + c] +
-                      st_red[(which * 4 + 3) * 64 + c];
-      unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 4) * 64;
-      wm_fx_add(slot + (size_t)(which * 2) * 64 + c, slot + (size_t)(which * 2 + 1) * 64 + c, t);
-    }
-  };
+  st_red[tid] = 0.f;
+  st_red[256 + tid] = 0.f;
 
   int pair = blockIdx.x;
   if (pair < npairs) issue_patch(pair, smem_base);
@@ -921,20 +941,15 @@ __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs 
     __syncthreads();
     const int T0 = pair * 2;
     if (a.stat != nullptr) {
-      // running per-thread sums over this block's pairs (static schedule: pair = blockIdx.x + it * gridDim.x, so the
-      // order is fixed), flushed when the statistics group changes and after the last pair
-      const int g = __builtin_amdgcn_readfirstlane((int)(((long long)wm_div((uint32_t)T0, d_timg) * a.DH * a.DW) / a.stat_rpg));
-      if (g != st_g) {
-        if (st_g >= 0) stat_flush(st_g);
-        st_g = g;
-        st_sm = st_sq = 0.f;
-      }
       const int c = tid & 63, part = tid >> 6;
+      float sm = 0.f, sq = 0.f;
       for (int rr = part * 32; rr < (part + 1) * 32; ++rr) {
         const float v = bf2f(*reinterpret_cast<const uint16_t*>(stage + rr * ST_CS + c * 2));
-        st_sm += v;
-        st_sq = fmaf(v, v, st_sq);
+        sm += v;
+        sq = fmaf(v, v, sq);
       }
+      st_red[tid] += sm;        // slot (part, c) of the first sum: tid = part * 64 + c
+      st_red[256 + tid] += sq;
     }
     {
       int n[2], h0[2], w0[2];
@@ -950,7 +965,16 @@ __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs 
       }
     }
   }
-  if (a.stat != nullptr && st_g >= 0) stat_flush(st_g);
+  if (a.stat != nullptr) {
+    __syncthreads();
+    if (tid < 128) {
+      const int which = tid >> 6, c = tid & 63;
+      const float t = st_red[(which * 4) * 64 + c] + st_red[(which * 4 + 1) * 64 + c] + st_red[(which * 4 + 2) * 64 + c] +
+                      st_red[(which * 4 + 3) * 64 + c];
+      unsigned long long* slot = a.stat + ((size_t)((int)(blockIdx.x % a.stat_nb)) * 2) * 64;  // (group 0 of this launch)
+      wm_fx_add(slot + (size_t)which * 64 + c, t, WM_FX_FWD);
+    }
+  }
 }
 
 // ------------------------------------------------------------------------------------ wgrad
@@ -1430,9 +1454,22 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
         const char* e = getenv("WM_STEM_BLOCKS_PER_CU");
         slots = cus * (e ? atoi(e) : 3);  // 36 KB of LDS, 168 registers per lane: three resident blocks per CU
       }
-      conv_stem_patch<<<npairs < slots ? npairs : slots, CV_THREADS, ST_LDS, st>>>(
-          a, npairs, wm_div_make((uint32_t)((a.DH >> 3) * (a.DW >> 3))), wm_div_make((uint32_t)(a.DW >> 3)));
-      WM_LAUNCH_CHECK();
+      // one launch per statistics group (whole images, an even number of tiles: stem_patch_ok): a block then flushes
+      // its running sums once, after its last tile pair
+      const int groups = a.stat != nullptr ? a.M / a.stat_rpg : 1;
+      const int n_g = a.N / groups;
+      const int pairs_g = npairs / groups;
+      for (int g = 0; g < groups; ++g) {
+        ConvArgs ag = a;
+        ag.N = n_g;
+        ag.M = n_g * a.DH * a.DW;
+        ag.src = a.src + (size_t)g * n_g * a.SH * a.SW * 16;
+        ag.dst = a.dst + (size_t)g * n_g * a.DH * a.DW * 64;
+        if (a.stat != nullptr) ag.stat = a.stat + (size_t)g * a.stat_nb * 2 * 64;
+        conv_stem_patch<<<pairs_g < slots ? pairs_g : slots, CV_THREADS, ST_LDS, st>>>(
+            ag, pairs_g, wm_div_make((uint32_t)((a.DH >> 3) * (a.DW >> 3))), wm_div_make((uint32_t)(a.DW >> 3)));
+        WM_LAUNCH_CHECK();
+      }
       return WM_OK;
     }
     // (256-pixel tiles for the 64-channel stem are 7 % faster alone but 10 % slower inside the training

@@ -205,14 +205,15 @@ __global__ __launch_bounds__(LT_THREADS) void layouts_refresh_batched(const WmLa
   else refresh_tile<1>(d, tk * LB_T, tc * LB_T, tile);
 }
 
-// One (32 x 32 (k, c) tile, tap) of one parameter: sum of its nsplit weight-gradient slabs [K][RS][C], in slab order
-// (fixed: bit-reproducible), added to the OIHW gradient.  Reads are 128-byte rows of every slab; the OIHW side is a
+// One (8 x 128 (k, c) tile, tap) of one parameter: sum of its nsplit weight-gradient slabs [K][RS][C], in slab order
+// (fixed: bit-reproducible), added to the OIHW gradient.  A thread owns four channels of one k: per slab the block
+// reads eight 512-byte runs (32 x 32 tiles, i.e. 128-byte runs 18 KB apart, streamed at 2.2 TB/s); the OIHW side is a
 // strided 4-byte read-modify-write (gradients are a few per cent of the slab bytes).
+constexpr int FB_K = 8, FB_C = 128;
 template <int RS>
 __device__ __forceinline__ void fold_tile(const WmLayoutDesc& d, int k0, int c0, int rs) {
   const int K = d.K, C = d.C, ns = d.nsplit;
-  // thread = (k row, four channels): one 16-byte load per slab, eight slabs in flight; C % 4 == 0 (host-checked)
-  const int k = k0 + ((int)threadIdx.x >> 3), c = c0 + ((int)threadIdx.x & 7) * 4;
+  const int k = k0 + ((int)threadIdx.x >> 5), c = c0 + ((int)threadIdx.x & 31) * 4;  // C % 4 == 0 (host-checked)
   if (k >= K || c >= C) return;
   const size_t slab = (size_t)K * RS * C;
   const float* src = d.ws + ((size_t)k * RS + rs) * C + c;
@@ -239,6 +240,7 @@ __device__ __forceinline__ void fold_tile(const WmLayoutDesc& d, int k0, int c0,
 }
 
 // weight-gradient slabs -> += OIHW gradients (and bias slabs -> += bias gradients), all parameters of a backward pass.
+// tiles_c = ceil(C / 128); tiles per parameter = ceil(K / 8) * tiles_c * RS.
 __global__ __launch_bounds__(LT_THREADS) void wgrad_fold_batched(const WmLayoutDesc* __restrict__ descs, int n_desc) {
   const int di = lb_find(descs, n_desc, blockIdx.x);
   const WmLayoutDesc d = descs[di];
@@ -246,11 +248,11 @@ __global__ __launch_bounds__(LT_THREADS) void wgrad_fold_batched(const WmLayoutD
   const int rs = t % d.RS;
   t /= d.RS;
   const int tk = t / d.tiles_c, tc = t - tk * d.tiles_c;
-  if (d.RS == 9) fold_tile<9>(d, tk * LB_T, tc * LB_T, rs);
-  else fold_tile<1>(d, tk * LB_T, tc * LB_T, rs);
+  if (d.RS == 9) fold_tile<9>(d, tk * FB_K, tc * FB_C, rs);
+  else fold_tile<1>(d, tk * FB_K, tc * FB_C, rs);
   if (d.w != nullptr && tc == 0 && rs == 0) {  // bias slabs [nsplit][K] -> bias gradient
-    const int k = tk * LB_T + (int)threadIdx.x;
-    if ((int)threadIdx.x < LB_T && k < d.K) {
+    const int k = tk * FB_K + (int)threadIdx.x;
+    if ((int)threadIdx.x < FB_K && k < d.K) {
       float v = 0.f;
       for (int sp = 0; sp < d.nsplit; ++sp) v += d.w[(size_t)sp * d.K + k];
       reinterpret_cast<float*>(d.krsc)[k] += v;

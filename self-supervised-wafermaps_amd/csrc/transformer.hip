@@ -1177,3 +1177,86 @@ extern "C" int wm_matmul_f32(const float* a, const float* b, float* c, int M, in
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
+
+// ---- per-row ascending argsort of up to 256 float keys (lightly.models.utils.random_token_mask: the permutation of an
+// image's tokens is the argsort of uniform noise; reference scripts/WM811k_benchmark.py:930).  One block per row, a
+// bitonic network over (key, index) pairs in LDS; ties go to the lower index (a stable ascending order), rows are
+// padded to 256 with +inf.
+namespace {
+__global__ __launch_bounds__(256) void argsort_rows_kernel(const float* __restrict__ keys, int S, long long* __restrict__ out) {
+  __shared__ float sk[256];
+  __shared__ int si[256];
+  const int t = threadIdx.x;
+  const size_t row = blockIdx.x;
+  sk[t] = t < S ? keys[row * S + t] : INFINITY;
+  si[t] = t;
+  __syncthreads();
+  for (int k = 2; k <= 256; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const int p = t ^ j;
+      if (p > t) {
+        const float a = sk[t], b = sk[p];
+        const int ia = si[t], ib = si[p];
+        const bool a_after_b = a > b || (a == b && ia > ib);
+        const bool up = (t & k) == 0;
+        if (a_after_b == up) {
+          sk[t] = b; sk[p] = a;
+          si[t] = ib; si[p] = ia;
+        }
+      }
+      __syncthreads();
+    }
+  }
+  if (t < S) out[row * S + t] = si[t];
+}
+
+// y[r][c] = x[r][c] * g[c] (bf16 x / y, f32 g): the trainable gain of a weight-normalised Linear
+// (DINOProjectionHead(norm_last_layer=False)).  Backward: dx = dy * g, dg[c] = sum_r dy[r][c] * x[r][c] (one thread per
+// column walks the rows: a few hundred rows, coalesced across columns, deterministic).
+__global__ __launch_bounds__(256) void colscale_fwd_kernel(const uint16_t* __restrict__ x, const float* __restrict__ g,
+                                                           long long rows, int C, uint16_t* __restrict__ y) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256)
+    y[i] = f2bf(bf2f(x[i]) * g[i % C]);
+}
+__global__ __launch_bounds__(256) void colscale_bwd_kernel(const uint16_t* __restrict__ x, const float* __restrict__ g,
+                                                           const uint16_t* __restrict__ dy, long long rows, int C,
+                                                           uint16_t* __restrict__ dx, float* __restrict__ dg, int accumulate) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float gc = g[c];
+  float acc = 0.f;
+  for (long long r = 0; r < rows; ++r) {
+    const float d = bf2f(dy[r * C + c]);
+    acc = fmaf(d, bf2f(x[r * C + c]), acc);
+    dx[r * C + c] = f2bf(d * gc);
+  }
+  dg[c] = accumulate ? dg[c] + acc : acc;
+}
+}  // namespace
+
+extern "C" int wm_argsort_rows(const float* keys, int rows, int S, long long* out, void* stream) {
+  WM_REQUIRE(keys && out && rows > 0 && S > 0, WM_EINVAL);
+  WM_REQUIRE(S <= 256, WM_EUNSUPPORTED);
+  argsort_rows_kernel<<<rows, 256, 0, static_cast<hipStream_t>(stream)>>>(keys, S, out);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_colscale_fwd(const void* x, const float* g, long long rows, int C, void* y, void* stream) {
+  WM_REQUIRE(x && g && y && rows > 0 && C > 0, WM_EINVAL);
+  long long b = (rows * C + 255) / 256;
+  colscale_fwd_kernel<<<(int)(b < 4096 ? b : 4096), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(x), g, rows, C, static_cast<uint16_t*>(y));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_colscale_bwd(const void* x, const float* g, const void* dy, long long rows, int C, void* dx, float* dg,
+                               int accumulate, void* stream) {
+  WM_REQUIRE(x && g && dy && dx && dg && rows > 0 && C > 0, WM_EINVAL);
+  colscale_bwd_kernel<<<wm_cdiv(C, 256), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(x), g, static_cast<const uint16_t*>(dy), rows, C, static_cast<uint16_t*>(dx), dg, accumulate);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

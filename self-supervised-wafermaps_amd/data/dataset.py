@@ -79,7 +79,14 @@ class WaferLoader:
             yield mine, rng
 
     def __iter__(self):
-        for mine, rng in self._batches():
+        return self.batches_in(0, len(self))
+
+    def batches_in(self, lo: int, hi: int):
+        """Batches lo <= index < hi of the epoch, in order: images are produced only for those (an evaluation pass
+        sharded over the ranks by contiguous batch ranges: models/knn.py)."""
+        for bi, (mine, rng) in enumerate(self._batches()):
+            if bi < lo or bi >= hi:
+                continue
             views, y = self.dataset.get_batch(mine, rng, fmt=self.fmt)
             if self.unwrap_single and len(views) == 1:
                 yield views[0], y

@@ -129,3 +129,21 @@ def sharded_knn_topk(query: torch.Tensor, bank_shard: torch.Tensor, k: int, shar
     dist.all_gather(sims, sim.contiguous())
     dist.all_gather(idxs, idx.contiguous())
     return F_hip.knn_merge(torch.stack(sims), torch.stack(idxs))
+
+
+def all_gather_rows(t: torch.Tensor) -> torch.Tensor:
+    """Concatenation over the ranks (in rank order) of tensors [n_rank, ...] whose first dimension may differ per rank:
+    one all-gather of the row counts, one of the rows padded to the longest shard.  world 1: `t` itself."""
+    w = world_size()
+    if w == 1:
+        return t
+    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+    counts = [torch.empty_like(n) for _ in range(w)]
+    dist.all_gather(counts, n)
+    counts = [int(c.item()) for c in counts]
+    m = max(counts)
+    pad = t.new_zeros((m,) + tuple(t.shape[1:]))
+    pad[: t.shape[0]] = t
+    parts = [torch.empty_like(pad) for _ in range(w)]
+    dist.all_gather(parts, pad.contiguous())
+    return torch.cat([p[:c] for p, c in zip(parts, counts)], dim=0)

@@ -123,11 +123,26 @@ class GraphedTrainStep:
                 ok = ok and float(g[: lows[k + 1]].abs().max()) == 0.0
         return ok
 
-    def capture(self, sample_idx: np.ndarray, rng: np.random.Generator, sync=None):
+    def _training_state(self):
+        """Every tensor a training step mutates besides the gradients: parameters (arena views and the ones outside,
+        e.g. EMA teachers), buffers (BatchNorm statistics and counters, DINO centre, MoCo bank), optimiser moments."""
+        ts = [p.data for p in self.model.parameters()] + [b for b in self.model.buffers() if b.numel()]
+        for a in getattr(self.opt, "_arenas", []):
+            ts += [t for t in (a.momentum, a.second) if t is not None]
+        return ts
+
+    def capture(self, sample_idx: np.ndarray, rng: np.random.Generator, sync=None, restore: bool = True):
         """Warm up eagerly on a side stream, then record the graph(s) (torch.cuda.graph).  `sync` (a
         distributed.GradSync) keeps the warm-up steps data-parallel: without the gradient exchange the
-        replicas' weights would drift apart before the first captured step."""
+        replicas' weights would drift apart before the first captured step.
+        restore: the warm-up steps (and the capture pass itself) are real optimiser steps on the first batch; with
+        restore=True the training state is put back afterwards (parameters, buffers, moments, step counters), so a
+        graph-replayed run is step-for-step the eager run -- only torch's RNG stream has advanced."""
         params = self.tr.sample(self.ds.store, np.asarray(sample_idx), rng)
+        snap = None
+        if restore:
+            torch.cuda.synchronize()
+            snap = ([t.clone() for t in self._training_state()], list(getattr(self.opt, "_steps", [])))
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
@@ -167,6 +182,20 @@ class GraphedTrainStep:
                     x.backward(leaf.grad)
                 self.graphs.append(gk)
         self.graph = g0
+        if snap is not None:
+            # (the capture pass enqueues nothing, but the warm-up steps ran: undo them)
+            torch.cuda.synchronize()
+            with torch.no_grad():
+                for t, saved in zip(self._training_state(), snap[0]):
+                    t.copy_(saved)
+            if hasattr(self.opt, "_steps"):
+                self.opt._steps[:] = snap[1]
+            ops.bump_weight_epoch()
+            ops.refresh_layouts(p for g in self.opt.param_groups for p in g["params"])  # bf16 layouts of the restored weights
+            teachers = [p for p in self.model.parameters() if not p.requires_grad]
+            if teachers:
+                ops.refresh_layouts(teachers)
+            torch.cuda.synchronize()
         return self
 
     def step(self, sample_idx: np.ndarray, rng: np.random.Generator, sync=None):

@@ -54,17 +54,20 @@ class ProjectionHead(nn.Module):
 
 
 class SimCLRProjectionHead(ProjectionHead):
-    """Linear-BN-ReLU (x num_layers-1), Linear-BN  (SimCLR v2 form, lightly's default since 1.2;
-    SURVEY Appendix A.2 — lightly is unpinned in the reference, the BN-free v1 form is not built)."""
+    """lightly SimCLRProjectionHead(input_dim, hidden_dim, output_dim, num_layers=2, batch_norm=True):
+    Linear-BN-ReLU (x num_layers-1), Linear-BN  (the SimCLR v2 form, lightly's default since 1.2; the reference calls
+    it with the defaults, scripts/WM811k_benchmark.py:233).  batch_norm=False is the v1 form: the Linear layers carry
+    a bias and the ReLU rides in the GEMM epilogue."""
 
     def __init__(self, input_dim: int = 2048, hidden_dim: int = 2048, output_dim: int = 128, num_layers: int = 2,
                  batch_norm: bool = True):
-        if not batch_norm:
-            raise NotImplementedError("SimCLRProjectionHead(batch_norm=False) has no HIP path yet")
-        blocks = [(input_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.ReLU())]
+        def bn(dim):
+            return hnn.BatchNorm1d(dim) if batch_norm else None
+
+        blocks = [(input_dim, hidden_dim, bn(hidden_dim), hnn.ReLU())]
         for _ in range(2, num_layers):
-            blocks.append((hidden_dim, hidden_dim, hnn.BatchNorm1d(hidden_dim), hnn.ReLU()))
-        blocks.append((hidden_dim, output_dim, hnn.BatchNorm1d(output_dim), None))
+            blocks.append((hidden_dim, hidden_dim, bn(hidden_dim), hnn.ReLU()))
+        blocks.append((hidden_dim, output_dim, bn(output_dim), None))
         super().__init__(blocks)
 
 
@@ -184,9 +187,43 @@ class DINOProjectionHead(ProjectionHead):
         return self.last_layer(x)
 
 
+class _ColScale(torch.autograd.Function):
+    """y = x * g (per output column): the gain of a weight-normalised Linear applied to the product with the
+    unit-norm rows (wm_colscale_fwd / wm_colscale_bwd)."""
+
+    @staticmethod
+    def forward(ctx, x, g):
+        from . import _lib
+        from ._lib import check, ptr, stream_ptr
+
+        x = x.to(torch.bfloat16).contiguous()
+        rows, c = x.shape
+        gf = g.detach().reshape(-1).float().contiguous()
+        y = torch.empty_like(x)
+        check(_lib.load().wm_colscale_fwd(ptr(x), ptr(gf), rows, c, ptr(y), stream_ptr()), "wm_colscale_fwd")
+        ctx.save_for_backward(x, gf)
+        ctx.gshape = g.shape
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        from . import _lib
+        from ._lib import check, ptr, stream_ptr
+
+        x, gf = ctx.saved_tensors
+        rows, c = x.shape
+        dy = dy.to(torch.bfloat16).contiguous()
+        dx = torch.empty_like(x)
+        dg = torch.empty(c, dtype=torch.float32, device=x.device)
+        check(_lib.load().wm_colscale_bwd(ptr(x), ptr(gf), ptr(dy), rows, c, ptr(dx), ptr(dg), 0, stream_ptr()),
+              "wm_colscale_bwd")
+        return dx, dg.view(ctx.gshape)
+
+
 class _WeightNormLinear(nn.Module):
     """torch.nn.utils.weight_norm(nn.Linear(in, out, bias=False)) with parameters weight_g [out, 1]
-    (filled with 1) and weight_v [out, in]: W = g * v / ||v||_row."""
+    (filled with 1) and weight_v [out, in]: W = g * v / ||v||_row.  norm_last_layer=True (lightly's default, the
+    reference's call) freezes g at 1; with a trainable gain the product with the unit rows is scaled per column."""
 
     def __init__(self, in_features: int, out_features: int, train_gain: bool = False):
         super().__init__()
@@ -194,9 +231,11 @@ class _WeightNormLinear(nn.Module):
         nn.init.kaiming_uniform_(v, a=5 ** 0.5)
         self.weight_g = nn.Parameter(torch.ones(out_features, 1), requires_grad=train_gain)
         self.weight_v = nn.Parameter(v)
-        if train_gain:
-            raise NotImplementedError("DINOProjectionHead(norm_last_layer=False): trainable gain has no HIP path yet")
+        self.train_gain = train_gain
 
     def forward(self, x):
-        w = F_hip.l2_normalize(self.weight_v, eps=0.0)  # gain frozen at 1
-        return ops.linear(x, w)
+        w = F_hip.l2_normalize(self.weight_v, eps=0.0)
+        y = ops.linear(x, w)
+        if self.train_gain:
+            y = _ColScale.apply(y, self.weight_g)
+        return y

@@ -14,8 +14,27 @@ from typing import Dict, List
 import torch
 import torch.nn as nn
 
+from .. import distributed as wdist
 from .. import functional as F_hip
 from ..utils.benchmarking import knn_predict
+
+
+def rank_batches(loader):
+    """This rank's share of an evaluation loader: with torch.distributed initialised and a loader that is not
+    itself rank-sliced, the contiguous range [rank * n / world, (rank + 1) * n / world) of its batches (so that the
+    concatenation over the ranks, in rank order, is the single-process order); otherwise every batch."""
+    w, r = wdist.world_size(), wdist.rank()
+    if w == 1 or getattr(loader, "world_size", 1) > 1:
+        yield from loader
+        return
+    nb = len(loader)
+    lo, hi = r * nb // w, (r + 1) * nb // w
+    if hasattr(loader, "batches_in"):
+        yield from loader.batches_in(lo, hi)   # images are built for the owned batches only
+        return
+    for bi, batch in enumerate(loader):
+        if lo <= bi < hi:
+            yield batch
 
 
 def macro_metrics(preds: torch.Tensor, targets: torch.Tensor, num_classes: int):
@@ -69,13 +88,27 @@ class KNNBenchmarkModule(nn.Module):
 
     @torch.no_grad()
     def on_validation_epoch_start(self):
+        """Rebuild the feature bank (reference :67-85).  Data parallel: every rank embeds only its contiguous share of
+        the kNN loader's batches; ONE all-gather of the shards (37 k x 512 floats for WM-811K: few, large collectives
+        suit the point-to-point xGMI links) leaves the whole bank, in single-process order, on every rank, so the
+        validation batches need no further exchange."""
         feats, targets = [], []
-        for img, target in self.dataloader_kNN:
+        for img, target in rank_batches(self.dataloader_kNN):
             feats.append(self._features(img.to(self.device)))
             targets.append(target.to(self.device))
-        self.feature_bank_nd = torch.cat(feats, dim=0).contiguous()   # [N, D]
+        d = feats[0].shape[1] if feats else 0
+        bank = torch.cat(feats, dim=0).contiguous() if feats else torch.empty((0, d), device=self.device)
+        tbank = (torch.cat(targets, dim=0).long().contiguous() if targets
+                 else torch.empty((0,), dtype=torch.long, device=self.device))
+        if wdist.world_size() > 1 and getattr(self.dataloader_kNN, "world_size", 1) == 1:
+            bank, tbank = wdist.all_gather_rows(bank), wdist.all_gather_rows(tbank)
+        self.feature_bank_nd = bank.contiguous()                      # [N, D]
         self.feature_bank = self.feature_bank_nd.t()                  # [D, N] view, as the reference holds it
-        self.targets_bank = torch.cat(targets, dim=0).long().contiguous()
+        self.targets_bank = tbank
+
+    def shard_eval_batches(self, loader):
+        """(batch index, batch) pairs this rank validates (Trainer.validate): its share of the loader's batches."""
+        return enumerate(rank_batches(loader))
 
     @torch.no_grad()
     def validation_step(self, batch, batch_idx):
@@ -88,12 +121,15 @@ class KNNBenchmarkModule(nn.Module):
 
     def on_validation_epoch_end(self):
         preds, targets = torch.cat(self.all_preds), torch.cat(self.all_targets)
+        if wdist.world_size() > 1:   # the ranks validated disjoint shares: the metrics are over all of them
+            preds, targets = wdist.all_gather_rows(preds.contiguous()), wdist.all_gather_rows(targets.contiguous())
         acc, f1, cm = macro_metrics(preds, targets, self.num_classes)
         self.max_accuracy = max(self.max_accuracy, acc)
         self.max_f1 = max(self.max_f1, f1)
         self.log("knn_accuracy", acc)
         self.log("knn_f1", f1)
         self.confusion_matrix.append(cm.cpu().numpy())
+        self.last_preds, self.last_targets = preds, targets
         self.all_preds.clear()
         self.all_targets.clear()
 

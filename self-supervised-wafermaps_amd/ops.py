@@ -202,9 +202,14 @@ def _desc_table(rows, device, per_tap: bool = False):
         arr = _np.zeros(len(rows), dtype=LAYOUT_DESC)
         tile0 = 0
         for i, (w, krsc, crsk, ws, grad, k, c, rs, ns) in enumerate(rows):
-            tc = (c + 31) // 32
-            arr[i] = (w, krsc, crsk, ws, grad, k, c, rs, tc, tile0, ns)
-            tile0 += ((k + 31) // 32) * tc * (rs if per_tap else 1)
+            if per_tap:   # wm_wgrad_fold: (8 k x 128 c) tiles, one block per tile and tap
+                tc = (c + 127) // 128
+                arr[i] = (w, krsc, crsk, ws, grad, k, c, rs, tc, tile0, ns)
+                tile0 += ((k + 7) // 8) * tc * rs
+            else:         # wm_layouts_refresh: (32 x 32) tiles with all their taps
+                tc = (c + 31) // 32
+                arr[i] = (w, krsc, crsk, ws, grad, k, c, rs, tc, tile0, ns)
+                tile0 += ((k + 31) // 32) * tc
         dev_tab = torch.from_numpy(arr.view(_np.uint8).reshape(-1).copy()).to(device)
         if len(_TABLES) >= _TABLES_MAX:
             for old_key in [kk for kk, vv in _TABLES.items() if not vv[3]][: _TABLES_MAX // 2]:
@@ -406,9 +411,9 @@ def stat_buckets(rows_per_group: int) -> int:
 
 
 def new_stats_buffer(groups: int, channels: int, device) -> torch.Tensor:
-    """Zeroed int64 [groups, STAT_BUCKETS, 2 statistics, 2 (hi, lo), C]: exact fixed-point partial sums
+    """Zeroed int64 [groups, STAT_BUCKETS, 2 statistics, C]: fixed-point partial sums added with integer atomics
     (include/wafer_hip.h, wm_conv2d_fwd_stats); the finalize kernels clear what they read."""
-    return torch.zeros((groups, STAT_BUCKETS, 2, 2, channels), dtype=torch.int64, device=device)
+    return torch.zeros((groups, STAT_BUCKETS, 2, channels), dtype=torch.int64, device=device)
 
 
 def stats_fusable(rows: int, groups: int) -> bool:

@@ -34,6 +34,10 @@ class Trainer:
         """GraphedTrainStep for this (model, loader) or None when the step cannot be captured."""
         if not (self.use_graph and getattr(model, "graph_safe", False) and hasattr(loader, "iter_indices")):
             return None
+        if not getattr(loader, "drop_last", False) and len(loader.dataset) % (loader.batch_size * getattr(loader, "world_size", 1)):
+            # a captured step has ONE batch shape: a short final batch cannot be replayed (ADVICE r2)
+            raise ValueError("Trainer(use_graph=True) needs drop_last=True on the training loader (or a dataset size "
+                             "divisible by the global batch): the captured step replays one batch shape")
         from .graph import GraphedTrainStep
 
         idx, rng = next(iter(loader.iter_indices()))
@@ -100,7 +104,9 @@ class Trainer:
         wdist.sync_bn_buffers(model)  # rank 0's running statistics everywhere, as DDP's broadcast_buffers
         model.eval()
         model.on_validation_epoch_start()
-        for bi, batch in enumerate(val_dataloaders):
+        # data parallel: a model that can shard its evaluation hands each rank its share of the batches
+        batches = model.shard_eval_batches(val_dataloaders) if hasattr(model, "shard_eval_batches") else enumerate(val_dataloaders)
+        for bi, batch in batches:
             model.validation_step(batch, bi)
         model.on_validation_epoch_end()
         model.train()

@@ -9,7 +9,7 @@ import torch
 import torch.nn as nn
 
 from .. import _lib
-from .._lib import check, stream_ptr
+from .._lib import check, ptr, stream_ptr
 
 _ALIGN = 64  # elements; the same rule as optim._Arena so a flattened copy mirrors an arena's gaps
 
@@ -98,7 +98,14 @@ def random_token_mask(size: Tuple[int, int], mask_ratio: float = 0.6, mask_class
     noise = torch.rand(batch_size, sequence_length, device=device, generator=generator)
     if not mask_class_token and sequence_length > 0:
         noise[:, 0] = -1
-    indices = torch.argsort(noise, dim=1)
+    if noise.is_cuda and 0 < sequence_length <= 256:
+        # the permutation on the device: one bitonic network per image (wm_argsort_rows), no library sort
+        noise = noise.float().contiguous()
+        indices = torch.empty((batch_size, sequence_length), dtype=torch.int64, device=noise.device)
+        check(_lib.load().wm_argsort_rows(ptr(noise), batch_size, sequence_length, ptr(indices), stream_ptr()),
+              "wm_argsort_rows")
+    else:  # host tensors (the CPU-side logic tests) and sequences beyond the kernel's 256 keys
+        indices = torch.argsort(noise, dim=1)
     return indices[:, :num_keep], indices[:, num_keep:]
 
 
@@ -143,17 +150,46 @@ def mask_at_index(tokens: torch.Tensor, index: torch.Tensor, mask_token: torch.T
     return set_at_index(tokens, index, mask_token.to(tokens.dtype).expand(b, k, tokens.shape[2]))
 
 
+def _dist_world():
+    import torch.distributed as dist
+
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
 def batch_shuffle(batch: torch.Tensor, distributed: bool = False):
     """lightly.models.utils.batch_shuffle: random permutation of the batch dimension (MoCo's guard against
-    BatchNorm leaking the positive pair across GPUs).  Returns (shuffled batch, permutation)."""
-    if distributed:
-        raise NotImplementedError("batch_shuffle(distributed=True) is not built (the reference runs single-GPU)")
+    BatchNorm leaking the positive pair across GPUs; reference scripts/WM811k_benchmark.py:321).  Returns
+    (shuffled batch, permutation).  distributed=True (lightly's batch_shuffle_distributed): the batch is gathered
+    from all ranks, ONE permutation of the global batch (rank 0's, broadcast) is applied and every rank keeps its
+    contiguous share; the second return value is then the inverse permutation for batch_unshuffle."""
+    if distributed and _dist_world() > 1:
+        import torch.distributed as dist
+
+        from ..distributed import all_gather_rows
+
+        world, rank = dist.get_world_size(), dist.get_rank()
+        gathered = all_gather_rows(batch.contiguous())
+        n_all = gathered.shape[0]
+        idx_shuffle = torch.randperm(n_all, device=batch.device)
+        dist.broadcast(idx_shuffle, src=0)
+        idx_unshuffle = torch.argsort(idx_shuffle)
+        idx_this = idx_shuffle.view(world, -1)[rank]
+        return gathered[idx_this], idx_unshuffle
     shuffle = torch.randperm(batch.shape[0], device=batch.device)
     return batch[shuffle], shuffle
 
 
 def batch_unshuffle(batch: torch.Tensor, shuffle: torch.Tensor, distributed: bool = False):
-    if distributed:
-        raise NotImplementedError("batch_unshuffle(distributed=True) is not built")
+    """Undo batch_shuffle.  distributed=True: `shuffle` is the inverse permutation of the GLOBAL batch returned by
+    batch_shuffle(distributed=True); the ranks' batches are gathered again and this rank takes its original rows."""
+    if distributed and _dist_world() > 1:
+        import torch.distributed as dist
+
+        from ..distributed import all_gather_rows
+
+        world, rank = dist.get_world_size(), dist.get_rank()
+        gathered = all_gather_rows(batch.contiguous())
+        idx_this = shuffle.view(world, -1)[rank]
+        return gathered[idx_this]
     unshuffle = torch.argsort(shuffle)
     return batch[unshuffle]

@@ -259,3 +259,187 @@ def _sharded_knn(rank, world):
 
 def test_sharded_knn_topk_equals_unsharded_world2():
     _spawn(_sharded_knn, 2)
+
+
+# ---- sharded kNN evaluation on the product path (models/knn.py, utils/benchmarking.KNNClassifier)
+def _knn_stand_ins():
+    """Contract-equivalent torch code for wm_l2_normalize / wm_knn_topk / wm_knn_vote (no GPU here)."""
+    import ssl_wafermap_amd.functional as F_hip
+
+    def ref_l2(x, eps=1e-12, out_dtype=None):
+        return torch.nn.functional.normalize(x.float(), dim=1, eps=eps)
+
+    def ref_topk(query, bank, k, index_base=0):
+        s, i = (query @ bank.t()).topk(k, dim=1)
+        return s, (i + index_base).to(torch.int32)
+
+    def ref_vote(sim, idx, labels, num_classes, t):
+        w = (sim / t).exp()
+        one = torch.zeros(sim.shape[0], num_classes)
+        one.scatter_add_(1, labels[idx.long()], w)
+        return one.argsort(dim=1, descending=True)
+
+    F_hip.l2_normalize, F_hip.knn_topk, F_hip.knn_vote = ref_l2, ref_topk, ref_vote
+
+
+class _ListLoader:
+    """A plain list of (images, targets) batches with a length: what rank_batches shards by contiguous ranges."""
+
+    def __init__(self, batches):
+        self.batches = batches
+
+    def __len__(self):
+        return len(self.batches)
+
+    def __iter__(self):
+        return iter(self.batches)
+
+
+def _knn_problem():
+    g = torch.Generator().manual_seed(5)
+    proj = torch.randn(20, 12, generator=g)
+    centers = torch.randn(4, 20, generator=g) * 2
+    def make(n):
+        y = torch.randint(0, 4, (n,), generator=g)
+        return centers[y] + torch.randn(n, 20, generator=g), y
+    xb, yb = make(103)
+    xv, yv = make(41)
+    bank = _ListLoader([(xb[i:i + 16], yb[i:i + 16]) for i in range(0, 103, 16)])   # 7 batches, ragged tail
+    val = _ListLoader([(xv[i:i + 8], yv[i:i + 8]) for i in range(0, 41, 8)])        # 6 batches
+    return proj, bank, val
+
+
+def _knn_module_run(world_tag):
+    from ssl_wafermap_amd.models.knn import KNNBenchmarkModule
+    from ssl_wafermap_amd.trainer import Trainer
+
+    proj, bank, val = _knn_problem()
+
+    class M(KNNBenchmarkModule):
+        def __init__(self):
+            super().__init__(bank, 4, knn_k=5, knn_t=0.1)
+            self.backbone = torch.nn.Linear(20, 12, bias=False)
+            with torch.no_grad():
+                self.backbone.weight.copy_(proj.t())
+
+    m = M()
+    tr = Trainer(verbose=False)
+    torch.cuda.synchronize = lambda *a, **k: None
+    tr.validate(m, val)
+    return m
+
+
+def _sharded_knn_module(rank, world):
+    _knn_stand_ins()
+    m = _knn_module_run("dp")
+    # every rank holds the whole bank in single-process order and reports the metrics of ALL validation samples
+    _, bank, val = _knn_problem()
+    assert m.feature_bank_nd.shape[0] == 103 and torch.equal(m.targets_bank, torch.cat([y for _, y in bank.batches]))
+    assert m.last_preds.shape[0] == 41 and torch.equal(m.last_targets, torch.cat([y for _, y in val.batches]))
+    out = torch.cat([m.last_preds.float(), torch.tensor([m.logged["knn_accuracy"], m.logged["knn_f1"]])])
+    both = [torch.empty_like(out) for _ in range(world)]
+    dist.all_gather(both, out)
+    assert torch.equal(both[0], both[1])
+    torch.save(out, os.environ["WM_TEST_OUT"] + f".{rank}")
+
+
+def test_knn_module_sharded_evaluation_equals_single_process_world2(tmp_path):
+    """KNNBenchmarkModule under world_size 2: each rank embeds its share of the bank and validates its share of the
+    batches; predictions and metrics equal the single-process run EXACTLY."""
+    _knn_stand_ins()
+    single = _knn_module_run("single")
+    want = torch.cat([single.last_preds.float(), torch.tensor([single.logged["knn_accuracy"], single.logged["knn_f1"]])])
+    os.environ["WM_TEST_OUT"] = str(tmp_path / "knn_out")
+    _spawn(_sharded_knn_module, 2)
+    for r in range(2):
+        got = torch.load(str(tmp_path / "knn_out") + f".{r}")
+        assert torch.equal(got, want)
+
+
+def test_knn_classifier_fit_and_predict_cpu_contract():
+    """utils.benchmarking.KNNClassifier (lightly's class form): bank from training_step batches, top-k accuracies
+    from validation_step, predictions equal to knn_predict on the same features."""
+    from ssl_wafermap_amd.utils.benchmarking import KNNClassifier, knn_predict, mean_topk_accuracy
+
+    _knn_stand_ins()
+    proj, bank, val = _knn_problem()
+    model = torch.nn.Linear(20, 12, bias=False)
+    with torch.no_grad():
+        model.weight.copy_(proj.t())
+    clf = KNNClassifier(model, num_classes=4, knn_k=5, knn_t=0.1, topk=(1, 3))
+    assert clf.validation_step(val.batches[0]) is None            # no bank yet
+    clf.fit_bank(bank)
+    assert clf._train_features_tensor.shape == (12, 103)
+    xb = torch.cat([x for x, _ in bank.batches])
+    yb = torch.cat([y for _, y in bank.batches])
+    fb = torch.nn.functional.normalize(xb @ proj, dim=1)
+    hits = 0
+    for x, y in val.batches:
+        pred = clf.validation_step((x, y))
+        want = knn_predict(torch.nn.functional.normalize(x @ proj, dim=1), fb.t(), yb, 4, 5, 0.1)
+        assert torch.equal(pred, want)
+        acc = mean_topk_accuracy(pred, y, k=(1, 3))
+        assert float(clf.logged["val_top1"]) == float(acc[1]) and float(acc[3]) >= float(acc[1])
+        hits += int((pred[:, 0] == y).sum())
+    assert hits / 41 > 0.6
+
+
+def _batch_shuffle(rank, world):
+    from ssl_wafermap_amd.utils.model_utils import batch_shuffle, batch_unshuffle
+
+    torch.manual_seed(100 + rank)      # different generators per rank: the permutation must still be rank 0's
+    mine = torch.arange(6, dtype=torch.float32).reshape(6, 1) + 10 * rank
+    shuf, inv = batch_shuffle(mine.clone(), distributed=True)
+    assert shuf.shape == mine.shape
+    both = [torch.empty_like(shuf) for _ in range(world)]
+    dist.all_gather(both, shuf)
+    seen = sorted(torch.cat(both).flatten().tolist())
+    assert seen == sorted(list(range(6)) + [10 + i for i in range(6)])       # a permutation of the GLOBAL batch
+    invs = [torch.empty_like(inv) for _ in range(world)]
+    dist.all_gather(invs, inv)
+    assert torch.equal(invs[0], invs[1])                                      # one permutation, rank 0's
+    back = batch_unshuffle(shuf * 2.0, inv, distributed=True)                 # (a per-row function in between)
+    assert torch.equal(back, mine * 2.0)
+
+
+def test_batch_shuffle_distributed_world2():
+    _spawn(_batch_shuffle, 2)
+
+
+def _gathered_sinkhorn(rank, world):
+    """loss.sinkhorn(gather_distributed=True) all-gathers the [B, K] scores and runs ONE Sinkhorn on the global matrix,
+    keeping this rank's rows.  lightly instead all-reduces the total and the per-prototype sums inside the loop: the
+    two formulations are the same iteration (checked here with the kernel's arithmetic restated in torch)."""
+    import ssl_wafermap_amd.loss as L
+
+    b, k = 5, 12
+    g = torch.Generator().manual_seed(1)
+    scores_all = torch.randn(world * b, k, generator=g)
+
+    def sinkhorn_matrix(out, iterations, eps):        # wm_sinkhorn's contract on one matrix
+        q = torch.exp(out / eps).t()
+        q = q / q.sum()
+        kk, bb = q.shape
+        for _ in range(iterations):
+            q = q / q.sum(1, keepdim=True) / kk
+            q = q / q.sum(0, keepdim=True) / bb
+        return (q * bb).t()
+
+    mine = scores_all[rank * b:(rank + 1) * b]
+    gathered = L._all_gather_rows(mine.contiguous())            # the product path's exchange
+    assert torch.equal(gathered, scores_all)
+    got = sinkhorn_matrix(gathered, 3, 0.05)[rank * b:(rank + 1) * b]
+    q = torch.exp(mine / 0.05).t()                              # lightly.loss.swav_loss.sinkhorn, gather_distributed
+    tot = q.sum()
+    dist.all_reduce(tot)
+    q = q / tot
+    for _ in range(3):
+        rs = q.sum(1, keepdim=True)
+        dist.all_reduce(rs)
+        q = q / rs / k
+        q = q / q.sum(0, keepdim=True) / (b * world)
+    torch.testing.assert_close(got, (q * b * world).t(), rtol=1e-5, atol=1e-7)
+
+
+def test_sinkhorn_gather_distributed_equals_lightly_allreduce_form_world2():
+    _spawn(_gathered_sinkhorn, 2)

@@ -622,3 +622,109 @@ def test_knn_topk_batched_pipelined_equals_single_calls():
             s1, i1 = F.knn_topk(q[o:o + 64], bank, 8)
             assert torch.equal(sim[o:o + 64], s1) and torch.equal(idx[o:o + 64], i1)
         assert torch.equal(idx[:, 0].long().cpu(), torch.arange(100, 100 + q.shape[0]))
+
+
+def test_knn_classifier_matches_oracle_knn_predict():
+    """utils.benchmarking.KNNClassifier (north_star's API name; lightly's class form of the reference's knn_predict
+    evaluation, src/ssl_wafermap/models/knn.py:67-101) on the HIP kernels against the oracle on the same features."""
+    from oracle import knn as ok
+    from ssl_wafermap_amd.utils.benchmarking import KNNClassifier, mean_topk_accuracy
+
+    g = torch.Generator().manual_seed(11)
+    w = torch.randn(48, 64, generator=g)
+    centers = torch.randn(6, 48, generator=g) * 1.5
+
+    def make(n):
+        y = torch.randint(0, 6, (n,), generator=g)
+        return centers[y] + torch.randn(n, 48, generator=g), y
+
+    xb, yb = make(900)
+    xv, yv = make(130)
+
+    class Backbone(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.w = torch.nn.Parameter(w.clone())
+
+        def forward(self, x):
+            return x @ self.w
+
+    clf = KNNClassifier(Backbone().to(DEV), num_classes=6, knn_k=20, knn_t=0.1, topk=(1, 5))
+    clf.fit_bank([(xb[i:i + 128].to(DEV), yb[i:i + 128].to(DEV)) for i in range(0, 900, 128)])
+    pred = clf.validation_step((xv.to(DEV), yv.to(DEV)))
+    fb = torch.nn.functional.normalize(xb @ w, dim=1)
+    fq = torch.nn.functional.normalize(xv @ w, dim=1)
+    want = ok.knn_predict(fq, fb.t().contiguous(), yb, 6, 20, 0.1)
+    assert torch.equal(pred[:, 0].cpu(), want[:, 0])
+    acc = mean_topk_accuracy(want, yv, k=(1, 5))
+    assert abs(float(clf.logged["val_top1"]) - float(acc[1])) < 1e-6
+    assert float(clf.logged["val_top5"]) >= float(clf.logged["val_top1"]) > 0.8
+
+
+def test_projection_head_variants_match_torch():
+    """SimCLRProjectionHead(batch_norm=False) (the v1 form: Linear+bias, ReLU, Linear+bias) and
+    DINOProjectionHead(norm_last_layer=False) (trainable weight-norm gain) -- SURVEY Appendix A.2 -- forward and
+    gradients against torch float32 on the same (bf16-exact) weights."""
+    from ssl_wafermap_amd import heads
+
+    torch.manual_seed(0)
+    x = torch.randn(64, 128).bfloat16().float()
+    # ---- SimCLR v1
+    h = heads.SimCLRProjectionHead(128, 128, 64, batch_norm=False).to(DEV)
+    assert [type(m).__name__ for m in h.layers] == ["Linear", "ReLU", "Linear"] and h.layers[0].bias is not None
+    with torch.no_grad():
+        for p in h.parameters():
+            p.copy_(p.bfloat16().float())
+    xd = x.to(DEV).bfloat16().requires_grad_(True)
+    out = h(xd)
+    t = torch.randn(64, 64)
+    (out.float() * t.to(DEV)).sum().backward()
+    w0, b0, w1, b1 = [p.detach().cpu().clone().requires_grad_(True) for p in h.parameters()]
+    xr = x.clone().requires_grad_(True)
+    ref = torch.relu(xr @ w0.t() + b0) @ w1.t() + b1
+    (ref * t).sum().backward()
+    torch.testing.assert_close(out.float().cpu(), ref.detach(), atol=3e-2, rtol=2e-2)
+    for p, r in zip(h.parameters(), (w0, b0, w1, b1)):
+        torch.testing.assert_close(p.grad.cpu(), r.grad, atol=2e-2 * float(r.grad.abs().max()), rtol=2e-2)
+    # ---- DINO head with a trainable last-layer gain
+    d = heads.DINOProjectionHead(128, 128, 64, 256, norm_last_layer=False).to(DEV)
+    assert d.last_layer.weight_g.requires_grad
+    with torch.no_grad():
+        d.last_layer.weight_g.copy_(torch.rand(256, 1) + 0.5)
+    z = torch.nn.functional.normalize(torch.randn(64, 64), dim=1).bfloat16().float()
+    zd = z.to(DEV).bfloat16().requires_grad_(True)
+    y = d.last_layer(zd)
+    t2 = torch.randn(64, 256)
+    (y.float() * t2.to(DEV)).sum().backward()
+    v = d.last_layer.weight_v.detach().cpu().clone().requires_grad_(True)
+    gq = d.last_layer.weight_g.detach().cpu().clone().requires_grad_(True)
+    zr = z.clone().requires_grad_(True)
+    wn = gq * v / v.norm(dim=1, keepdim=True)
+    yr = zr @ wn.t()
+    (yr * t2).sum().backward()
+    torch.testing.assert_close(y.float().cpu(), yr.detach(), atol=2e-2, rtol=2e-2)
+    torch.testing.assert_close(d.last_layer.weight_g.grad.cpu(), gq.grad, atol=3e-2 * float(gq.grad.abs().max()), rtol=3e-2)
+    torch.testing.assert_close(d.last_layer.weight_v.grad.cpu(), v.grad, atol=3e-2 * float(v.grad.abs().max()), rtol=5e-2)
+    torch.testing.assert_close(zd.grad.float().cpu(), zr.grad, atol=3e-2 * float(zr.grad.abs().max()), rtol=5e-2)
+
+
+def test_random_token_mask_on_device_equals_argsort():
+    """random_token_mask's permutation is built by wm_argsort_rows (a bitonic network per image), not a library sort:
+    same indices as torch.argsort of the same noise, class token first, for the reference's sequence lengths."""
+    from ssl_wafermap_amd import _lib
+    from ssl_wafermap_amd._lib import check, ptr, stream_ptr
+    from ssl_wafermap_amd.utils import random_token_mask
+
+    for b, s in ((7, 50), (5, 197), (3, 256), (4, 1)):
+        noise = torch.rand(b, s, device=DEV)
+        noise[:, 0] = -1
+        noise[:, s // 2] = noise[:, -1]          # a tie: the lower index first
+        idx = torch.empty((b, s), dtype=torch.int64, device=DEV)
+        check(_lib.load().wm_argsort_rows(ptr(noise), b, s, ptr(idx), stream_ptr()), "wm_argsort_rows")
+        want = torch.argsort(noise, dim=1, stable=True)
+        assert torch.equal(idx, want), (b, s)
+    g = torch.Generator(device=DEV).manual_seed(3)
+    keep, mask = random_token_mask((6, 50), 0.75, device=DEV, generator=g)
+    assert keep.shape == (6, 12) and mask.shape == (6, 38) and bool((keep[:, 0] == 0).all())
+    both = torch.cat([keep, mask], dim=1).sort(dim=1).values
+    assert torch.equal(both, torch.arange(50, device=DEV).expand(6, 50))
