@@ -201,16 +201,17 @@ int wm_ntxent_bwd(const float* zn, const float* zall, const float* lse_all, int 
  * (the space-to-depth stem).  A Linear layer is the 1x1 convolution with H = W = P = Q = 1. */
 int wm_conv2d_fwd(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
                   int R, int S, int P, int Q, int stride, int pad, void* stream);
-/* The same convolution, also accumulating the per-channel (sum, sum of squares) of its bf16 outputs
- * into stat_part: int64 [G][stat_buckets][2 statistics][K] (G = N*P*Q / rows_per_group row groups, bucket = tile %
- * stat_buckets).  A tile's f32 partial sum p is added as the integer rint(p * 2^24) with a 64-bit INTEGER atomic
- * (associative), so a bucket holds the same value whatever the arrival order: the statistics (and everything
- * downstream) are bit-reproducible from run to run.  |bucket sum| < 5.5e11, resolution 6e-8.
- * rows_per_group % 128 == 0.  stat_part must be zero on entry; wm_bn_train_fwd_from_stats clears it again as it
- * reads it. */
+/* The same convolution, also leaving the per-channel (sum, sum of squares) of its bf16 outputs in stat_part: f32
+ * [G][stat_tiles][2 statistics][K] (G = N*P*Q / rows_per_group row groups).  Every 128-row output tile STORES its
+ * column sums into its own slot (no atomics, nothing to zero); wm_bn_train_fwd_from_stats adds the slots in slot
+ * order, so the statistics -- and everything downstream -- are bit-reproducible from run to run.
+ * stat_tiles = wm_conv2d_fwd_stats_tiles(same geometry): rows_per_group / 128, except for the persistent stem
+ * kernel, whose workgroups sum over their tiles and write one slot each.  rows_per_group % 128 == 0. */
+int wm_conv2d_fwd_stats_tiles(int N, int H, int W, int C, int K, int R, int S, int P, int Q, int stride, int pad,
+                              int rows_per_group);
 int wm_conv2d_fwd_stats(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K,
-                        int R, int S, int P, int Q, int stride, int pad, void* stat_part,
-                        int stat_buckets, int rows_per_group, void* stream);
+                        int R, int S, int P, int Q, int stride, int pad, float* stat_part,
+                        int stat_tiles, int rows_per_group, void* stream);
 /* dx = conv_transpose(dy, w): w_crsk bf16 [C][R][S][K]; C % 64 == 0. */
 int wm_conv2d_dgrad(const void* dy, const void* w_crsk, void* dx, int N, int H, int W, int C, int K,
                     int R, int S, int P, int Q, int stride, int pad, void* stream);
@@ -224,9 +225,9 @@ int wm_conv2d_dgrad_add(const void* dy, const void* w_crsk, const void* residual
  * scripts/WM811k_benchmark.py:231): the epilogue takes the gradient through the ReLU and accumulates the
  * BatchNorm-backward sums, so that BatchNorm's backward needs no reduction pass and no mask:
  *   g  = (conv_transpose(dy, w) (+ residual)) * mask          -> dx (the MASKED gradient, bf16)
- *   stat_part [G][stat_buckets][2][C] int64 += (sum g, sum g * bn_y) per channel, as rint(p * 2^44)
- *        (wm_conv2d_fwd_stats's fixed-point form at the scale of gradients: |bucket sum| < 5.2e5, resolution 5.7e-14;
- *        zero on entry, cleared by wm_bn_train_bwd_from_stats, which forms sum g * xhat from the two)
+ *   stat_part f32 [G][stat_tiles][2][C] = per-tile (sum g, sum g * bn_y) per channel, stat_tiles = rows of dx per
+ *        group / 128 (plain stores into the tile's slot; wm_bn_train_bwd_from_stats adds the slots in order and forms
+ *        sum g * xhat = invstd * (sum g y - mean * sum g) in double)
  * mask = relu_x > 0 when relu_x (the convolution's own forward input, shape of dx) is given; else recomputed from
  * bn_y as bf16(bn_y * gamma * invstd + beta - mean * gamma * invstd) > 0 (a BatchNorm without shortcut).
  * bn_y has the shape of dx; save_mean / save_invstd [G][C] over G equal groups of images.
@@ -236,7 +237,7 @@ int wm_conv2d_dgrad_bnstat_ok(int N, int H, int W, int C, int K, int R, int S, i
 int wm_conv2d_dgrad_bnstat(const void* dy, const void* w_crsk, const void* residual, void* dx, int N, int H, int W,
                            int C, int K, int R, int S, int P, int Q, int stride, int pad, const void* bn_y,
                            const void* relu_x, const float* gamma, const float* beta, const float* save_mean,
-                           const float* save_invstd, int G, void* stat_part, int stat_buckets, void* stream);
+                           const float* save_invstd, int G, float* stat_part, int stat_tiles, void* stream);
 /* Weight gradient: sum over pixels of dy (x) x, split over pixel ranges.  Split z STORES its partial sums into slab z
  * of dw_slabs (f32 [nsplit][K][R][S][C], nsplit = wm_conv2d_wgrad_splits(same geometry)): no atomics, nothing to zero;
  * wm_wgrad_fold / wm_wgrad_finalize / wm_stem_wgrad_finalize sum the slabs in a fixed order (bit-reproducible). */
@@ -266,6 +267,16 @@ int wm_linear_bias_gelu_fwd(const void* x, const void* w_krsc, const float* bias
 int wm_linear_dgrad_gelu(const void* dy, const void* w_crsk, const void* pre, void* dx, int rows, int C, int K,
                          void* stream);
 
+/* The whole transformer MLP block in ONE launch, for forward passes that keep nothing for a backward pass (the DINO
+ * teacher, kNN / embedding inference, validation): y = fc2(gelu(fc1(x) + b1)) + b2 (+ residual), with the hidden
+ * activation living in LDS only (128 token rows per workgroup, 128 hidden units at a time).  x, y, residual
+ * [rows][C] bf16; w1_krsc [H][C], w2_krsc [C][H] bf16 (forward layouts); b1 [H], b2 [C] f32.  Bit-identical to
+ * wm_linear_bias_gelu_fwd followed by wm_conv2d_fwd_bias_res.  wm_mlp_fused_fwd_ok: 1 for the served shapes (C = 192,
+ * H % 128 == 0: ViT-Tiny; wider x tiles do not fit beside the weight ring in 160 KB of LDS). */
+int wm_mlp_fused_fwd_ok(int rows, int C, int H);
+int wm_mlp_fused_fwd(const void* x, const void* w1_krsc, const float* b1, const void* w2_krsc, const float* b2,
+                     const void* residual, void* y, int rows, int C, int H, void* stream);
+
 /* f32 OIHW master weights -> bf16 [K][R][S][C] and/or [C][R][S][K] (either may be NULL). */
 int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int S, void* w_krsc, void* w_crsk,
                        void* stream);
@@ -275,8 +286,9 @@ int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int S, void* w_
  *   layouts (either may be NULL); RS = R*S in {1, 9}; tiles_c = ceil(C / 32); tile0 = index of the parameter's first
  *   32 x 32 (k, c) tile in the launch; total_tiles = sum over parameters of ceil(K / 32) * tiles_c.
  * wm_wgrad_fold: ws = f32 weight-gradient slabs [nsplit][K][RS][C] (wm_conv2d_wgrad), nsplit slabs summed in order;
- *   grad = f32 OIHW gradient (grad += sum); a block owns (8 x 128 (k, c) tile, one tap): tiles_c = ceil(C / 128),
- *   tiles per parameter = ceil(K / 8) * tiles_c * RS; C % 4 == 0.  Optional bias: w = f32 bias slabs [nsplit][K], krsc = (float*) bias gradient [K]
+ *   grad = f32 OIHW gradient (grad += sum); nsplit <= 32: a block owns an 8 x 128 (k, c) tile with all its taps
+ *   (tiles_c = ceil(C / 128), tiles = ceil(K / 8) * tiles_c); else a 4 x 64 tile of ONE tap (tiles_c = ceil(C / 64),
+ *   tiles = ceil(K / 4) * tiles_c * RS) with the slab range cut in four, summed in order; C % 4 == 0.  Optional bias: w = f32 bias slabs [nsplit][K], krsc = (float*) bias gradient [K]
  *   (+=), both NULL when absent (crsk unused).
  * Replaces 24-100 wm_weights_prepare / 19 wm_wgrad_finalize launches per training step. */
 typedef struct WmLayoutDesc {
@@ -318,14 +330,14 @@ int wm_bn_train_fwd_from_stats(const void* y, const void* residual, const float*
                                float* running_mean, float* running_var, long long* num_batches_tracked,
                                long long rows, int C, int G, float eps, float momentum, int relu, float* save_mean,
                                float* save_invstd,
-                               void* out, void* stat_part, int stat_buckets, void* workspace,
+                               void* out, const float* stat_part, int stat_tiles, void* workspace,
                                size_t workspace_bytes, void* stream);
 /* Statistics only: mean / invstd / running stats and the [G][C] scale, shift of the normalisation, for a
  * consumer that applies it itself (the fused stem below).  stat_part NULL: computed from y here. */
 int wm_bn_train_stats(const void* y, const float* gamma, const float* beta, float* running_mean,
                       float* running_var, long long* num_batches_tracked, long long rows, int C, int G, float eps, float momentum,
-                      float* save_mean, float* save_invstd, float* scale, float* shift, void* stat_part,
-                      int stat_buckets, void* workspace, size_t workspace_bytes, void* stream);
+                      float* save_mean, float* save_invstd, float* scale, float* shift, const float* stat_part,
+                      int stat_tiles, void* workspace, size_t workspace_bytes, void* stream);
 int wm_bn_eval_scale_shift(const float* gamma, const float* beta, const float* running_mean,
                            const float* running_var, int C, float eps, float* scale, float* shift, void* stream);
 int wm_bn_eval_fwd(const void* y, const void* residual, const float* gamma, const float* beta,
@@ -339,13 +351,13 @@ int wm_bn_train_bwd(const void* y, const void* dout, const void* out_relu, int r
                     const float* gamma, const float* beta, const float* save_mean, const float* save_invstd,
                     long long rows, int C, int G, float* dgamma, float* dbeta, int accumulate, void* dy,
                     void* dz, void* workspace, size_t workspace_bytes, void* stream);
-/* Backward whose sums were accumulated by wm_conv2d_dgrad_bnstat: g is the gradient ALREADY taken through the ReLU
- * (it is also the gradient of the shortcut branch, if any): finalize (and clear) stat_part, dgamma / dbeta (= or +=),
- * then one pass dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)).  workspace >= 7 * G * C floats. */
+/* Backward whose per-tile sums were stored by wm_conv2d_dgrad_bnstat: g is the gradient ALREADY taken through the ReLU
+ * (it is also the gradient of the shortcut branch, if any): add the slots in order, dgamma / dbeta (= or +=), then one
+ * pass dy = gamma * invstd * (g - mean(g) - xhat * mean(g * xhat)).  workspace >= (7 + 256) * G * C floats. */
 int wm_bn_train_bwd_from_stats(const void* y, const void* g, const float* gamma, const float* beta,
                                const float* save_mean, const float* save_invstd, long long rows, int C, int G,
-                               float* dgamma, float* dbeta, int accumulate, void* dy, void* stat_part,
-                               int stat_buckets, void* workspace, size_t workspace_bytes, void* stream);
+                               float* dgamma, float* dbeta, int accumulate, void* dy, const float* stat_part,
+                               int stat_tiles, void* workspace, size_t workspace_bytes, void* stream);
 /* Backward of the fused stem tail max_pool3x3s2(relu(BN(y))): y [N][H][W][C]; the gradient entering
  * the BN is gathered from pooled_dy / pool_idx [N][P][Q][C] inside the apply pass; with ysel (the
  * inputs at the selected positions, from the forward; may be NULL) the per-channel sums run over the

@@ -95,6 +95,10 @@ SIGNATURES = {
     "wm_weights_prepare": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "wm_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p]),
     "wm_conv2d_wgrad_splits": (c_int, [c_int] * 11),
+    "wm_mlp_fused_fwd_ok": (c_int, [c_int, c_int, c_int]),
+    "wm_mlp_fused_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int,
+                                c_void_p]),
+    "wm_conv2d_fwd_stats_tiles": (c_int, [c_int] * 12),
     "wm_conv2d_dgrad_bnstat_ok": (c_int, [c_int] * 12),
     "wm_conv2d_dgrad_bnstat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 11 +
                                [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),

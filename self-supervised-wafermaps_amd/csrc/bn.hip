@@ -219,33 +219,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_reduce(const uint16_t* __restri
 // of what these few-microsecond launches cost (44 of them per SimCLR step).
 __device__ __forceinline__ void finalize_sums2(float* __restrict__ part, int nblk, int g, int ng, int C, int c,
                                                int bl, int cl, double (*red)[2][32][33], double (&s)[2],
-                                               double (&ss)[2], bool clear = false, int fx = 0) {  // fx: 0 = f32 partials, else the fixed-point shift
+                                               double (&ss)[2], bool clear = false) {
   double a[2] = {0.0, 0.0}, b[2] = {0.0, 0.0};
-  if (c < C && fx) {
-    // fixed-point buckets of the convolution epilogues (wm_fx_add): int64 [nblk][2][C] per group; integer sums first
-    // (exact), one conversion per lane
-    long long* fxp = reinterpret_cast<long long*>(part);
-    long long t0[2] = {0, 0}, t1[2] = {0, 0};
-    for (int k = bl; k < nblk; k += 32) {
-#pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        if (u < ng) {
-          long long* q = fxp + ((size_t)((g + u) * nblk + k) * 2) * C + c;
-          t0[u] += q[0];
-          t1[u] += q[(size_t)C];
-          if (clear) {
-            q[0] = 0;
-            q[(size_t)C] = 0;
-          }
-        }
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      a[u] = wm_fx_value(t0[u], fx);
-      b[u] = wm_fx_value(t1[u], fx);
-    }
-  } else if (c < C) {
+  if (c < C) {
     for (int k = bl; k < nblk; k += 32) {
       float va[2] = {0.f, 0.f}, vb[2] = {0.f, 0.f};
 #pragma unroll
@@ -311,7 +287,7 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize(
   for (int g0 = 0; g0 < G; g0 += 2) {
     const int ng = G - g0 < 2 ? G - g0 : 2;
     double s2[2], ss2[2];
-    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s2, ss2, clear != 0, clear != 0 ? WM_FX_FWD : 0);
+    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s2, ss2, clear != 0);
     if (owner) {
       for (int u = 0; u < ng; ++u) {
         const int g = g0 + u;
@@ -414,7 +390,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize(
     float* __restrict__ part, int nblk, int G, int C, int rows_per_group,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-    float* __restrict__ coef, int fx) {
+    float* __restrict__ coef, int fx) {  // fx: the second sum is sum g * y (dgrad epilogue), not sum g * xhat
   __shared__ double red[2][2][32][33];
   const int bl = threadIdx.x >> 5, cl = threadIdx.x & 31;
   const int c = blockIdx.x * 32 + cl;
@@ -423,7 +399,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize(
   for (int g0 = 0; g0 < G; g0 += 2) {
     const int ng = G - g0 < 2 ? G - g0 : 2;
     double s1v[2], s2v[2];
-    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s1v, s2v, fx != 0, fx != 0 ? WM_FX_BWD : 0);
+    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, s1v, s2v);
     if (owner) {
       for (int u = 0; u < ng; ++u) {
         const int g = g0 + u;
@@ -605,6 +581,49 @@ __global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply(const uint16_t* 
       *reinterpret_cast<uint4*>(dy + off) = pack8(r);
     }
   }
+}
+
+// Tile slots [G][T][2][C] -> [G][T / R][2][C]: every output element is the sum of R consecutive slots, in slot order
+// (fixed: bit-reproducible).  Used when a convolution wrote more slots per group than the finalize kernels' 32-lane
+// strided walk handles quickly (64-channel layers at batch 512: 6272 tiles per view).
+__global__ __launch_bounds__(BN_THREADS) void stats_prereduce(const float* __restrict__ in, int T, int R, int To, int GC2,
+                                                              int C2, float* __restrict__ out) {
+  // one thread per (group, output slot, statistic, channel): consecutive threads = consecutive channels
+  const long long i = (long long)blockIdx.x * BN_THREADS + threadIdx.x;
+  const long long total = (long long)GC2 / C2 * To * C2;  // G * To * (2 C)
+  if (i >= total) return;
+  const int c2 = (int)(i % C2);
+  const long long u = i / C2;
+  const int to = (int)(u % To), g = (int)(u / To);
+  const float* src = in + ((size_t)g * T + (size_t)to * R) * C2 + c2;
+  const int n = min(R, T - to * R);
+  float v = 0.f;
+  int k = 0;
+  for (; k + 8 <= n; k += 8) {
+    float t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = src[(size_t)(k + q) * C2];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v += t[q];
+  }
+  for (; k < n; ++k) v += src[(size_t)k * C2];
+  out[i] = v;
+}
+
+// Statistics slots of a convolution epilogue -> the partial-sum array the finalize kernels read: the slots themselves
+// (<= 512 per group), else their pre-reduction into <= 128 per group inside `scratch` (G * 128 * 2 * C floats).
+inline const float* stat_partials(const float* stat_part, int T, int G, int C, float* scratch, int* nblk, hipStream_t st) {
+  if (T <= 512) {
+    *nblk = T;
+    return stat_part;
+  }
+  int R = 1;
+  while ((T + R - 1) / R > 128) R *= 2;
+  const int To = (T + R - 1) / R;
+  const long long total = (long long)G * To * 2 * C;
+  stats_prereduce<<<wm_cdiv(total, BN_THREADS), BN_THREADS, 0, st>>>(stat_part, T, R, To, G * 2 * C, 2 * C, scratch);
+  *nblk = To;
+  return scratch;
 }
 
 inline bool chunk_pow2(int C, int* shift) {
@@ -812,19 +831,22 @@ extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, c
                                           const float* beta, float* running_mean, float* running_var,
                                           long long* num_batches_tracked, long long rows, int C, int G, float eps,
                                           float momentum, int relu,
-                                          float* save_mean, float* save_invstd, void* out, void* stat_part,
-                                          int stat_buckets, void* workspace, size_t workspace_bytes,
+                                          float* save_mean, float* save_invstd, void* out, const float* stat_part,
+                                          int stat_tiles, void* workspace, size_t workspace_bytes,
                                           void* stream) {
   WM_REQUIRE(y && out && save_mean && save_invstd && workspace && stat_part, WM_EINVAL);
-  WM_REQUIRE(stat_buckets > 0, WM_EINVAL);
+  WM_REQUIRE(stat_tiles > 0, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
   if (rc != WM_OK) return rc;
-  WM_REQUIRE(workspace_bytes >= (size_t)2 * G * C * sizeof(float), WM_EWORKSPACE);
+  WM_REQUIRE(workspace_bytes >= ((size_t)2 * G * C + (stat_tiles > 512 ? (size_t)G * 128 * 2 * C : 0)) * sizeof(float), WM_EWORKSPACE);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rpg = (int)(rows / G);
   float* scale = static_cast<float*>(workspace);
   float* shift = scale + (size_t)G * C;
-  bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(static_cast<float*>(stat_part), stat_buckets, G, C, rpg, 1, gamma, beta, eps, momentum,
+  int nblk = 0;
+  const float* part = stat_partials(stat_part, stat_tiles, G, C, shift + (size_t)G * C, &nblk, st);
+  WM_LAUNCH_CHECK();
+  bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(const_cast<float*>(part), nblk, G, C, rpg, 0, gamma, beta, eps, momentum,
                                                    running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   WM_LAUNCH_CHECK();
   launch_bn_apply(y, residual, scale, shift, rows, C, rpg, relu, out, st);
@@ -837,16 +859,20 @@ extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, c
 // stat_part non-NULL: statistics were fused into the producing convolution; else they are computed here.
 extern "C" int wm_bn_train_stats(const void* y, const float* gamma, const float* beta, float* running_mean,
                                  float* running_var, long long* num_batches_tracked, long long rows, int C, int G, float eps, float momentum,
-                                 float* save_mean, float* save_invstd, float* scale, float* shift, void* stat_part,
-                                 int stat_buckets, void* workspace, size_t workspace_bytes, void* stream) {
+                                 float* save_mean, float* save_invstd, float* scale, float* shift, const float* stat_part,
+                                 int stat_tiles, void* workspace, size_t workspace_bytes, void* stream) {
   WM_REQUIRE(y && save_mean && save_invstd && scale && shift && workspace, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
   if (rc != WM_OK) return rc;
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rpg = (int)(rows / G);
   if (stat_part) {
-    WM_REQUIRE(stat_buckets > 0, WM_EINVAL);
-    bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(static_cast<float*>(stat_part), stat_buckets, G, C, rpg, 1, gamma, beta, eps, momentum,
+    WM_REQUIRE(stat_tiles > 0, WM_EINVAL);
+    WM_REQUIRE(stat_tiles <= 512 || workspace_bytes >= (size_t)G * 128 * 2 * C * sizeof(float), WM_EWORKSPACE);
+    int nblk = 0;
+    const float* part = stat_partials(stat_part, stat_tiles, G, C, static_cast<float*>(workspace), &nblk, st);
+    WM_LAUNCH_CHECK();
+    bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(const_cast<float*>(part), nblk, G, C, rpg, 0, gamma, beta, eps, momentum,
                                                      running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   } else {
     WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
@@ -923,17 +949,20 @@ extern "C" int wm_bn_train_bwd(const void* y, const void* dout, const void* out_
 extern "C" int wm_bn_train_bwd_from_stats(const void* y, const void* g, const float* gamma, const float* beta,
                                           const float* save_mean, const float* save_invstd, long long rows, int C,
                                           int G, float* dgamma, float* dbeta, int accumulate, void* dy,
-                                          void* stat_part, int stat_buckets, void* workspace,
+                                          const float* stat_part, int stat_tiles, void* workspace,
                                           size_t workspace_bytes, void* stream) {
-  WM_REQUIRE(y && g && save_mean && save_invstd && dy && stat_part && workspace && stat_buckets > 0, WM_EINVAL);
+  WM_REQUIRE(y && g && save_mean && save_invstd && dy && stat_part && workspace && stat_tiles > 0, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
   if (rc != WM_OK) return rc;
   WM_REQUIRE(!bn_wide(rows, C, G), WM_EUNSUPPORTED);
-  WM_REQUIRE(workspace_bytes >= (size_t)7 * G * C * sizeof(float), WM_EWORKSPACE);
+  WM_REQUIRE(workspace_bytes >= ((size_t)7 * G * C + (stat_tiles > 512 ? (size_t)G * 128 * 2 * C : 0)) * sizeof(float), WM_EWORKSPACE);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rpg = (int)(rows / G);
   float* coef = static_cast<float*>(workspace);
-  bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(static_cast<float*>(stat_part), stat_buckets, G, C, rpg, gamma, beta,
+  int nblk = 0;
+  const float* part = stat_partials(stat_part, stat_tiles, G, C, coef + (size_t)7 * G * C, &nblk, st);
+  WM_LAUNCH_CHECK();
+  bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(const_cast<float*>(part), nblk, G, C, rpg, gamma, beta,
                                                    save_mean, save_invstd, dgamma, dbeta, accumulate, coef, 1);
   WM_LAUNCH_CHECK();
   const int tpr = C >> 3;

@@ -93,6 +93,28 @@ __device__ __forceinline__ float group_max(float v) {
 __device__ __forceinline__ float wave_sum(float v) { return group_sum<64>(v); }
 __device__ __forceinline__ float wave_max(float v) { return group_max<64>(v); }
 
+// s_barrier that the COMPILER may not move memory operations across.  The intrinsic alone is IntrNoMem: in the k-loops
+// (`s_waitcnt vmcnt(N)` asm; barrier; issue next stage asm; fragment reads) the issue asm pins the reads below the
+// barrier, but in the steps that issue nothing (the last k-step; taps 7 and 8 of conv3x3_patch, which is fully unrolled)
+// hipcc hoisted the fragment reads of the step ABOVE the barrier -- a wave then read weight rows other waves' DMA had
+// not landed yet.  Found in round 3 as run-to-run differences in ~0.02 % of the outputs of the 64-channel layers at
+// batch 512 (tools/probes/conv_determinism.py: 18-24 k of 103 M elements per launch; none at batch 64, where the
+// loads land sooner).
+//
+// And it retires the wave's LDS reads first (`s_waitcnt lgkmcnt(0)`): the DMA ring kernels restage a buffer right
+// behind the barrier that follows its last use, and hipcc software-pipelines the loop -- the last fragment reads of a
+// step are ISSUED before that barrier and consumed after it.  A read still queued in a busy LDS (three workgroups of
+// conv3x3_patch per CU) could then be overtaken by another wave's DMA into the same stage: one wave of one workgroup
+// multiplied a whole tile with the NEXT slice's weight rows -- 8 or 16 output channels x 64 pixels grossly wrong, in
+// 1 of ~10^3 .. 10^5 workgroups, only once the launch's traffic had filled L2 (tools/probes/conv_determinism*.py;
+// cdna_hip_programming.md: "restage a buffer ... 1 phase after when an lgkmcnt before the reading phase's first barrier
+// retired those reads").
+__device__ __forceinline__ void wm_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
+
 // LDS byte address of a __shared__ pointer (what M0 / ds instructions take).
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)p;
@@ -166,25 +188,14 @@ __device__ __forceinline__ float wm_gelu_grad(float v) {
 }
 
 
-// ---- order-independent (bit-reproducible) accumulation of f32 partial sums across workgroups.
+// ---- bit-reproducible reductions across workgroups: NO floating-point atomics anywhere on the training path.
 // f32 atomics add in arrival order, so two runs of one launch differ in the last bits and bf16 roundings downstream
-// flip: BatchNorm statistics were one of the two sources of the 4-10 % run-to-run gradient noise of round 2 (the other:
-// split-K weight gradients).  Here a partial sum p is added as the 64-bit INTEGER rint(p * 2^shift) (integer addition is
-// associative): the bucket holds the exact sum of the partials rounded to multiples of 2^-shift, whatever the order.
-//   WM_FX_FWD = 24: activations -- |bucket sum| < 2^39 = 5.5e11, resolution 6e-8 (an f32 partial of magnitude >= 1
-//                   carries no finer bits);
-//   WM_FX_BWD = 44: gradients   -- |bucket sum| < 2^19 = 5.2e5, resolution 5.7e-14 (a tile's gradient sum of 1e-6
-//                   keeps full f32 precision; one of 1e-9 keeps 4 digits).
-// (A first build split p exactly into two integers, hi = rint(p 2^8) and lo = the rest * 2^48: scale-free, but twice
-// the atomic instructions -- the 64-channel patch kernels ran 16 % slower, atomics being ~50 ns per wave-instruction
-// and CU.)
-#define WM_FX_FWD 24
-#define WM_FX_BWD 44
-__device__ __forceinline__ void wm_fx_add(unsigned long long* slot, float p, int shift) {
-  const long long v = (long long)rintf(ldexpf(p, shift));
-  atomicAdd(slot, (unsigned long long)v);
-}
-__device__ __forceinline__ double wm_fx_value(long long v, int shift) { return ldexp((double)v, -shift); }
+// flip (round 2: 4-10 % run-to-run gradient noise from the BatchNorm statistics and the split-K weight gradients).
+// Every cross-workgroup sum is now "partials as plain stores into per-workgroup slots, summed later in slot order":
+// the convolution epilogues store a tile's per-channel sums into the tile's slot, the weight-gradient kernels store
+// split z's partial sums into slab z, and the BatchNorm finalize / weight-gradient fold kernels add slots in a fixed
+// order.  (Two fixed-point integer-atomic forms were built first -- exact, but 64-bit atomics into a few hundred
+// addresses cost the 64-channel layers 50 - 75 us per launch: profiles/r03_experiments.md.)
 
 static inline int wm_cdiv(long long a, long long b) { return (int)((a + b - 1) / b); }
 

@@ -51,8 +51,8 @@ struct ConvArgs {
   int N, SH, SW, SC, DH, DW, DC, R, S, stride, pad, M, nkt;
   // optional fused BatchNorm statistics (forward only): per-channel (sum, sum of squares) of the
   // bf16-rounded outputs, added into bucket (tile % stat_nb) of the tile's row group
-  unsigned long long* stat;  // [G][stat_nb][2][DC] int64 fixed point (wm_fx_add: order-independent sums), or NULL
-  int stat_nb, stat_rpg;
+  float* stat;          // [G][stat_nb][2][DC] f32: tile t of group g STORES its sums into slot (g, t) -- no atomics; or NULL
+  int stat_nb, stat_rpg;  // stat_nb = slots (tiles) per group
   // optional BatchNorm-BACKWARD epilogue (dgrad only, template flag BNB): this convolution's input was
   // relu(BN(bn_y) (+ shortcut)), so the gradient this kernel produces is the one entering that ReLU.  The epilogue
   // applies the ReLU mask (bn_x > 0 when the convolution's forward input bn_x is given, else recomputed from bn_y as
@@ -87,32 +87,72 @@ __device__ __forceinline__ float cv_gelu_grad(float v) { return wm_gelu_grad(v);
 __device__ __attribute__((aligned(256))) uint16_t conv_zero_page[128];
 
 
-// (sum, sum of squares) per channel of a staged bf16 tile [128 rows][CS bytes], BNC channels, added to the tile's
-// statistics slot.  `red` = LDS scratch of 2 * (256 / BNC) * BNC floats outside the tile.  The row slices are combined
-// in a fixed order and the block's sums go out through wm_fx_add: bit-reproducible.
+// Per-channel sums over the block of two per-thread running sums: a thread holds s1[8], s2[8] for the 8 channels of chunk
+// column tid % (BNC / 8), accumulated over its rows of the tile.  Lanes of a wave that share the column are summed on the
+// DPP network / lane swaps (row_ror:8, then the 16- and 32-lane swaps), the four waves through 2 x 4 x BNC floats of
+// LDS (`red`, outside the staged tile), and threads 0 .. 2 BNC - 1 store the block's sums into the tile's slot -- plain
+// stores, fixed order: bit-reproducible.  (First build: a separate pass of 32 two-byte LDS reads per thread and a
+// [2][32][BNC] LDS reduction -- 50-80 us per layer1 launch.)
+template <int CPR>
+__device__ __forceinline__ float strided_lane_sum(float v) {
+  static_assert(CPR == 8 || CPR == 16, "chunk columns per row");
+  if constexpr (CPR == 8) v += wm_dpp<0x128>(v);  // row_ror:8: lane i + lane i ^ 8
+  v = wm_xor16_sum(v);
+  v = wm_xor32_sum(v);
+  return v;
+}
 template <int BNC>
-__device__ __forceinline__ void tile_stats_fwd(const uint8_t* tile, int CS, int valid_rows, float* red,
-                                               unsigned long long* slot, int DC, int c_base, int tid) {
-  constexpr int TPC = CV_THREADS / BNC;
-  const int c = tid % BNC, part = tid / BNC;
-  float sm = 0.f, sq = 0.f;
-  for (int rr = part * (128 / TPC); rr < (part + 1) * (128 / TPC); ++rr) {
-    if (rr < valid_rows) {
-      const float v = bf2f(*reinterpret_cast<const uint16_t*>(tile + rr * CS + c * 2));
-      sm += v;
-      sq = fmaf(v, v, sq);
+__device__ __forceinline__ void block_colsums_store(float (&s1)[8], float (&s2)[8], float* red, float* slot, int DC,
+                                                    int c_base, int tid) {
+  constexpr int CPR = BNC / 8;
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    s1[e] = strided_lane_sum<CPR>(s1[e]);
+    s2[e] = strided_lane_sum<CPR>(s2[e]);
+  }
+  if (lane < CPR) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      red[wave * BNC + lane * 8 + e] = s1[e];
+      red[(4 + wave) * BNC + lane * 8 + e] = s2[e];
     }
   }
-  red[part * BNC + c] = sm;
-  red[(TPC + part) * BNC + c] = sq;
   __syncthreads();
   if (tid < 2 * BNC) {
     const int which = tid / BNC, cc = tid % BNC;
-    float t = 0.f;
-#pragma unroll
-    for (int q = 0; q < TPC; ++q) t += red[(which * TPC + q) * BNC + cc];
-    wm_fx_add(slot + (size_t)which * DC + c_base + cc, t, WM_FX_FWD);
+    const float* r = red + (size_t)which * 4 * BNC + cc;
+    slot[(size_t)which * DC + c_base + cc] = ((r[0] + r[BNC]) + r[2 * BNC]) + r[3 * BNC];
   }
+}
+
+// Store a FULL staged bf16 tile [128 rows][CS bytes] (BNC channels, row -> pixel by pix_of) and leave its per-channel
+// (sum, sum of squares) in the tile's statistics slot: the sums ride on the store loop's own LDS reads.
+template <int BNC, typename PixOf>
+__device__ __forceinline__ void store_tile_with_stats(const uint8_t* smem, int CS, uint16_t* dst, int DC, int n0, float* red,
+                                                      float* slot, int tid, PixOf pix_of) {
+  constexpr int CPR = BNC / 8;
+  constexpr int NIT = 128 * CPR / CV_THREADS;
+  const int chl = tid % CPR;
+  float s1[8], s2[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) s1[e] = s2[e] = 0.f;
+#pragma unroll
+  for (int it = 0; it < NIT; ++it) {
+    const int row = (tid + it * CV_THREADS) / CPR;
+    const uint4 v = *reinterpret_cast<const uint4*>(smem + row * CS + chl * 16);
+    const uint32_t vv[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const float lo = __builtin_bit_cast(float, vv[q] << 16), hi = __builtin_bit_cast(float, vv[q] & 0xffff0000u);
+      s1[2 * q] += lo;
+      s2[2 * q] = fmaf(lo, lo, s2[2 * q]);
+      s1[2 * q + 1] += hi;
+      s2[2 * q + 1] = fmaf(hi, hi, s2[2 * q + 1]);
+    }
+    *reinterpret_cast<uint4*>(dst + pix_of(row) * DC + n0 + chl * 8) = v;
+  }
+  block_colsums_store<BNC>(s1, s2, red, slot, DC, n0, tid);
 }
 
 // BatchNorm-backward epilogue of a dgrad tile (ConvArgs: bn_*), in two parts.
@@ -135,14 +175,13 @@ __device__ __forceinline__ void bnb_load16(u32x4_t& dst, const void* p) {
   dst = *reinterpret_cast<const u32x4_t*>(p);
 }
 template <int BNC, typename PixOf>
-__device__ __forceinline__ void bnb_prefetch(const ConvArgs& a, BnbRegs<BNC>& R, int valid_rows, int n0, int tid,
-                                             PixOf pix_of) {
+__device__ __forceinline__ void bnb_prefetch(const ConvArgs& a, BnbRegs<BNC>& R, int n0, int tid, PixOf pix_of) {
   constexpr int CPR = BNC / 8;
   const int c0 = n0 + (tid % CPR) * 8;
 #pragma unroll
   for (int it = 0; it < BnbRegs<BNC>::NIT; ++it) {
     const int row = (tid + it * CV_THREADS) / CPR;
-    const size_t pix = pix_of(row < valid_rows ? row : 0);  // (rows past the end: a valid address, value unused)
+    const size_t pix = pix_of(row);  // (tiles are full: the host admits only shapes whose 128-row tiles tile a group)
     R.pixs[it] = pix;
     bnb_load16(R.yv[it], a.bn_y + pix * a.DC + c0);
     if (a.res != nullptr) bnb_load16(R.rv[it], a.res + pix * a.DC + c0);
@@ -151,14 +190,13 @@ __device__ __forceinline__ void bnb_prefetch(const ConvArgs& a, BnbRegs<BNC>& R,
 }
 
 // bnb_epilogue: staged bf16 tile [128 rows][CS bytes] of BNC channels -> (+ residual) -> ReLU mask -> store, and the
-// tile's (sum g, sum g * bn_y) into its statistics slot.  Rows >= valid_rows are skipped.
+// tile's (sum g, sum g * bn_y) into its statistics slot.  `red`: 2 x 4 x BNC floats of LDS outside the tile.
 template <int BNC>
-__device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, const BnbRegs<BNC>& R, uint8_t* smem, int CS,
-                                             int valid_rows, int g, int n0, int bucket, int tid) {
+__device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, const BnbRegs<BNC>& R, const uint8_t* smem, int CS, float* red,
+                                             int g, int n0, int tile, int tid) {
   constexpr int CPR = BNC / 8;
   constexpr int NIT = BnbRegs<BNC>::NIT;
-  constexpr int RG = CV_THREADS / CPR;  // threads that share a chunk column
-  const int chl = tid % CPR, rg = tid / CPR;
+  const int chl = tid % CPR;
   const int c0 = n0 + chl * 8;
   // ReLU mask recomputed from the BatchNorm input (no shortcut): bn_y * scale + shift > 0 with the forward's scale and
   // shift.  (The forward rounds to bf16 before its ReLU; that rounding changes the sign test only for |value| < 2^-133.)
@@ -184,50 +222,34 @@ __device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, const BnbRegs<BN
 #pragma unroll
   for (int it = 0; it < NIT; ++it) {
     const int row = (tid + it * CV_THREADS) / CPR;
-    if (row < valid_rows) {
-      const uint4 v4 = *reinterpret_cast<const uint4*>(smem + row * CS + chl * 16);
-      const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
-      const uint32_t rr[4] = {R.rv[it][0], R.rv[it][1], R.rv[it][2], R.rv[it][3]};
-      const uint32_t yy[4] = {R.yv[it][0], R.yv[it][1], R.yv[it][2], R.yv[it][3]};
-      const uint32_t xx[4] = {R.xv[it][0], R.xv[it][1], R.xv[it][2], R.xv[it][3]};
-      uint32_t o[4];
+    const uint4 v4 = *reinterpret_cast<const uint4*>(smem + row * CS + chl * 16);
+    const uint32_t vv[4] = {v4.x, v4.y, v4.z, v4.w};
+    const uint32_t rr[4] = {R.rv[it][0], R.rv[it][1], R.rv[it][2], R.rv[it][3]};
+    const uint32_t yy[4] = {R.yv[it][0], R.yv[it][1], R.yv[it][2], R.yv[it][3]};
+    const uint32_t xx[4] = {R.xv[it][0], R.xv[it][1], R.xv[it][2], R.xv[it][3]};
+    uint32_t o[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        float gv[2];
+    for (int q = 0; q < 4; ++q) {
+      float gv[2];
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          const int e = q * 2 + h;
-          float v = __builtin_bit_cast(float, h ? (vv[q] & 0xffff0000u) : (vv[q] << 16));
-          if (a.res != nullptr) v += __builtin_bit_cast(float, h ? (rr[q] & 0xffff0000u) : (rr[q] << 16));
-          const float y = __builtin_bit_cast(float, h ? (yy[q] & 0xffff0000u) : (yy[q] << 16));
-          // (x is a bf16 pattern: > 0 <=> the 16-bit pattern is a positive non-zero number)
-          const bool keep = remask ? fmaf(y, sc[e], sh[e]) > 0.f
-                                   : __builtin_bit_cast(float, h ? (xx[q] & 0xffff0000u) : (xx[q] << 16)) > 0.f;
-          v = keep ? v : 0.f;
-          s1[e] += v;
-          s2[e] = fmaf(v, y, s2[e]);
-          gv[h] = v;
-        }
-        o[q] = pack_bf2(gv[0], gv[1]);
+      for (int h = 0; h < 2; ++h) {
+        const int e = q * 2 + h;
+        float v = __builtin_bit_cast(float, h ? (vv[q] & 0xffff0000u) : (vv[q] << 16));
+        if (a.res != nullptr) v += __builtin_bit_cast(float, h ? (rr[q] & 0xffff0000u) : (rr[q] << 16));
+        const float y = __builtin_bit_cast(float, h ? (yy[q] & 0xffff0000u) : (yy[q] << 16));
+        // (x is a bf16 pattern: > 0 <=> the 16-bit pattern is a positive non-zero number)
+        const bool keep = remask ? fmaf(y, sc[e], sh[e]) > 0.f
+                                 : __builtin_bit_cast(float, h ? (xx[q] & 0xffff0000u) : (xx[q] << 16)) > 0.f;
+        v = keep ? v : 0.f;
+        s1[e] += v;
+        s2[e] = fmaf(v, y, s2[e]);
+        gv[h] = v;
       }
-      *reinterpret_cast<uint4*>(a.dst + R.pixs[it] * a.DC + c0) = make_uint4(o[0], o[1], o[2], o[3]);
+      o[q] = pack_bf2(gv[0], gv[1]);
     }
+    *reinterpret_cast<uint4*>(a.dst + R.pixs[it] * a.DC + c0) = make_uint4(o[0], o[1], o[2], o[3]);
   }
-  __syncthreads();  // every read of the staged tile is over: its LDS carries the cross-thread sums now
-  float* red = reinterpret_cast<float*>(smem);  // [2][RG][BNC]
-#pragma unroll
-  for (int e = 0; e < 8; ++e) {
-    red[rg * BNC + chl * 8 + e] = s1[e];
-    red[(RG + rg) * BNC + chl * 8 + e] = s2[e];
-  }
-  __syncthreads();
-  if (tid < 2 * BNC) {
-    const int which = tid / BNC, cc = tid % BNC;
-    float t = 0.f;
-    for (int q = 0; q < RG; ++q) t += red[(which * RG + q) * BNC + cc];
-    unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + bucket) * 2) * a.DC;
-    wm_fx_add(slot + (size_t)which * a.DC + n0 + cc, t, WM_FX_BWD);
-  }
+  block_colsums_store<BNC>(s1, s2, red, a.stat + ((size_t)(g * a.stat_nb + tile) * 2) * a.DC, a.DC, n0, tid);
 }
 
 // Both operand tiles go HBM -> LDS by global_load_lds (16 B per lane, 1 KiB per wave instruction,
@@ -430,7 +452,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
 
   BnbRegs<BNB ? BN : 64> bnb;  // (unused and eliminated unless BNB)
   if constexpr (BNB) {
-    bnb_prefetch<BN>(a, bnb, a.M - m0, n0, tid, [&](int row) -> size_t {
+    bnb_prefetch<BN>(a, bnb, n0, tid, [&](int row) -> size_t {
       if constexpr (MODE == 2) {  // class-ordered row -> pixel (n, 2 h2 + ph, 2 w2 + pw)
         const int cls = a.M >> 2;
         const int pc = m0 / cls;
@@ -447,8 +469,10 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   if (nkt > 0) issue(0, smem_base);
   for (int kt = 0; kt < nkt; ++kt) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of tile kt have landed
-    __builtin_amdgcn_s_barrier();                     // ... everyone's; and compute(kt-1) is over
+    wm_barrier();                     // ... everyone's; and compute(kt-1) is over
     if (kt + 1 < nkt && !(WM_CONV_ABLATE & 1)) issue(kt + 1, smem_base + ((kt + 1) & 1) * STAGE);
+    else wm_barrier();  // nothing to issue: keep a phase between the wait that retired this tile and its fragment reads
+                        // (LDS-DMA data becomes readable a little after vmcnt retires it: see conv3x3_patch)
     if (!(WM_CONV_ABLATE & 2)) compute(cv_smem + (kt & 1) * STAGE);
   }
   __syncthreads();
@@ -465,23 +489,29 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
       *reinterpret_cast<uint2*>(cv_smem + pix * CS + ch * 2) = v;
     }
   __syncthreads();
-  if constexpr (MODE == 0) {
+  if constexpr (MODE == 0 && !EPI) {
     if (a.stat != nullptr) {
-      // column sums of the staged tile; rows_per_group % BM == 0, so the whole tile belongs to one statistics group
+      // rows_per_group % BM == 0: the tile is full and lies inside one statistics group; its column sums ride on the
+      // store loop
       const int g = m0 / a.stat_rpg;
-      unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 2) * a.DC;
-      tile_stats_fwd<BN>(cv_smem, CS, a.M - m0, reinterpret_cast<float*>(cv_smem + BM * CS), slot, a.DC, n0, tid);
+      float* slot = a.stat + ((size_t)(g * a.stat_nb + (m0 - g * a.stat_rpg) / BM) * 2) * a.DC;
+      store_tile_with_stats<BN>(cv_smem, CS, a.dst, a.DC, n0, reinterpret_cast<float*>(cv_smem + BM * CS), slot, tid,
+                                [&](int row) -> size_t { return (size_t)(m0 + row); });
+      return;
     }
   }
   if constexpr (BNB) {
-    int g;
+    int g, tile;  // statistics group of this tile and its slot inside the group
     if constexpr (MODE == 2) {
       const int cls = a.M >> 2;
-      g = (m0 % cls) / a.stat_rpg;  // stat_rpg: rows of one statistics group inside a parity class
+      const int pc = m0 / cls, in_cls = m0 - pc * cls;
+      g = in_cls / a.stat_rpg;  // stat_rpg: rows of one statistics group inside a parity class
+      tile = pc * (a.stat_rpg / BM) + (in_cls - g * a.stat_rpg) / BM;
     } else {
       g = m0 / a.stat_rpg;
+      tile = (m0 - g * a.stat_rpg) / BM;
     }
-    bnb_epilogue<BN>(a, bnb, cv_smem, CS, a.M - m0, g, n0, (int)(blockIdx.x % a.stat_nb), tid);
+    bnb_epilogue<BN>(a, bnb, cv_smem, CS, reinterpret_cast<float*>(cv_smem + BM * CS), g, n0, tile, tid);
     return;
   }
   if constexpr (EPI) {
@@ -626,6 +656,7 @@ constexpr int PT_SLOTS = 224;                // 2 patches = 220 slots, rounded u
 constexpr int PT_PATCH_BYTES = PT_SLOTS * CV_ROW;
 constexpr int PT_W_BYTES = 64 * CV_ROW;      // one tap's weights: 64 rows x 64 source channels
 constexpr int PT_WSTAGES = 3;                 // weight ring: two taps in flight ahead of the one being multiplied
+
 constexpr int PT_LDS = PT_PATCH_BYTES + PT_WSTAGES * PT_W_BYTES;
 
 template <int MODE, bool BNB = false>
@@ -672,7 +703,7 @@ __global__ __launch_bounds__(CV_THREADS, BNB ? 3 : 1) void conv3x3_patch(const C
   BnbRegs<64> bnb;  // (unused and eliminated unless BNB)
   if constexpr (BNB) {
     const size_t porg[2] = {((size_t)tn[0] * a.DH + th0[0]) * a.DW + tw0[0], ((size_t)tn[1] * a.DH + th0[1]) * a.DW + tw0[1]};
-    bnb_prefetch<64>(a, bnb, 128, 0, tid, [&](int row) -> size_t {
+    bnb_prefetch<64>(a, bnb, 0, tid, [&](int row) -> size_t {
       return porg[row >> 6] + (size_t)((row >> 3) & 7) * a.DW + (row & 7);
     });
   }
@@ -714,10 +745,13 @@ __global__ __launch_bounds__(CV_THREADS, BNB ? 3 : 1) void conv3x3_patch(const C
       woff[j][ks] = (uint32_t)(PT_PATCH_BYTES + row * CV_ROW + (((ks * 4 + fg) ^ (row & 7)) << 4));
     }
 
+  // Ring discipline (see wm_barrier in common.h for the race this kernel exposed): RAW -- a wave waits for ITS pieces of
+  // tap `tap` with a counted vmcnt (the two instructions of tap + 1 may stay in flight; vector-memory operations
+  // retire in issue order: tools/probes/ldsdma_order_probe.hip) and the barrier makes that everyone's; WAR -- the
+  // barrier's lgkmcnt(0) retires every wave's fragment reads of the previous tap before any wave restages that tap's
+  // ring slot.
 #pragma unroll
   for (int tap = 0; tap < 9; ++tap) {
-    // this wave's DMA pieces of tap `tap` (and, at tap 0, of the patches) have landed; the two
-    // instructions of tap + 1 may still be in flight
     constexpr int AHEAD = PT_WSTAGES - 1;  // taps in flight ahead (incl. the one waited for)
     if (tap + AHEAD - 1 < 9) {
       if (AHEAD == 3) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -727,7 +761,7 @@ __global__ __launch_bounds__(CV_THREADS, BNB ? 3 : 1) void conv3x3_patch(const C
     } else {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
-    __builtin_amdgcn_s_barrier();                     // ... everyone's; and the previous tap's reads are over
+    wm_barrier();                                     // ... everyone's; and the previous tap's reads are over
     if (tap + AHEAD < 9) issue_w(tap + AHEAD, smem_base + PT_PATCH_BYTES + ((tap + AHEAD) % PT_WSTAGES) * PT_W_BYTES);
     const int r = tap / 3, sx = tap % 3;
     const int prow = DGRAD ? 2 - r : r;      // patch row shift
@@ -763,20 +797,22 @@ __global__ __launch_bounds__(CV_THREADS, BNB ? 3 : 1) void conv3x3_patch(const C
       *reinterpret_cast<uint2*>(cv_smem + pix * CS + ch * 2) = v;
     }
   __syncthreads();
-  if constexpr (MODE == 0) {
-    if (a.stat != nullptr) {
-      // column sums of the staged tile; both 8x8 tiles lie in one statistics group (host-checked: an even number of
-      // tiles per group)
-      const int g = (int)(((long long)tn[0] * a.DH * a.DW) / a.stat_rpg);
-      unsigned long long* slot = a.stat + ((size_t)(g * a.stat_nb + (int)(blockIdx.x % a.stat_nb)) * 2) * 64;
-      tile_stats_fwd<64>(cv_smem, CS, 128, reinterpret_cast<float*>(cv_smem + 128 * CS), slot, 64, 0, tid);
-    }
-  }
   const size_t org[2] = {((size_t)tn[0] * a.DH + th0[0]) * a.DW + tw0[0], ((size_t)tn[1] * a.DH + th0[1]) * a.DW + tw0[1]};
   if constexpr (BNB) {
     const int g = (int)(((long long)tn[0] * a.DH * a.DW) / a.stat_rpg);
-    bnb_epilogue<64>(a, bnb, cv_smem, CS, 128, g, 0, (int)(blockIdx.x % a.stat_nb), tid);
+    bnb_epilogue<64>(a, bnb, cv_smem, CS, reinterpret_cast<float*>(cv_smem + 128 * CS), g, 0,
+                     (int)blockIdx.x - g * (a.stat_rpg >> 7), tid);
     return;
+  }
+  if constexpr (MODE == 0) {
+    if (a.stat != nullptr) {
+      // both 8x8 tiles lie in one statistics group (host-checked: an even number of tiles per group)
+      const int g = (int)(((long long)tn[0] * a.DH * a.DW) / a.stat_rpg);
+      float* slot = a.stat + ((size_t)(g * a.stat_nb + ((int)blockIdx.x - g * (a.stat_rpg >> 7))) * 2) * 64;
+      store_tile_with_stats<64>(cv_smem, CS, a.dst, 64, 0, reinterpret_cast<float*>(cv_smem + 128 * CS), slot, tid,
+                                [&](int row) -> size_t { return org[row >> 6] + (size_t)((row >> 3) & 7) * a.DW + (row & 7); });
+      return;
+    }
   }
 #pragma unroll
   for (int q = 0; q < 128 * 8 / CV_THREADS; ++q) {
@@ -903,7 +939,7 @@ __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs 
     // AFTER these patch fetches (waiting for them too cost 0.5 us per pair and block).
     if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // (a statistics flush's atomics precede the stores: covered)
-    __builtin_amdgcn_s_barrier();
+    wm_barrier();
     if (pair + (int)gridDim.x < npairs) issue_patch(pair + gridDim.x, smem_base + ((it + 1) & 1) * ST_PATCH_BYTES);
     const uint8_t* pb = cv_smem + (it & 1) * ST_PATCH_BYTES;
 
@@ -971,8 +1007,7 @@ __global__ __launch_bounds__(CV_THREADS, 3) void conv_stem_patch(const ConvArgs 
       const int which = tid >> 6, c = tid & 63;
       const float t = st_red[(which * 4) * 64 + c] + st_red[(which * 4 + 1) * 64 + c] + st_red[(which * 4 + 2) * 64 + c] +
                       st_red[(which * 4 + 3) * 64 + c];
-      unsigned long long* slot = a.stat + ((size_t)((int)(blockIdx.x % a.stat_nb)) * 2) * 64;  // (group 0 of this launch)
-      wm_fx_add(slot + (size_t)which * 64 + c, t, WM_FX_FWD);
+      a.stat[((size_t)blockIdx.x * 2 + which) * 64 + c] = t;  // slot = this block (group 0 of this launch)
     }
   }
 }
@@ -1178,8 +1213,9 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   issue(0, smem_base);
   for (int it = 0; it < iters; ++it) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    wm_barrier();
     if (it + 1 < iters && !(WM_CONV_ABLATE & 1)) issue(it + 1, smem_base + ((it + 1) & 1) * STAGE);
+    else wm_barrier();  // (as in conv_igemm: a phase between the retiring wait and the reads when nothing is issued)
     if (!(WM_CONV_ABLATE & 2)) compute(wg_smem + (it & 1) * STAGE);
   }
 
@@ -1280,7 +1316,13 @@ int launch_patch(const ConvArgs& a, hipStream_t st) {
     attr = true;
   }
   const int blocks = (int)((long long)a.N * (a.DH >> 3) * (a.DW >> 3) / 2);
-  conv3x3_patch<MODE, BNB><<<blocks, CV_THREADS, PT_LDS, st>>>(a);
+  static int lds_pad = -1;  // WM_PATCH_LDS_PAD: extra dynamic LDS per block (experiment: 12288 -> two blocks per CU)
+  if (lds_pad < 0) {
+    const char* e = getenv("WM_PATCH_LDS_PAD");
+    lds_pad = e ? atoi(e) : 0;
+    if (lds_pad > 0 && set_lds(&conv3x3_patch<MODE, BNB>, PT_LDS + lds_pad) != WM_OK) lds_pad = 0;
+  }
+  conv3x3_patch<MODE, BNB><<<blocks, CV_THREADS, PT_LDS + lds_pad, st>>>(a);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -1387,7 +1429,7 @@ static int conv_check(int N, int H, int W, int C, int K, int R, int S, int P, in
 }
 
 static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int R,
-                         int S, int P, int Q, int stride, int pad, unsigned long long* stat, int stat_nb, int stat_rpg,
+                         int S, int P, int Q, int stride, int pad, float* stat, int stat_nb, int stat_rpg,
                          void* stream, const float* bias = nullptr, const void* residual = nullptr,
                          void* pre_out = nullptr);
 
@@ -1403,18 +1445,52 @@ extern "C" int wm_conv2d_fwd_bias_res(const void* x, const void* w_krsc, const f
   return conv_fwd_impl(x, w_krsc, y, N, H, W, C, K, R, S, P, Q, stride, pad, nullptr, 0, 0, stream, bias, residual);
 }
 
+// Statistics slots per group a forward-with-statistics launch of this geometry writes: one per 128-row tile, except
+// the persistent stem kernel, whose blocks accumulate over their tiles and write one slot each.
+static int stem_patch_slots();
+extern "C" int wm_conv2d_fwd_stats_tiles(int N, int H, int W, int C, int K, int R, int S, int P, int Q, int stride,
+                                         int pad, int rows_per_group) {
+  if (conv_check(N, H, W, C, K, R, S, P, Q, stride, pad) != WM_OK || rows_per_group <= 0) return WM_EINVAL;
+  const long long M = (long long)N * P * Q;
+  if (rows_per_group % 128 != 0 || M % rows_per_group != 0) return WM_EUNSUPPORTED;
+  if (C == 16) {
+    ConvArgs a{};
+    a.N = N; a.SH = H; a.SW = W; a.SC = C; a.DH = P; a.DW = Q; a.DC = K; a.R = R; a.S = S; a.stride = stride; a.pad = pad;
+    a.M = (int)M; a.stat = reinterpret_cast<float*>(1); a.stat_rpg = rows_per_group; a.bias = nullptr; a.res = nullptr;
+    if (stem_patch_ok(a)) {
+      const int pairs_g = rows_per_group / 128;
+      const int slots = stem_patch_slots();
+      return pairs_g < slots ? pairs_g : slots;
+    }
+  }
+  return rows_per_group / 128;
+}
+
 extern "C" int wm_conv2d_fwd_stats(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C,
-                                   int K, int R, int S, int P, int Q, int stride, int pad, void* stat_part,
-                                   int stat_buckets, int rows_per_group, void* stream) {
-  WM_REQUIRE(stat_part && stat_buckets > 0 && rows_per_group > 0, WM_EINVAL);
+                                   int K, int R, int S, int P, int Q, int stride, int pad, float* stat_part,
+                                   int stat_tiles, int rows_per_group, void* stream) {
+  WM_REQUIRE(stat_part && rows_per_group > 0, WM_EINVAL);
   WM_REQUIRE(rows_per_group % 128 == 0 && ((long long)N * P * Q) % rows_per_group == 0, WM_EUNSUPPORTED);
-  WM_REQUIRE((reinterpret_cast<uintptr_t>(stat_part) & 7) == 0, WM_EALIGN);
-  return conv_fwd_impl(x, w_krsc, y, N, H, W, C, K, R, S, P, Q, stride, pad, static_cast<unsigned long long*>(stat_part),
-                       stat_buckets, rows_per_group, stream);
+  WM_REQUIRE(stat_tiles == wm_conv2d_fwd_stats_tiles(N, H, W, C, K, R, S, P, Q, stride, pad, rows_per_group), WM_EINVAL);
+  return conv_fwd_impl(x, w_krsc, y, N, H, W, C, K, R, S, P, Q, stride, pad, stat_part, stat_tiles, rows_per_group, stream);
+}
+
+// resident blocks of the persistent stem kernel: 38 KB of LDS, 168 registers per lane -> three per CU
+static int stem_patch_slots() {
+  static int slots = 0;
+  if (slots == 0) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+      cus = 256;
+    const char* e = getenv("WM_STEM_BLOCKS_PER_CU");
+    slots = cus * (e ? atoi(e) : 3);
+  }
+  return slots;
 }
 
 static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int H, int W, int C, int K, int R,
-                         int S, int P, int Q, int stride, int pad, unsigned long long* stat, int stat_nb, int stat_rpg,
+                         int S, int P, int Q, int stride, int pad, float* stat, int stat_nb, int stat_rpg,
                          void* stream, const float* bias, const void* residual, void* pre_out) {
   WM_REQUIRE(pre_out == nullptr || (residual == nullptr && R == 1 && S == 1), WM_EUNSUPPORTED);
   WM_REQUIRE(x && w_krsc && y, WM_EINVAL);
@@ -1443,17 +1519,13 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
     a.nkt = R;
     if (stem_patch_ok(a)) {
       const int npairs = (int)((long long)a.N * (a.DH >> 3) * (a.DW >> 3) / 2);
-      static int slots = 0;
-      if (slots == 0) {
+      static bool attr = false;
+      if (!attr) {
         const int rc2 = set_lds(&conv_stem_patch, ST_LDS);
         if (rc2 != WM_OK) return rc2;
-        int dev = 0, cus = 0;
-        if (hipGetDevice(&dev) != hipSuccess ||
-            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
-          cus = 256;
-        const char* e = getenv("WM_STEM_BLOCKS_PER_CU");
-        slots = cus * (e ? atoi(e) : 3);  // 36 KB of LDS, 168 registers per lane: three resident blocks per CU
+        attr = true;
       }
+      const int slots = stem_patch_slots();
       // one launch per statistics group (whole images, an even number of tiles: stem_patch_ok): a block then flushes
       // its running sums once, after its last tile pair
       const int groups = a.stat != nullptr ? a.M / a.stat_rpg : 1;
@@ -1465,7 +1537,7 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
         ag.M = n_g * a.DH * a.DW;
         ag.src = a.src + (size_t)g * n_g * a.SH * a.SW * 16;
         ag.dst = a.dst + (size_t)g * n_g * a.DH * a.DW * 64;
-        if (a.stat != nullptr) ag.stat = a.stat + (size_t)g * a.stat_nb * 2 * 64;
+        if (a.stat != nullptr) ag.stat = a.stat + (size_t)g * a.stat_nb * 2 * 64;  // (stat_nb = blocks of a launch)
         conv_stem_patch<<<pairs_g < slots ? pairs_g : slots, CV_THREADS, ST_LDS, st>>>(
             ag, pairs_g, wm_div_make((uint32_t)((a.DH >> 3) * (a.DW >> 3))), wm_div_make((uint32_t)(a.DW >> 3)));
         WM_LAUNCH_CHECK();
@@ -1488,7 +1560,7 @@ struct BnbArgs {  // BatchNorm-backward epilogue (ConvArgs: bn_*)
   const void* bn_x;
   const float *mean, *invstd, *gamma, *beta;
   int G;
-  unsigned long long* stat;
+  float* stat;
   int stat_nb;
 };
 
@@ -1542,15 +1614,16 @@ extern "C" int wm_conv2d_dgrad_bnstat_ok(int N, int H, int W, int C, int K, int 
 extern "C" int wm_conv2d_dgrad_bnstat(const void* dy, const void* w_crsk, const void* residual, void* dx, int N, int H,
                                       int W, int C, int K, int R, int S, int P, int Q, int stride, int pad,
                                       const void* bn_y, const void* relu_x, const float* gamma, const float* beta,
-                                      const float* save_mean, const float* save_invstd, int G, void* stat_part,
-                                      int stat_buckets, void* stream) {
-  WM_REQUIRE(bn_y && save_mean && save_invstd && stat_part && stat_buckets > 0, WM_EINVAL);
+                                      const float* save_mean, const float* save_invstd, int G, float* stat_part,
+                                      int stat_tiles, void* stream) {
+  WM_REQUIRE(bn_y && save_mean && save_invstd && stat_part, WM_EINVAL);
+  WM_REQUIRE(G > 0 && stat_tiles == (int)((long long)N * H * W / G / 128), WM_EINVAL);  // one slot per 128-row tile
   WM_REQUIRE(relu_x || (gamma && beta), WM_EINVAL);
   WM_REQUIRE(wm_conv2d_dgrad_bnstat_ok(N, H, W, C, K, R, S, P, Q, stride, pad, G), WM_EUNSUPPORTED);
   WM_REQUIRE(aligned16(bn_y) && aligned16(save_mean) && aligned16(save_invstd) && (relu_x == nullptr || aligned16(relu_x)) &&
-                 (residual == nullptr || aligned16(residual)) && (reinterpret_cast<uintptr_t>(stat_part) & 7) == 0,
+                 (residual == nullptr || aligned16(residual)),
              WM_EALIGN);
-  BnbArgs b{bn_y, relu_x, save_mean, save_invstd, gamma, beta, G, static_cast<unsigned long long*>(stat_part), stat_buckets};
+  BnbArgs b{bn_y, relu_x, save_mean, save_invstd, gamma, beta, G, stat_part, stat_tiles};
   return conv_dgrad_impl(dy, w_crsk, dx, residual, N, H, W, C, K, R, S, P, Q, stride, pad, stream, nullptr, &b);
 }
 

@@ -205,21 +205,19 @@ __global__ __launch_bounds__(LT_THREADS) void layouts_refresh_batched(const WmLa
   else refresh_tile<1>(d, tk * LB_T, tc * LB_T, tile);
 }
 
-// One (8 x 128 (k, c) tile, tap) of one parameter: sum of its nsplit weight-gradient slabs [K][RS][C], in slab order
-// (fixed: bit-reproducible), added to the OIHW gradient.  A thread owns four channels of one k: per slab the block
-// reads eight 512-byte runs (32 x 32 tiles, i.e. 128-byte runs 18 KB apart, streamed at 2.2 TB/s); the OIHW side is a
-// strided 4-byte read-modify-write (gradients are a few per cent of the slab bytes).
-constexpr int FB_K = 8, FB_C = 128;
-template <int RS>
-__device__ __forceinline__ void fold_tile(const WmLayoutDesc& d, int k0, int c0, int rs) {
-  const int K = d.K, C = d.C, ns = d.nsplit;
-  const int k = k0 + ((int)threadIdx.x >> 5), c = c0 + ((int)threadIdx.x & 31) * 4;  // C % 4 == 0 (host-checked)
-  if (k >= K || c >= C) return;
-  const size_t slab = (size_t)K * RS * C;
-  const float* src = d.ws + ((size_t)k * RS + rs) * C + c;
+// Weight-gradient fold: sum of a parameter's nsplit slabs [K][RS][C], in a FIXED order (bit-reproducible), added to the
+// OIHW gradient; a block owns one (k, c) tile of one tap, a thread four channels (C % 4 == 0, host-checked).
+//   nsplit <= FB_SPLIT_MIN: tile 8 k x 128 c x ALL taps, one thread per (k, four channels): all slabs in slab order;
+//   nsplit  > FB_SPLIT_MIN: tile 4 k x 64 c, FOUR threads per (k, four channels), each summing a quarter of the slab
+//     range in slab order; the quarters are combined in quarter order through LDS.  (The 64-channel layers run ~170
+//     splits: one thread walking all of them was a chain of 20 - 40 dependent round trips, and those few blocks -- not
+//     the bytes -- set the launch time: 265 us for 590 MB.)
+// The OIHW side is a strided 4-byte read-modify-write (gradients are a few per cent of the slab bytes).
+constexpr int FB_SPLIT_MIN = 32;
+__device__ __forceinline__ float4 fold_range(const float* src, size_t slab, int s0, int s1) {
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  int sp = 0;
-  for (; sp + 8 <= ns; sp += 8) {
+  int sp = s0;
+  for (; sp + 8 <= s1; sp += 8) {
     float4 t[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) t[u] = *reinterpret_cast<const float4*>(src + (size_t)(sp + u) * slab);
@@ -228,31 +226,76 @@ __device__ __forceinline__ void fold_tile(const WmLayoutDesc& d, int k0, int c0,
       v.x += t[u].x; v.y += t[u].y; v.z += t[u].z; v.w += t[u].w;
     }
   }
-  for (; sp < ns; ++sp) {
+  for (; sp < s1; ++sp) {
     const float4 t = *reinterpret_cast<const float4*>(src + (size_t)sp * slab);
     v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
   }
-  float* g = d.grad + ((size_t)k * C + c) * RS + rs;
-  g[0] += v.x;
-  g[RS] += v.y;
-  g[2 * RS] += v.z;
-  g[3 * RS] += v.w;
+  return v;
+}
+
+template <int RS>
+__device__ __forceinline__ void fold_tile(const WmLayoutDesc& d, int tk, int tc, int rs, float4 (*part)[64]) {
+  const int K = d.K, C = d.C, ns = d.nsplit;
+  const size_t slab = (size_t)K * RS * C;
+  const int tid = (int)threadIdx.x;
+  if (ns <= FB_SPLIT_MIN) {
+    // all RS taps of (k, four channels) in one thread: its 4 * RS gradient values are CONTIGUOUS in OIHW
+    // (offset j * RS + rs), i.e. RS aligned float4 read-modify-writes instead of 4 * RS scattered words
+    const int k = tk * 8 + (tid >> 5), c = tc * 128 + (tid & 31) * 4;
+    if (k >= K || c >= C) return;
+    float o[4 * RS];
+#pragma unroll
+    for (int t = 0; t < RS; ++t) {
+      const float4 v = fold_range(d.ws + ((size_t)k * RS + t) * C + c, slab, 0, ns);
+      o[t] = v.x; o[RS + t] = v.y; o[2 * RS + t] = v.z; o[3 * RS + t] = v.w;
+    }
+    float4* g = reinterpret_cast<float4*>(d.grad + ((size_t)k * C + c) * RS);  // 16-byte aligned: c % 4 == 0
+#pragma unroll
+    for (int i = 0; i < RS; ++i) {
+      float4 cur = g[i];
+      cur.x += o[4 * i]; cur.y += o[4 * i + 1]; cur.z += o[4 * i + 2]; cur.w += o[4 * i + 3];
+      g[i] = cur;
+    }
+    return;
+  }
+  const int q = tid >> 6, e = tid & 63;                       // quarter of the slab range, element of the 4 x 64 tile
+  const int k = tk * 4 + (e >> 4), c = tc * 64 + (e & 15) * 4;
+  const bool on = k < K && c < C;
+  const int per = (ns + 3) >> 2;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on) v = fold_range(d.ws + ((size_t)k * RS + rs) * C + c, slab, q * per, min(ns, (q + 1) * per));
+  part[q][e] = v;
+  __syncthreads();
+  if (q == 0 && on) {
+    const float4 a = part[0][e], b = part[1][e], cc = part[2][e], dd = part[3][e];
+    float* g = d.grad + ((size_t)k * C + c) * RS + rs;
+    g[0] += ((a.x + b.x) + cc.x) + dd.x;
+    g[RS] += ((a.y + b.y) + cc.y) + dd.y;
+    g[2 * RS] += ((a.z + b.z) + cc.z) + dd.z;
+    g[3 * RS] += ((a.w + b.w) + cc.w) + dd.w;
+  }
 }
 
 // weight-gradient slabs -> += OIHW gradients (and bias slabs -> += bias gradients), all parameters of a backward pass.
-// tiles_c = ceil(C / 128); tiles per parameter = ceil(K / 8) * tiles_c * RS.
+// tiles_c = ceil(C / 128), tiles = ceil(K / 8) * tiles_c (nsplit <= 32); else tiles_c = ceil(C / 64), tiles =
+// ceil(K / 4) * tiles_c * RS.
 __global__ __launch_bounds__(LT_THREADS) void wgrad_fold_batched(const WmLayoutDesc* __restrict__ descs, int n_desc) {
+  __shared__ float4 part[4][64];
   const int di = lb_find(descs, n_desc, blockIdx.x);
   const WmLayoutDesc d = descs[di];
   int t = blockIdx.x - d.tile0;
-  const int rs = t % d.RS;
-  t /= d.RS;
+  int rs = 0;
+  if (d.nsplit > FB_SPLIT_MIN) {  // one block per tap only in the split mode
+    rs = t % d.RS;
+    t /= d.RS;
+  }
   const int tk = t / d.tiles_c, tc = t - tk * d.tiles_c;
-  if (d.RS == 9) fold_tile<9>(d, tk * FB_K, tc * FB_C, rs);
-  else fold_tile<1>(d, tk * FB_K, tc * FB_C, rs);
+  if (d.RS == 9) fold_tile<9>(d, tk, tc, rs, part);
+  else fold_tile<1>(d, tk, tc, rs, part);
+  const int kt = d.nsplit <= FB_SPLIT_MIN ? 8 : 4;
   if (d.w != nullptr && tc == 0 && rs == 0) {  // bias slabs [nsplit][K] -> bias gradient
-    const int k = tk * FB_K + (int)threadIdx.x;
-    if ((int)threadIdx.x < FB_K && k < d.K) {
+    const int k = tk * kt + (int)threadIdx.x;
+    if ((int)threadIdx.x < kt && k < d.K) {
       float v = 0.f;
       for (int sp = 0; sp < d.nsplit; ++sp) v += d.w[(size_t)sp * d.K + k];
       reinterpret_cast<float*>(d.krsc)[k] += v;

@@ -51,15 +51,15 @@ class _BatchNorm(nn.Module):
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
 
-    def stats_buffer(self, groups: int, which: str = "_stat_buf"):
-        """Persistent zeroed statistics buffer (ops.new_stats_buffer) for sums fused into a convolution's epilogue:
-        the producing convolution's forward (batch statistics) or, `which="_stat_buf_bwd"`, the consuming
-        convolution's dgrad (backward sums).  The BN finalize kernels clear it again as they read it."""
-        buf = getattr(self, which, None)
-        if buf is None or buf.shape[0] != groups or buf.device != self.weight.device:
-            buf = ops.new_stats_buffer(groups, self.num_features, self.weight.device)
-            setattr(self, which, buf)
-        return buf
+    def stats_buffer(self, groups: int = 0, which: str = "_stat_buf"):
+        """The StatSlots object (ops) of this BatchNorm for sums produced in a convolution's epilogue: the producing
+        convolution's forward (batch statistics) or, `which="_stat_buf_bwd"`, the consuming convolution's dgrad
+        (backward sums).  Per-tile slots written with plain stores, summed in order by the finalize kernels."""
+        slots = getattr(self, which, None)
+        if slots is None:
+            slots = ops.StatSlots(self.num_features)
+            setattr(self, which, slots)
+        return slots
 
     def forward(self, x, residual=None, relu=False, stats=None):
         # num_batches_tracked (+1 per forward call = + the number of statistics groups) is incremented inside

@@ -202,10 +202,10 @@ def _desc_table(rows, device, per_tap: bool = False):
         arr = _np.zeros(len(rows), dtype=LAYOUT_DESC)
         tile0 = 0
         for i, (w, krsc, crsk, ws, grad, k, c, rs, ns) in enumerate(rows):
-            if per_tap:   # wm_wgrad_fold: (8 k x 128 c) tiles, one block per tile and tap
-                tc = (c + 127) // 128
+            if per_tap:   # wm_wgrad_fold: one block per (k, c) tile and tap; 8 x 128 tiles, 4 x 64 beyond 32 slabs
+                tk, tc = ((k + 7) // 8, (c + 127) // 128) if ns <= 32 else ((k + 3) // 4, (c + 63) // 64)
                 arr[i] = (w, krsc, crsk, ws, grad, k, c, rs, tc, tile0, ns)
-                tile0 += ((k + 7) // 8) * tc * rs
+                tile0 += tk * tc * (1 if ns <= 32 else rs)   # up to 32 slabs: a block folds all taps of its tile
             else:         # wm_layouts_refresh: (32 x 32) tiles with all their taps
                 tc = (c + 31) // 32
                 arr[i] = (w, krsc, crsk, ws, grad, k, c, rs, tc, tile0, ns)
@@ -397,23 +397,37 @@ def _arena_grad(p: torch.Tensor):
     return None
 
 
-STAT_BUCKETS = 64  # most partial-sum buckets per statistics group in the fused conv epilogues (buffer size)
+_STAT_TILES = {}
 
 
-def stat_buckets(rows_per_group: int) -> int:
-    """Buckets actually used for a tensor of `rows_per_group` rows per statistics group: ~16 tiles of 128 rows per
-    bucket, a power of two in 4 .. STAT_BUCKETS (the finalize kernel reads and clears every bucket: 64 buckets of a
-    512-channel layer would be 2 MB per BatchNorm, for 98 tiles)."""
-    nb = 4
-    while nb < STAT_BUCKETS and nb * 2 * 16 * 128 <= rows_per_group:
-        nb *= 2
-    return nb
+def fwd_stat_tiles(n, h, w, c, k, r, s, p, q, stride, pad, rows_per_group) -> int:
+    """Statistics slots per group that wm_conv2d_fwd_stats writes for this geometry (one per 128-row tile; the
+    persistent stem kernel: one per workgroup)."""
+    key = (n, h, w, c, k, r, s, p, q, stride, pad, rows_per_group)
+    v = _STAT_TILES.get(key)
+    if v is None:
+        v = int(_lib.load().wm_conv2d_fwd_stats_tiles(*key))
+        if v <= 0:
+            check(v if v < 0 else _lib.WM_EUNSUPPORTED, "wm_conv2d_fwd_stats_tiles")
+        _STAT_TILES[key] = v
+    return v
 
 
-def new_stats_buffer(groups: int, channels: int, device) -> torch.Tensor:
-    """Zeroed int64 [groups, STAT_BUCKETS, 2 statistics, C]: fixed-point partial sums added with integer atomics
-    (include/wafer_hip.h, wm_conv2d_fwd_stats); the finalize kernels clear what they read."""
-    return torch.zeros((groups, STAT_BUCKETS, 2, channels), dtype=torch.int64, device=device)
+class StatSlots:
+    """Per-tile statistics slots of one BatchNorm, filled by a convolution epilogue with plain stores (no atomics,
+    nothing to clear) and summed in slot order by the BatchNorm finalize kernels: float32 [groups, tiles, 2, C],
+    (re)allocated when the producing convolution's tile count changes.  `_hip_busy`: a dgrad epilogue has filled it and
+    the BatchNorm backward has not consumed it yet."""
+
+    def __init__(self, channels: int):
+        self.channels, self.buf, self.tiles, self.groups = channels, None, 0, 0
+        self._hip_busy = None
+
+    def get(self, groups: int, tiles: int, device) -> torch.Tensor:
+        if self.buf is None or self.tiles != tiles or self.groups != groups or self.buf.device != device:
+            self.buf = torch.empty((groups, tiles, 2, self.channels), dtype=torch.float32, device=device)
+            self.tiles, self.groups = tiles, groups
+        return self.buf
 
 
 def stats_fusable(rows: int, groups: int) -> bool:
@@ -458,8 +472,9 @@ class _Conv2d(torch.autograd.Function):
         krsc, _ = _WCACHE.get(weight, need_crsk=train and x.requires_grad)
         y = _empty_nhwc(n, k, p, q, x.device)
         if stats is not None and stats_fusable(n * p * q, groups):
+            tiles = fwd_stat_tiles(n, h, w, c, k, r, s, p, q, stride, pad, n * p * q // groups)
             check(_run("conv_fwd", 2.0 * n * p * q * k * r * s * c, _lib.load().wm_conv2d_fwd_stats, ptr(x), ptr(krsc),
-                       y.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, ptr(stats), stat_buckets(n * p * q // groups),
+                       y.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad, ptr(stats.get(groups, tiles, x.device)), tiles,
                        n * p * q // groups, stream_ptr()), "wm_conv2d_fwd_stats")
         else:
             check(_run("conv_fwd", 2.0 * n * p * q * k * r * s * c, _lib.load().wm_conv2d_fwd, ptr(x), ptr(krsc),
@@ -491,12 +506,12 @@ class _Conv2d(torch.autograd.Function):
             if (link is not None and not link.ready and getattr(link.stats, "_hip_busy", None) is None
                     and lib.wm_conv2d_dgrad_bnstat_ok(n, h, w, c, k, r, s, p, q, stride, pad, link.groups)):
                 # the input was relu(BN(link.y) (+ shortcut)): ReLU backward + that BatchNorm's backward sums in the epilogue
-                rows_pg = n * h * w // link.groups
+                tiles = n * h * w // link.groups // 128
                 check(_run("conv_dgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_dgrad_bnstat, dy.data_ptr(), ptr(crsk),
                            dres.data_ptr() if dres is not None else 0, dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad,
                            link.y.data_ptr(), x.data_ptr() if link.has_res else 0, ptr(link.gamma), ptr(link.beta),
-                           ptr(link.mean), ptr(link.invstd), link.groups, ptr(link.stats), stat_buckets(rows_pg),
-                           stream_ptr()), "wm_conv2d_dgrad_bnstat")
+                           ptr(link.mean), ptr(link.invstd), link.groups, ptr(link.stats.get(link.groups, tiles, dy.device)),
+                           tiles, stream_ptr()), "wm_conv2d_dgrad_bnstat")
                 link.ready, link.g_ptr, link.g_version = True, dx.data_ptr(), dx._version
                 link.stats._hip_busy = True
             elif dres is not None:
@@ -515,8 +530,8 @@ class _Conv2d(torch.autograd.Function):
 def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int = 0,
            stats: Optional[torch.Tensor] = None, groups: int = 1) -> torch.Tensor:
     """bias-free conv2d; x bf16 NHWC (converted if not), weight float32 [K, C, R, S].
-    `stats`: zeroed buffer (new_stats_buffer) into which the epilogue accumulates the BatchNorm statistics of the
-    output (used when `stats_fusable(rows, groups)`)."""
+    `stats`: a StatSlots object into whose per-tile slots the epilogue stores the BatchNorm statistics of the output
+    (used when `stats_fusable(rows, groups)`)."""
     return _Conv2d.apply(x, weight, int(stride), int(padding), stats, int(groups), False, getattr(x, "_hip_bn", None))
 
 
@@ -559,8 +574,9 @@ class _StemConv(torch.autograd.Function):
         ws2d, _ = _WCACHE.get(weight, kind="stem")
         y = _empty_nhwc(n, k, h2, w2, x.device)
         if stats is not None and stats_fusable(n * h2 * w2, groups):
+            tiles = fwd_stat_tiles(n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2, n * h2 * w2 // groups)
             check(_run("conv_fwd", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_fwd_stats, ptr(xs), ptr(ws2d), y.data_ptr(),
-                       n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2, ptr(stats), stat_buckets(n * h2 * w2 // groups),
+                       n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2, ptr(stats.get(groups, tiles, xs.device)), tiles,
                        n * h2 * w2 // groups, stream_ptr()), "wm_conv2d_fwd_stats(stem)")
         else:
             check(_run("conv_fwd", 2.0 * n * h2 * w2 * k * 147, lib.wm_conv2d_fwd, ptr(xs), ptr(ws2d), y.data_ptr(), n, h2,
@@ -641,12 +657,12 @@ class _BatchNorm(torch.autograd.Function):
                 raise ValueError("batch_norm: rows not divisible by groups")
             mean = torch.empty((groups, c), dtype=torch.float32, device=y.device)
             invstd = torch.empty_like(mean)
-            if stats is not None and stats_fusable(rows, groups):
+            if stats is not None and stats.buf is not None and stats_fusable(rows, groups):
                 check(lib.wm_bn_train_fwd_from_stats(y.data_ptr(), ptr(residual) if residual is not None else 0,
                                                      ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                                      ptr(counter), rows, c,
                                                      groups, eps, momentum, int(relu), ptr(mean), ptr(invstd),
-                                                     out.data_ptr(), ptr(stats), stat_buckets(rows // groups), ptr(ws),
+                                                     out.data_ptr(), ptr(stats.buf), stats.tiles, ptr(ws),
                                                      ws.numel(), stream_ptr()), "wm_bn_train_fwd_from_stats")
             else:
                 check(lib.wm_bn_train_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma),
@@ -693,14 +709,15 @@ class _BatchNorm(torch.autograd.Function):
                 # accumulated its sums: finalize + ONE pass; the shortcut's gradient is the masked gradient itself
                 check(lib.wm_bn_train_bwd_from_stats(y.data_ptr(), dout.data_ptr(), ptr(gamma), ptr(beta), ptr(mean),
                                                      ptr(invstd), rows, c, groups, ptr(dgamma), ptr(dbeta), int(direct),
-                                                     dy.data_ptr(), ptr(link.stats), stat_buckets(rows // groups), ptr(ws),
+                                                     dy.data_ptr(), ptr(link.stats.buf), link.stats.tiles, ptr(ws),
                                                      ws.numel(), stream_ptr()), "wm_bn_train_bwd_from_stats")
                 dz = dout if has_res else None
                 fused = True
             else:
                 # another consumer's gradient was accumulated on top: the sums in the buffer are not this tensor's.
-                # Discard them; the general path below re-applies the mask (idempotent) and reduces again.
-                link.stats.zero_()
+                # Ignore them (slots are overwritten by their next producer); the general path below re-applies the mask
+                # (idempotent) and reduces again.
+                pass
         if not fused:
             dz = torch.empty_like(y) if has_res else None
             check(lib.wm_bn_train_bwd(y.data_ptr(), dout.data_ptr(), out.data_ptr() if (relu and not mask_from_y) else 0,
@@ -748,11 +765,11 @@ class _BnReluMaxPool(torch.autograd.Function):
         if training:
             mean, invstd = torch.empty_like(scale), torch.empty_like(scale)
             ws = _bn_workspace(rows, c, g, y.device)
-            fused = stats is not None and stats_fusable(rows, g)
+            fused = stats is not None and stats.buf is not None and stats_fusable(rows, g)
             check(lib.wm_bn_train_stats(y.data_ptr(), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                         ptr(counter), rows, c, g,
                                         eps, momentum, ptr(mean), ptr(invstd), ptr(scale), ptr(shift),
-                                        ptr(stats) if fused else 0, stat_buckets(rows // g), ptr(ws), ws.numel(), stream_ptr()),
+                                        ptr(stats.buf) if fused else 0, stats.tiles if fused else 0, ptr(ws), ws.numel(), stream_ptr()),
                   "wm_bn_train_stats")
             ctx.save_for_backward(y, mean, invstd)
         else:

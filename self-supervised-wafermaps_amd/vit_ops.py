@@ -8,6 +8,7 @@ No CPU fallback: every function raises when the HIP library is missing.
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -313,7 +314,25 @@ class _MlpGelu(torch.autograd.Function):
 
 def mlp_gelu(x: torch.Tensor, fc1_weight: torch.Tensor, fc1_bias: torch.Tensor, fc2_weight: torch.Tensor,
              fc2_bias: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """fc2(gelu(fc1(x))) (+ residual) on bf16 [rows, C] with biases: the transformer MLP block."""
+    """fc2(gelu(fc1(x))) (+ residual) on bf16 [rows, C] with biases: the transformer MLP block.
+    When no gradient is being recorded (DINO teacher, validation, embedding inference) and the shape is served
+    (wm_mlp_fused_fwd_ok: C = 192, ViT-Tiny), the whole block is ONE launch with the hidden activation kept in LDS
+    (wm_mlp_fused_fwd) -- bit-identical to the two-launch path."""
+    needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
+                                                 (x, fc1_weight, fc1_bias, fc2_weight, fc2_bias, residual))
+    if not needs_grad and os.environ.get("WM_MLP_FUSED", "1") != "0":
+        lib = _lib.load()
+        rows, c = x.shape
+        hid = fc1_weight.shape[0]
+        if x.is_cuda and x.dim() == 2 and fc2_weight.shape[0] == c and lib.wm_mlp_fused_fwd_ok(rows, c, hid):
+            xb = _bf16_rows(x)
+            k1, _ = ops._WCACHE.get(fc1_weight, kind="linear")
+            k2, _ = ops._WCACHE.get(fc2_weight, kind="linear")
+            y = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device)
+            rb = _bf16_rows(residual) if residual is not None else None
+            check(ops._run("gemm_fwd", 4.0 * rows * c * hid, lib.wm_mlp_fused_fwd, ptr(xb), ptr(k1), ptr(fc1_bias.detach()),
+                           ptr(k2), ptr(fc2_bias.detach()), ptr(rb), ptr(y), rows, c, hid, stream_ptr()), "wm_mlp_fused_fwd")
+            return y
     return _MlpGelu.apply(x, fc1_weight, fc1_bias, fc2_weight, fc2_bias, residual)
 
 

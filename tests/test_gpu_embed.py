@@ -9,6 +9,9 @@ from oracle import knn as ok
 from oracle import ntxent as on
 
 
+DEV = "cuda:0"
+
+
 def _dev():
     return torch.device("cuda:0")
 

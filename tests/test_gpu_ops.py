@@ -3,6 +3,7 @@
 import pytest
 import torch
 import torch.nn.functional as F
+from parity_log import parity
 
 pytestmark = pytest.mark.gpu
 
@@ -92,7 +93,7 @@ def test_conv3x3_patch_kernel(n, h, w):
     groups = 2
     if ops.stats_fusable(n * h * w, groups):
         gamma, beta = (torch.rand(64, generator=g) + 0.5).to(DEV), (torch.randn(64, generator=g) * 0.1).to(DEV)
-        st = ops.new_stats_buffer(groups, 64, DEV)
+        st = ops.StatSlots(64)
         rm1, rv1 = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
         rm2, rv2 = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
         xin = ops.to_nhwc_bf16(x.to(DEV))
@@ -287,11 +288,12 @@ def test_resnet18_forward_backward_matches_oracle():
     loss.backward()
     fr = torch.cat([f0, f1]).detach()
     cos = F.cosine_similarity(f.float().cpu(), fr, dim=1)
-    assert (1 - cos).max() < 1e-3, f"backbone embedding cosine distance {float((1 - cos).max()):.2e}"
+    parity("ResNet-18 embeddings vs float32 oracle, bs 64 of 64x64 (1 - cosine, worst row)", float((1 - cos).max()), 1e-3)
     zr = torch.cat([z0, z1]).detach()
     cosz = F.cosine_similarity(z.float().cpu(), zr, dim=1)
-    assert (1 - cosz).max() < 5e-3
-    assert abs(loss.item() - loss_ref.item()) / loss_ref.item() < 2e-2
+    parity("ResNet-18 + SimCLR head projections vs float32 oracle (1 - cosine, worst row)", float((1 - cosz).max()), 5e-3)
+    parity("ResNet-18 + head + NT-Xent loss vs float32 oracle, bs 32 of 64x64 (relative)",
+           abs(loss.item() - loss_ref.item()) / loss_ref.item(), 2e-2)
     # gradients: direction agreement per parameter tensor
     # (bf16 activations/gradients through 18 layers at batch 32 of 64x64 images: the stem sees the most rounding noise)
     cosines = {}
@@ -309,16 +311,16 @@ def test_resnet18_forward_backward_matches_oracle():
     # torch's own bf16 autocast on the same GPU lands at the same 0.92-0.98 against the fp32 oracle
     # (tools/diag_bf16_noise.py, profiles/r01_bf16_gradient_noise_diag.txt): this is bf16 rounding at
     # random init, not a kernel defect; the per-op tests above hold the tight tolerances.
-    assert vals[0] > 0.85, f"worst gradient cosine {vals[0]:.4f}"
-    assert vals[len(vals) // 2] > 0.93, f"median gradient cosine {vals[len(vals) // 2]:.4f}"
+    parity("ResNet-18 parameter gradients vs float32 oracle (cosine, worst tensor)", vals[0], 0.85, higher=True,
+           note="bf16 rounding at random init; torch's own bf16 autocast lands at the same 0.92-0.98")
+    parity("ResNet-18 parameter gradients vs float32 oracle (cosine, median tensor)", vals[len(vals) // 2], 0.93, higher=True)
     # running statistics were updated twice (two groups), as two reference forwards do
     torch.testing.assert_close(backbone.bn1.running_mean.cpu(), params["backbone.bn1.running_mean"], atol=2e-3, rtol=2e-2)
     assert int(backbone.bn1.num_batches_tracked) == 2
 
 
 def test_conv_bn_fused_statistics_match_unfused():
-    """conv epilogue statistics + finalize-from-stats == separate statistics pass; and the buffer is
-    clean again afterwards (read-and-clear)."""
+    """conv epilogue statistics (per-tile slots, plain stores) + finalize-from-slots == separate statistics pass."""
     from ssl_wafermap_amd import ops
 
     g = torch.Generator().manual_seed(0)
@@ -327,13 +329,15 @@ def test_conv_bn_fused_statistics_match_unfused():
     gamma, beta = (torch.rand(128, generator=g) + 0.5).to(DEV), (torch.randn(128, generator=g) * 0.1).to(DEV)
     groups = 2
     assert ops.stats_fusable(8 * 16 * 16, groups)
-    st = ops.new_stats_buffer(groups, 128, DEV)
+    st = ops.StatSlots(128)
     rm1, rv1 = torch.zeros(128, device=DEV), torch.ones(128, device=DEV)
     rm2, rv2 = torch.zeros(128, device=DEV), torch.ones(128, device=DEV)
     y1 = ops.conv2d(x, w, 1, 1, stats=st, groups=groups)
-    assert float(st.abs().sum()) > 0
+    assert st.buf is not None and st.tiles == 8 * 16 * 16 // groups // 128 and float(st.buf.abs().sum()) > 0
+    # the slots hold each tile's column sums: their sum over the tiles is the column sum of the tensor
+    want = y1.float().permute(0, 2, 3, 1).reshape(groups, -1, 128).sum(1)
+    torch.testing.assert_close(st.buf[:, :, 0].sum(1), want, atol=2e-2, rtol=2e-3)
     o1 = ops.batch_norm(y1, gamma, beta, rm1, rv1, True, relu=True, groups=groups, stats=st)
-    assert float(st.abs().sum()) == 0.0
     y2 = ops.conv2d(x, w, 1, 1)
     o2 = ops.batch_norm(y2, gamma, beta, rm2, rv2, True, relu=True, groups=groups)
     assert torch.equal(y1, y2)
@@ -459,7 +463,7 @@ def test_batched_layout_refresh_and_wgrad_fold_match_the_per_parameter_kernels()
 
     lib = _lib.load()
     g = torch.Generator().manual_seed(0)
-    shapes = [(64, 64, 3, 3, 5), (128, 64, 1, 1, 1), (512, 256, 3, 3, 3), (192, 576, 1, 1, 17), (40, 72, 3, 3, 9),
+    shapes = [(64, 64, 3, 3, 45), (128, 64, 1, 1, 1), (36, 68, 1, 1, 33), (512, 256, 3, 3, 3), (192, 576, 1, 1, 17), (40, 72, 3, 3, 9),
               (33, 36, 1, 1, 2)]
     rows_l, rows_f, refs = [], [], []
     keep = []
@@ -487,7 +491,10 @@ def test_batched_layout_refresh_and_wgrad_fold_match_the_per_parameter_kernels()
     torch.cuda.synchronize()
     for (krsc, crsk, rk, rc, slabs, grad, grad2, bgrad, bgrad2), shp in zip(refs, shapes):
         assert torch.equal(krsc, rk) and torch.equal(crsk, rc), shp
-        assert torch.equal(grad, grad2), shp
+        if shp[4] <= 32:   # slab order, as wm_wgrad_finalize: bit-identical
+            assert torch.equal(grad, grad2), shp
+        else:              # more than 32 slabs: four quarter sums combined in order -- another (fixed) summation order
+            torch.testing.assert_close(grad, grad2, rtol=1e-5, atol=1e-5)
         assert torch.equal(bgrad, bgrad2), shp
         # and the finalize itself against torch (float32 sums in another order: tolerance)
         k, c, r, s, ns = shp

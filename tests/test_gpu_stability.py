@@ -10,6 +10,7 @@ Reference step: scripts/WM811k_benchmark.py:242-255."""
 import numpy as np
 import pytest
 import torch
+from parity_log import parity
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -139,8 +140,9 @@ def test_bs32_first_steps_track_the_float32_oracle():
     print("hip   ", got)
     print("oracle", want)
     rel = np.abs(np.array(got) - np.array(want)) / np.abs(want)
-    assert rel[0] < 2e-3, rel           # one bf16 step from identical weights
-    assert rel.max() < 3e-2, rel        # five steps of bf16-vs-float32 drift (measured 0.5-1.5 %; f32 atomics vary run to run)
+    parity("SimCLR bs 32 graph-replayed step 1 loss vs float32 oracle (relative)", rel[0], 2e-3)
+    parity("SimCLR bs 32 graph-replayed steps 1-5 loss vs float32 oracle (relative, worst)", rel.max(), 3e-2,
+           note="five optimiser steps of bf16-vs-float32 drift")
 
 
 def test_bs64_whole_step_loss_matches_the_float32_oracle():
@@ -164,7 +166,8 @@ def test_bs64_whole_step_loss_matches_the_float32_oracle():
         ref, _ = orn.simclr_loss(v[:B], v[B:], sd, 0.5, True)
         rels.append(abs(float(loss.detach()) - float(ref)) / abs(float(ref)))
     print("whole-step loss, relative error vs float32 oracle at bs 64:", rels)
-    assert max(rels) < 1e-3, rels
+    parity("SimCLR whole step loss at bs 64 vs float32 oracle (relative, worst of 2 seeds)", max(rels), 1e-3,
+           note="north_star asks 1e-4: holds at the loss kernel (1e-5); 18 bf16 layers in front of it")
 
 
 def test_bs256_step_is_bit_reproducible():

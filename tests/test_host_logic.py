@@ -108,8 +108,9 @@ def test_resnet18_state_dict_has_timm_keys():
     assert "layers.0.bias" not in h and "layers.4.running_var" in h
     with pytest.raises(NotImplementedError):
         create_model("resnet50")
-    with pytest.raises(NotImplementedError):
-        SimCLRProjectionHead(512, 512, 128, batch_norm=False)
+    # the BN-free (SimCLR v1) form: Linear layers with a bias, no BatchNorm keys (lightly's batch_norm=False)
+    h1 = SimCLRProjectionHead(512, 512, 128, batch_norm=False).state_dict()
+    assert set(h1) == {"layers.0.weight", "layers.0.bias", "layers.2.weight", "layers.2.bias"}
 
 
 def test_ntxent_constructor_checks_and_scheduler():

@@ -41,11 +41,12 @@ for name, C, H, K, R, stride, pad in SHAPES:
     wc = (torch.randn(C, R, R, K, generator=g, device=dev) * 0.05).bfloat16()
     dx, res = torch.empty_like(x), torch.randn_like(x.float()).bfloat16()
     bn_y = torch.randn_like(x.float()).bfloat16()
-    stats = ops.new_stats_buffer(G, max(C, K), dev)
     mean, invstd = torch.zeros(G, C, device=dev), torch.ones(G, C, device=dev)
     gamma, beta = torch.ones(C, device=dev), torch.zeros(C, device=dev)
     geom = (N, H, H, C, K, R, R, P, P, stride, pad)
-    nbf, nbb = ops.stat_buckets(N * P * P // G), ops.stat_buckets(N * H * H // G)
+    nbf = int(lib.wm_conv2d_fwd_stats_tiles(*geom, N * P * P // G))
+    nbb = N * H * H // G // 128
+    stats = torch.empty(G * max(nbf, nbb) * 2 * max(C, K), device=dev)
     t = {}
     t["fwd"] = timeit(lambda: check(lib.wm_conv2d_fwd(ptr(x), ptr(wk), ptr(y), *geom, st), "f"))
     t["fwd+stats"] = timeit(lambda: check(lib.wm_conv2d_fwd_stats(ptr(x), ptr(wk), ptr(y), *geom, ptr(stats), nbf, N * P * P // G, st), "fs"))
@@ -56,5 +57,4 @@ for name, C, H, K, R, stride, pad in SHAPES:
             ptr(y), ptr(wc), 0, ptr(dx), *geom, ptr(bn_y), 0, ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), G, ptr(stats), nbb, st), "b1"))
         t["dgrad+res+bnb(x mask)"] = timeit(lambda: check(lib.wm_conv2d_dgrad_bnstat(
             ptr(y), ptr(wc), ptr(res), ptr(dx), *geom, ptr(bn_y), ptr(x), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), G, ptr(stats), nbb, st), "b2"))
-    stats.zero_()
     print(f"{name:18s} " + "  ".join(f"{k} {v:7.1f}us" for k, v in t.items()), flush=True)
