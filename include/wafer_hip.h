@@ -40,6 +40,12 @@ extern "C" {
 
 int wm_version(void);
 const char* wm_error_string(int code);
+/* Small device-side pieces that keep framework launches out of the captured training step: clear a buffer (the flat
+ * gradient arena of optimizer.zero_grad; a kernel, never a memset node: profiles/r02_nan_root_cause.md) and
+ * out[0] = mean_i f(x_i), f = identity or sqrt(scale * x_i) (mean of the NT-Xent row losses, scripts/WM811k_benchmark.py:247;
+ * lightly's std_of_l2_normalized monitor, :239), one block, fixed summation order. */
+int wm_fill_zero(void* p, size_t bytes, void* stream);
+int wm_mean_f32(const float* x, long long n, float scale, int sqrt_of, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Two-view augmentation.

@@ -50,3 +50,38 @@ extern "C" int wm_debug_absmax(const void* x, int dtype, long long n, float* slo
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
+
+// ---- the small device-side pieces that would otherwise be framework (ATen) launches inside the captured training
+// step: clearing the flat gradient arena (optimizer.zero_grad) and scalar means of short vectors (the mean of the
+// NT-Xent row losses; the mean of sqrt(scale * column variance) of lightly's std_of_l2_normalized monitor).
+namespace {
+// out[0] = mean_i f(x_i), f = identity (sqrt_of = 0) or sqrt(scale * x_i).  ONE block, a fixed summation order
+// (strided per-thread sums, then a fixed tree): bit-reproducible.
+__global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ x, long long n, float scale, int sqrt_of,
+                                                    float* __restrict__ out) {
+  __shared__ float red[1024];
+  float s = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 1024) s += sqrt_of ? sqrtf(scale * x[i]) : x[i];
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = red[0] / (float)n;
+}
+}  // namespace
+
+extern "C" int wm_fill_zero(void* p, size_t bytes, void* stream) {
+  WM_REQUIRE(p && bytes > 0, WM_EINVAL);
+  WM_REQUIRE(bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0, WM_EALIGN);
+  const hipError_t e = wm_zero_async(p, bytes, static_cast<hipStream_t>(stream));
+  return e == hipSuccess ? WM_OK : (int)e;
+}
+
+extern "C" int wm_mean_f32(const float* x, long long n, float scale, int sqrt_of, float* out, void* stream) {
+  WM_REQUIRE(x && out && n > 0, WM_EINVAL);
+  mean_kernel<<<1, 1024, 0, static_cast<hipStream_t>(stream)>>>(x, n, scale, sqrt_of, out);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

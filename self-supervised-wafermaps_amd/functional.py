@@ -232,6 +232,16 @@ def l2_normalize(x: torch.Tensor, eps: float = 1e-12, out_dtype: Optional[torch.
     return y
 
 
+def vector_mean(x: torch.Tensor, scale: float = 1.0, sqrt_of: bool = False) -> torch.Tensor:
+    """mean_i f(x_i) of a float32 vector as a 0-d tensor, f = identity or sqrt(scale * x_i): one block, fixed
+    summation order (wm_mean_f32) -- keeps torch's reduction kernels out of the captured training step."""
+    require_gpu(x)
+    x = x.contiguous()
+    out = torch.empty(1, dtype=torch.float32, device=x.device)
+    check(_lib.load().wm_mean_f32(ptr(x), x.numel(), float(scale), int(bool(sqrt_of)), ptr(out), stream_ptr()), "wm_mean_f32")
+    return out[0]
+
+
 # --------------------------------------------------------------------------------------- NT-Xent
 
 

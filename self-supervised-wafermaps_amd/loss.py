@@ -41,7 +41,7 @@ class _NTXentCore(torch.autograd.Function):
             lse_all = lse
         ctx.save_for_backward(zn, zall, lse_all)
         ctx.meta = (b_local, b_global, rank * b_local, temperature)
-        return rows.mean()
+        return F_hip.vector_mean(rows)
 
     @staticmethod
     def backward(ctx, grad_out):

@@ -128,7 +128,7 @@ class SGD(_ArenaStateMixin, torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False) -> None:
         ops.drop_pending_folds()  # (a backward pass that raised leaves its queue behind: ADVICE r2)
         for a in self._arenas:
-            a.grads.zero_()
+            check(_lib.load().wm_fill_zero(ptr(a.grads), a.grads.numel() * 4, stream_ptr()), "wm_fill_zero")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -177,7 +177,7 @@ class AdamW(_ArenaStateMixin, torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False) -> None:
         ops.drop_pending_folds()  # (a backward pass that raised leaves its queue behind: ADVICE r2)
         for a in self._arenas:
-            a.grads.zero_()
+            check(_lib.load().wm_fill_zero(ptr(a.grads), a.grads.numel() * 4, stream_ptr()), "wm_fill_zero")
 
     @torch.no_grad()
     def step(self, closure=None):
@@ -231,7 +231,7 @@ class LARS(_ArenaStateMixin, torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False) -> None:
         ops.drop_pending_folds()  # (a backward pass that raised leaves its queue behind: ADVICE r2)
         for a in self._arenas:
-            a.grads.zero_()
+            check(_lib.load().wm_fill_zero(ptr(a.grads), a.grads.numel() * 4, stream_ptr()), "wm_fill_zero")
 
     @torch.no_grad()
     def step(self, closure=None):

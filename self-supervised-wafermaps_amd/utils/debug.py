@@ -20,4 +20,4 @@ def std_of_l2_normalized(z: torch.Tensor) -> torch.Tensor:
     stats = torch.zeros(2, c, dtype=torch.float32, device=zn.device)
     check(_lib.load().wm_colstats(ptr(zn), dtype_code(zn), rows, c, ptr(stats[0]), ptr(stats[1]), stream_ptr()),
           "wm_colstats")
-    return (stats[1] * (rows / (rows - 1.0))).sqrt().mean()
+    return F_hip.vector_mean(stats[1], scale=rows / (rows - 1.0), sqrt_of=True)

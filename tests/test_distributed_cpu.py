@@ -98,6 +98,7 @@ def _ntxent_gathered(rank, world):
     F_hip.ntxent_forward = ref_ntxent_forward
     F_hip.ntxent_backward = ref_ntxent_backward
     F_hip.l2_normalize = lambda x, eps=1e-12, out_dtype=None: torch.nn.functional.normalize(x, dim=1, eps=eps)
+    F_hip.vector_mean = lambda x, scale=1.0, sqrt_of=False: (torch.sqrt(scale * x) if sqrt_of else x).mean()
     b, d, t = 6, 32, 0.5
     g = torch.Generator().manual_seed(0)
     z0_all, z1_all = torch.randn(world * b, d, generator=g), torch.randn(world * b, d, generator=g)
