@@ -364,6 +364,28 @@ int wm_bn_train_bwd_from_stats(const void* y, const void* g, const float* gamma,
                                const float* save_mean, const float* save_invstd, long long rows, int C, int G,
                                float* dgamma, float* dbeta, int accumulate, void* dy, const float* stat_part,
                                int stat_tiles, void* workspace, size_t workspace_bytes, void* stream);
+/* Synchronised BatchNorm (torch.nn.SyncBatchNorm; the reference's `sync_batchnorm` flag, scripts/WM811k_benchmark.py:62,
+ * :1103): statistics over the batches of all ranks.  The library holds no communicator, so each pass is cut at the
+ * point where the CALLER all-reduces (sum) a [G][2][C] f32 vector: forward (sum y, sum y^2), backward (sum g,
+ * sum g * xhat).  group_count = rows per statistics group summed over the ranks (equal per-rank batches).  dgamma /
+ * dbeta stay this rank's local sums, as torch's do (the gradient exchange averages them).  C <= 2048.
+ * wm_bn_sync_fwd_sums: stat_part NULL -> computed from y (workspace: wm_bn_workspace_bytes), else the slots of
+ * wm_conv2d_fwd_stats.  wm_bn_sync_bwd_sums / _apply: mask arguments as wm_bn_train_bwd. */
+int wm_bn_sync_fwd_sums(const void* y, long long rows, int C, int G, const float* stat_part, int stat_tiles,
+                        float* sums, void* workspace, size_t workspace_bytes, void* stream);
+int wm_bn_sync_fwd_apply(const void* y, const void* residual, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, long long* num_batches_tracked, long long rows, int C,
+                         int G, long long group_count, float eps, float momentum, int relu, float* save_mean,
+                         float* save_invstd, void* out, const float* sums, void* workspace, size_t workspace_bytes,
+                         void* stream);
+int wm_bn_sync_bwd_sums(const void* y, const void* dout, const void* out_relu, int relu_from_y, const float* gamma,
+                        const float* beta, const float* save_mean, const float* save_invstd, long long rows, int C,
+                        int G, float* dgamma, float* dbeta, int accumulate, float* sums, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int wm_bn_sync_bwd_apply(const void* y, const void* dout, const void* out_relu, int relu_from_y, const float* gamma,
+                         const float* beta, const float* save_mean, const float* save_invstd, long long rows, int C,
+                         int G, long long group_count, const float* sums, void* dy, void* dz, void* workspace,
+                         size_t workspace_bytes, void* stream);
 /* Backward of the fused stem tail max_pool3x3s2(relu(BN(y))): y [N][H][W][C]; the gradient entering
  * the BN is gathered from pooled_dy / pool_idx [N][P][Q][C] inside the apply pass; with ysel (the
  * inputs at the selected positions, from the forward; may be NULL) the per-channel sums run over the

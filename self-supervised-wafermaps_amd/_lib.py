@@ -109,6 +109,22 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_int,
          c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
     ),
+    "wm_bn_sync_fwd_sums": (c_int, [c_void_p, c_longlong, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wm_bn_sync_fwd_apply": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_longlong,
+         c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "wm_bn_sync_bwd_sums": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int,
+         c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
+    "wm_bn_sync_bwd_apply": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int,
+         c_longlong, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+    ),
     "wm_stem_weights_prepare": (c_int, [c_void_p, c_int, c_void_p, c_void_p]),
     "wm_stem_wgrad_finalize": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_void_p]),
     "wm_image_to_s2d": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),

@@ -315,6 +315,27 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize(
   }
 }
 
+// Partial sums [G][nblk][2][C] -> their totals [G][2][C] (double accumulation in slot order, rounded once): what a
+// rank contributes to the cross-rank all-reduce of synchronised BatchNorm.
+__global__ __launch_bounds__(1024) void bn_sums_finalize(float* __restrict__ part, int nblk, int G, int C,
+                                                          float* __restrict__ sums) {
+  __shared__ double red[2][2][32][33];
+  const int bl = threadIdx.x >> 5, cl = threadIdx.x & 31;
+  const int c = blockIdx.x * 32 + cl;
+  const bool owner = bl == 0 && c < C;
+  for (int g0 = 0; g0 < G; g0 += 2) {
+    const int ng = G - g0 < 2 ? G - g0 : 2;
+    double a[2], b[2];
+    finalize_sums2(part, nblk, g0, ng, C, c, bl, cl, red, a, b);
+    if (owner) {
+      for (int u = 0; u < ng; ++u) {
+        sums[((size_t)(g0 + u) * 2 + 0) * C + c] = (float)a[u];
+        sums[((size_t)(g0 + u) * 2 + 1) * C + c] = (float)b[u];
+      }
+    }
+  }
+}
+
 // Eval-mode scale/shift from running statistics.
 __global__ void bn_eval_params(const float* __restrict__ gamma, const float* __restrict__ beta,
                                const float* __restrict__ running_mean,
@@ -1063,6 +1084,130 @@ static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, in
     bn_bwd_apply<false><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
         coef, rows, C, rpg, remask ? 1 : 0, csh, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz), ps);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+// ---- synchronised BatchNorm (torch.nn.SyncBatchNorm semantics: statistics over the batches of ALL ranks) -------------
+// The library has no communicator: each pass is cut in two at the point where the caller all-reduces a [G][2][C]
+// float vector (RCCL / gloo through torch.distributed).  `group_count` = rows per statistics group summed over ranks.
+extern "C" int wm_bn_sync_fwd_sums(const void* y, long long rows, int C, int G, const float* stat_part, int stat_tiles,
+                                   float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(y && sums && workspace, WM_EINVAL);
+  const int rc = bn_shape_check(rows, C, G);
+  if (rc != WM_OK) return rc;
+  WM_REQUIRE(!bn_wide(rows, C, G), WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rpg = (int)(rows / G);
+  int nblk = 0;
+  const float* part;
+  if (stat_part) {
+    WM_REQUIRE(stat_tiles > 0, WM_EINVAL);
+    WM_REQUIRE(stat_tiles <= 512 || workspace_bytes >= (size_t)G * 128 * 2 * C * sizeof(float), WM_EWORKSPACE);
+    part = stat_partials(stat_part, stat_tiles, G, C, static_cast<float*>(workspace), &nblk, st);
+  } else {
+    WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
+    nblk = reduce_blocks(rpg, C);
+    const int tpr = C >> 3, rpp = BN_THREADS / tpr;
+    const size_t lds = (size_t)2 * rpp * C * sizeof(float);
+    bn_reduce<0><<<dim3(nblk, G), BN_THREADS, lds, st>>>(static_cast<const uint16_t*>(y), nullptr, nullptr, nullptr,
+                                                         nullptr, nullptr, nullptr, rpg, C, wm_cdiv(rpg, nblk),
+                                                         static_cast<float*>(workspace), PoolSrc{});
+    part = static_cast<float*>(workspace);
+  }
+  WM_LAUNCH_CHECK();
+  bn_sums_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(const_cast<float*>(part), nblk, G, C, sums);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_bn_sync_fwd_apply(const void* y, const void* residual, const float* gamma, const float* beta,
+                                    float* running_mean, float* running_var, long long* num_batches_tracked,
+                                    long long rows, int C, int G, long long group_count, float eps, float momentum,
+                                    int relu, float* save_mean, float* save_invstd, void* out, const float* sums,
+                                    void* workspace, size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(y && out && save_mean && save_invstd && sums && workspace, WM_EINVAL);
+  const int rc = bn_shape_check(rows, C, G);
+  if (rc != WM_OK) return rc;
+  WM_REQUIRE(!bn_wide(rows, C, G), WM_EUNSUPPORTED);
+  WM_REQUIRE(group_count >= rows / G && group_count < (1ll << 31), WM_EINVAL);
+  WM_REQUIRE(workspace_bytes >= (size_t)2 * G * C * sizeof(float), WM_EWORKSPACE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* scale = static_cast<float*>(workspace);
+  float* shift = scale + (size_t)G * C;
+  bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(const_cast<float*>(sums), 1, G, C, (int)group_count, 0, gamma, beta, eps,
+                                                   momentum, running_mean, running_var, num_batches_tracked, save_mean,
+                                                   save_invstd, scale, shift);
+  WM_LAUNCH_CHECK();
+  launch_bn_apply(y, residual, scale, shift, rows, C, (int)(rows / G), relu, out, st);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+// Local (sum g, sum g * xhat) per (group, channel) -> sums [G][2][C], and this rank's dgamma / dbeta (torch's
+// SyncBatchNorm leaves their reduction to the gradient exchange).  Workspace as wm_bn_train_bwd.
+extern "C" int wm_bn_sync_bwd_sums(const void* y, const void* dout, const void* out_relu, int relu_from_y,
+                                   const float* gamma, const float* beta, const float* save_mean,
+                                   const float* save_invstd, long long rows, int C, int G, float* dgamma, float* dbeta,
+                                   int accumulate, float* sums, void* workspace, size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(y && dout && save_mean && save_invstd && sums && workspace, WM_EINVAL);
+  const int rc = bn_shape_check(rows, C, G);
+  if (rc != WM_OK) return rc;
+  WM_REQUIRE(!bn_wide(rows, C, G), WM_EUNSUPPORTED);
+  WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rpg = (int)(rows / G);
+  const int nblk = reduce_blocks(rpg, C);
+  float* part = static_cast<float*>(workspace);
+  float* coef = part + (size_t)G * nblk * 2 * C;
+  const int tpr = C >> 3, rpp = BN_THREADS / tpr;
+  const size_t lds = (size_t)2 * rpp * C * sizeof(float);
+  const bool remask = relu_from_y && !out_relu;
+  WM_REQUIRE(!remask || (gamma && beta), WM_EINVAL);
+  bn_reduce<1><<<dim3(nblk, G), BN_THREADS, lds, st>>>(
+      static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
+      save_mean, save_invstd, remask ? gamma : nullptr, remask ? beta : nullptr, rpg, C, wm_cdiv(rpg, nblk), part, PoolSrc{});
+  WM_LAUNCH_CHECK();
+  bn_sums_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, sums);
+  WM_LAUNCH_CHECK();
+  if (dgamma || dbeta) {  // the local parameter gradients from the local totals (coef is scratch here)
+    bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(sums, 1, G, C, rpg, gamma, beta, save_mean, save_invstd, dgamma,
+                                                     dbeta, accumulate, coef, 0);
+    WM_LAUNCH_CHECK();
+  }
+  return WM_OK;
+}
+
+// sums: the all-reduced totals.  dy = gamma * invstd * (dz - sum(dz)/M - xhat * sum(dz * xhat)/M), M = group_count.
+extern "C" int wm_bn_sync_bwd_apply(const void* y, const void* dout, const void* out_relu, int relu_from_y,
+                                    const float* gamma, const float* beta, const float* save_mean,
+                                    const float* save_invstd, long long rows, int C, int G, long long group_count,
+                                    const float* sums, void* dy, void* dz, void* workspace, size_t workspace_bytes,
+                                    void* stream) {
+  WM_REQUIRE(y && dout && save_mean && save_invstd && sums && dy && workspace, WM_EINVAL);
+  const int rc = bn_shape_check(rows, C, G);
+  if (rc != WM_OK) return rc;
+  WM_REQUIRE(!bn_wide(rows, C, G), WM_EUNSUPPORTED);
+  WM_REQUIRE(group_count >= rows / G && group_count < (1ll << 31), WM_EINVAL);
+  WM_REQUIRE(workspace_bytes >= (size_t)7 * G * C * sizeof(float), WM_EWORKSPACE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int rpg = (int)(rows / G);
+  float* coef = static_cast<float*>(workspace);
+  const bool remask = relu_from_y && !out_relu;
+  WM_REQUIRE(!remask || (gamma && beta), WM_EINVAL);
+  bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(const_cast<float*>(sums), 1, G, C, (int)group_count, gamma, beta,
+                                                   save_mean, save_invstd, nullptr, nullptr, 0, coef, 0);
+  WM_LAUNCH_CHECK();
+  const int tpr = C >> 3;
+  int csh = 0;
+  if (chunk_pow2(C, &csh))
+    bn_bwd_apply<true><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
+        coef, rows, C, rpg, remask ? 1 : 0, csh, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz), PoolSrc{});
+  else
+    bn_bwd_apply<false><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
+        coef, rows, C, rpg, remask ? 1 : 0, csh, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz), PoolSrc{});
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

@@ -50,6 +50,14 @@ class _BatchNorm(nn.Module):
         self.register_buffer("running_mean", torch.zeros(num_features))
         self.register_buffer("running_var", torch.ones(num_features))
         self.register_buffer("num_batches_tracked", torch.tensor(0, dtype=torch.long))
+        self.sync, self.process_group = False, None  # see convert_sync_batchnorm
+
+    def _synced(self) -> bool:
+        if not (self.sync and self.training):
+            return False
+        import torch.distributed as dist
+
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size(self.process_group) > 1
 
     def stats_buffer(self, groups: int = 0, which: str = "_stat_buf"):
         """The StatSlots object (ops) of this BatchNorm for sums produced in a convolution's epilogue: the producing
@@ -64,6 +72,10 @@ class _BatchNorm(nn.Module):
     def forward(self, x, residual=None, relu=False, stats=None):
         # num_batches_tracked (+1 per forward call = + the number of statistics groups) is incremented inside
         # the statistics kernel: 22 one-block torch kernels per ResNet-18 step otherwise
+        if self._synced():
+            return ops.sync_batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, residual=residual,
+                                       relu=relu, eps=self.eps, momentum=self.momentum, stats=stats,
+                                       num_batches_tracked=self.num_batches_tracked, process_group=self.process_group)
         bwd = None
         if self.training and relu and x.dim() == 4 and torch.is_grad_enabled():
             bwd = self.stats_buffer(ops.current_bn_groups(), "_stat_buf_bwd")
@@ -75,6 +87,8 @@ class _BatchNorm(nn.Module):
 class BatchNorm2d(_BatchNorm):
     def forward_relu_maxpool(self, x, stats=None):
         """maxpool3x3s2(relu(self(x))) fused (ResNet stem)."""
+        if self._synced():  # the statistics need the exchange between the two halves of the fused kernel pair
+            return ops.max_pool3x3s2(self.forward(x, relu=True, stats=stats))
         return ops.bn_relu_maxpool(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
                                    eps=self.eps, momentum=self.momentum, stats=stats,
                                    num_batches_tracked=self.num_batches_tracked)
@@ -82,6 +96,17 @@ class BatchNorm2d(_BatchNorm):
 
 class BatchNorm1d(_BatchNorm):
     pass
+
+
+def convert_sync_batchnorm(module: nn.Module, process_group=None) -> nn.Module:
+    """torch.nn.SyncBatchNorm.convert_sync_batchnorm for this package's BatchNorm layers (what Lightning's
+    `Trainer(sync_batchnorm=True)` does in the reference, scripts/WM811k_benchmark.py:1103): in training mode, with a
+    process group of more than one rank, every BatchNorm takes its batch statistics over all ranks.  In place; the
+    module is returned for chaining.  State dict and eval mode are unchanged."""
+    for m in module.modules():
+        if isinstance(m, _BatchNorm):
+            m.sync, m.process_group = True, process_group
+    return module
 
 
 class Linear(nn.Module):

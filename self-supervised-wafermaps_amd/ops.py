@@ -746,6 +746,92 @@ def batch_norm(y, gamma, beta, running_mean, running_var, training: bool, residu
     return out
 
 
+class _SyncBatchNorm(torch.autograd.Function):
+    """torch.nn.SyncBatchNorm on the HIP kernels: batch statistics over every rank of `group` (the reference's
+    `sync_batchnorm=True`, scripts/WM811k_benchmark.py:62,1103 -> Lightning's convert_sync_batchnorm).  Forward: this
+    rank's (sum y, sum y^2) -> all-reduce -> normalise with the global mean / variance; backward: (sum g, sum g * xhat)
+    -> all-reduce -> dy with the global means.  dgamma / dbeta stay local sums (torch's do; GradSync averages them).
+    Equal per-rank batches (drop_last loaders)."""
+
+    @staticmethod
+    def forward(ctx, y, residual, gamma, beta, running_mean, running_var, groups, eps, momentum, relu, stats, counter,
+                group):
+        import torch.distributed as dist
+
+        _need_cuda(y, "sync_batch_norm")
+        y = _as_act(y)
+        if residual is not None:
+            residual = _as_act(residual)
+            if residual.shape != y.shape:
+                raise ValueError("sync_batch_norm: residual shape mismatch")
+        rows, c = _rows_c(y)
+        if rows % groups:
+            raise ValueError("sync_batch_norm: rows not divisible by groups")
+        if c > 2048:
+            raise NotImplementedError("sync_batch_norm: more than 2048 channels")
+        lib = _lib.load()
+        world = dist.get_world_size(group)
+        out = torch.empty_like(y)
+        ws = _bn_workspace(rows, c, groups, y.device)
+        sums = torch.empty((groups, 2, c), dtype=torch.float32, device=y.device)
+        fused = stats is not None and stats.buf is not None and stats_fusable(rows, groups)
+        check(lib.wm_bn_sync_fwd_sums(y.data_ptr(), rows, c, groups, ptr(stats.buf) if fused else 0,
+                                      stats.tiles if fused else 0, ptr(sums), ptr(ws), ws.numel(), stream_ptr()),
+              "wm_bn_sync_fwd_sums")
+        dist.all_reduce(sums, group=group)
+        mean = torch.empty((groups, c), dtype=torch.float32, device=y.device)
+        invstd = torch.empty_like(mean)
+        count = rows // groups * world
+        check(lib.wm_bn_sync_fwd_apply(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma), ptr(beta),
+                                       ptr(running_mean), ptr(running_var), ptr(counter), rows, c, groups, count, eps,
+                                       momentum, int(relu), ptr(mean), ptr(invstd), out.data_ptr(), ptr(sums), ptr(ws),
+                                       ws.numel(), stream_ptr()), "wm_bn_sync_fwd_apply")
+        mask_from_y = relu and residual is None and gamma is not None and beta is not None
+        ctx.save_for_backward(y, out if (relu and not mask_from_y) else None, mean, invstd)
+        ctx.affine = (gamma, beta)
+        ctx.meta = (rows, c, groups, relu, residual is not None, mask_from_y, count, group)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        import torch.distributed as dist
+
+        y, out, mean, invstd = ctx.saved_tensors
+        gamma, beta = ctx.affine
+        rows, c, groups, relu, has_res, mask_from_y, count, group = ctx.meta
+        dout = _as_act(dout)
+        lib = _lib.load()
+        dy = torch.empty_like(y)
+        sg, sb = _arena_grad(gamma), _arena_grad(beta)
+        direct = sg is not None and sb is not None
+        dgamma = sg if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
+        dbeta = sb if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
+        ws = _bn_workspace(rows, c, groups, y.device)
+        sums = torch.empty((groups, 2, c), dtype=torch.float32, device=y.device)
+        mask = out.data_ptr() if (relu and not mask_from_y) else 0
+        check(lib.wm_bn_sync_bwd_sums(y.data_ptr(), dout.data_ptr(), mask, int(mask_from_y), ptr(gamma), ptr(beta),
+                                      ptr(mean), ptr(invstd), rows, c, groups, ptr(dgamma), ptr(dbeta), int(direct),
+                                      ptr(sums), ptr(ws), ws.numel(), stream_ptr()), "wm_bn_sync_bwd_sums")
+        dist.all_reduce(sums, group=group)
+        dz = torch.empty_like(y) if has_res else None
+        check(lib.wm_bn_sync_bwd_apply(y.data_ptr(), dout.data_ptr(), mask, int(mask_from_y), ptr(gamma), ptr(beta),
+                                       ptr(mean), ptr(invstd), rows, c, groups, count, ptr(sums), dy.data_ptr(),
+                                       dz.data_ptr() if has_res else 0, ptr(ws), ws.numel(), stream_ptr()),
+              "wm_bn_sync_bwd_apply")
+        if direct:
+            return (dy, dz) + (None,) * 11
+        return (dy, dz, dgamma, dbeta) + (None,) * 9
+
+
+def sync_batch_norm(y, gamma, beta, running_mean, running_var, residual=None, relu: bool = False, eps: float = 1e-5,
+                    momentum: float = 0.1, groups: Optional[int] = None, stats=None, num_batches_tracked=None,
+                    process_group=None):
+    """Training-mode BatchNorm with statistics over all ranks of `process_group` (see _SyncBatchNorm)."""
+    g = current_bn_groups() if groups is None else groups
+    return _SyncBatchNorm.apply(y, residual, gamma, beta, running_mean, running_var, int(g), float(eps), float(momentum),
+                                bool(relu), stats, num_batches_tracked, process_group)
+
+
 class _BnReluMaxPool(torch.autograd.Function):
     """ResNet stem tail: maxpool3x3s2(relu(BN(y))) without materialising the normalised activation."""
 

@@ -18,13 +18,15 @@ from . import distributed as wdist
 
 class Trainer:
     def __init__(self, max_epochs: int = 1, log_every_n_steps: int = 50, limit_train_batches: Optional[int] = None,
-                 verbose: bool = True, use_graph: bool = False, overlap_grad_sync: bool = True):
+                 verbose: bool = True, use_graph: bool = False, overlap_grad_sync: bool = True,
+                 sync_batchnorm: bool = False):
         self.max_epochs = max_epochs
         self.log_every_n_steps = log_every_n_steps
         self.limit_train_batches = limit_train_batches
         self.verbose = verbose and wdist.rank() == 0
         self.use_graph = use_graph
         self.overlap_grad_sync = overlap_grad_sync
+        self.sync_batchnorm = sync_batchnorm  # the reference's module-level flag (scripts/WM811k_benchmark.py:62,1103)
         self.global_step = 0
         self.current_epoch = 0
         self.history = []
@@ -34,6 +36,8 @@ class Trainer:
         """GraphedTrainStep for this (model, loader) or None when the step cannot be captured."""
         if not (self.use_graph and getattr(model, "graph_safe", False) and hasattr(loader, "iter_indices")):
             return None
+        if self.sync_batchnorm and wdist.world_size() > 1:
+            return None  # a statistics exchange inside every BatchNorm: the step runs eagerly
         if not getattr(loader, "drop_last", False) and len(loader.dataset) % (loader.batch_size * getattr(loader, "world_size", 1)):
             # a captured step has ONE batch shape: a short final batch cannot be replayed (ADVICE r2)
             raise ValueError("Trainer(use_graph=True) needs drop_last=True on the training loader (or a dataset size "
@@ -48,6 +52,10 @@ class Trainer:
     def fit(self, model, train_dataloaders, val_dataloaders=None):
         opts, scheds = model.configure_optimizers()
         opt = opts[0]
+        if self.sync_batchnorm:
+            from .nn import convert_sync_batchnorm
+
+            convert_sync_batchnorm(model)
         sync = wdist.GradSync(opt)
         wdist.broadcast_state(model, opt)  # replicas start from rank 0's weights, buffers, teachers and banks
         if wdist.world_size() > 1 and not getattr(train_dataloaders, "drop_last", True):

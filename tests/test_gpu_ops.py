@@ -27,12 +27,12 @@ def _close(got, ref, rel=8e-3, what="", rms=4e-3, cos=1e-5):
     got, ref = got.float().cpu(), ref.float()
     scale = ref.abs().max().item() + 1e-12
     err = (got - ref).abs().max().item()
-    assert err <= rel * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
     r = ((got - ref).pow(2).mean().sqrt() / (ref.pow(2).mean().sqrt() + 1e-30)).item()
     c = 1.0 - F.cosine_similarity(got.flatten().double(), ref.flatten().double(), dim=0).item()
     RMS_LOG.append((what, r, c))
-    assert r <= rms, f"{what}: relative RMS error {r:.3g} > {rms:.3g}"
-    assert c <= cos, f"{what}: 1 - cosine {c:.3g} > {cos:.3g}"
+    parity(f"{what}: max |err| / max |ref|", err / scale, rel)
+    parity(f"{what}: relative RMS error", r, rms)
+    parity(f"{what}: 1 - cosine", c, cos)
 
 
 # (N, C, H, W, K, R, stride, pad): every distinct conv of ResNet-18 at a small batch + ragged tiles
@@ -288,12 +288,12 @@ def test_resnet18_forward_backward_matches_oracle():
     loss.backward()
     fr = torch.cat([f0, f1]).detach()
     cos = F.cosine_similarity(f.float().cpu(), fr, dim=1)
-    parity("ResNet-18 embeddings vs float32 oracle, bs 64 of 64x64 (1 - cosine, worst row)", float((1 - cos).max()), 1e-3)
+    parity("ResNet-18 embeddings vs float32 oracle, bs 64 of 64x64 (1 - cosine, worst row)", float((1 - cos).max()), 3e-4)  # measured 1.5e-4
     zr = torch.cat([z0, z1]).detach()
     cosz = F.cosine_similarity(z.float().cpu(), zr, dim=1)
-    parity("ResNet-18 + SimCLR head projections vs float32 oracle (1 - cosine, worst row)", float((1 - cosz).max()), 5e-3)
+    parity("ResNet-18 + SimCLR head projections vs float32 oracle (1 - cosine, worst row)", float((1 - cosz).max()), 2.9e-3)  # measured 1.45e-3
     parity("ResNet-18 + head + NT-Xent loss vs float32 oracle, bs 32 of 64x64 (relative)",
-           abs(loss.item() - loss_ref.item()) / loss_ref.item(), 2e-2)
+           abs(loss.item() - loss_ref.item()) / loss_ref.item(), 1e-3)  # measured 4.9e-4
     # gradients: direction agreement per parameter tensor
     # (bf16 activations/gradients through 18 layers at batch 32 of 64x64 images: the stem sees the most rounding noise)
     cosines = {}

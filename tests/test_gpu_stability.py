@@ -140,7 +140,7 @@ def test_bs32_first_steps_track_the_float32_oracle():
     print("hip   ", got)
     print("oracle", want)
     rel = np.abs(np.array(got) - np.array(want)) / np.abs(want)
-    parity("SimCLR bs 32 graph-replayed step 1 loss vs float32 oracle (relative)", rel[0], 2e-3)
+    parity("SimCLR bs 32 graph-replayed step 1 loss vs float32 oracle (relative)", rel[0], 6e-4)  # measured 3.0e-4
     parity("SimCLR bs 32 graph-replayed steps 1-5 loss vs float32 oracle (relative, worst)", rel.max(), 3e-2,
            note="five optimiser steps of bf16-vs-float32 drift")
 
@@ -166,7 +166,7 @@ def test_bs64_whole_step_loss_matches_the_float32_oracle():
         ref, _ = orn.simclr_loss(v[:B], v[B:], sd, 0.5, True)
         rels.append(abs(float(loss.detach()) - float(ref)) / abs(float(ref)))
     print("whole-step loss, relative error vs float32 oracle at bs 64:", rels)
-    parity("SimCLR whole step loss at bs 64 vs float32 oracle (relative, worst of 2 seeds)", max(rels), 1e-3,
+    parity("SimCLR whole step loss at bs 64 vs float32 oracle (relative, worst of 2 seeds)", max(rels), 3e-4,
            note="north_star asks 1e-4: holds at the loss kernel (1e-5); 18 bf16 layers in front of it")
 
 

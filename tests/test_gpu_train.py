@@ -171,7 +171,7 @@ def test_moco_step_matches_oracle_and_keeps_the_bank_order():
     opt.zero_grad()
     loss = model.training_step(batch, 0)
     loss.backward()
-    parity("MoCo step loss vs float32 oracle (relative)", abs(float(loss.detach()) - float(ref)) / abs(float(ref)), 2e-2)
+    parity("MoCo step loss vs float32 oracle (relative)", abs(float(loss.detach()) - float(ref)) / abs(float(ref)), 2e-4)  # measured 9.8e-5
     assert int(model.criterion.bank_ptr) == 2 * b
     got_bank = model.criterion.bank.cpu()
     cos = torch.nn.functional.cosine_similarity(got_bank[:, :2 * b].T, bank[:, :2 * b].T, dim=1)
@@ -231,7 +231,7 @@ def test_siamese_steps_match_oracle(name):
     opt.zero_grad()
     loss = model.training_step(batch, 0)
     loss.backward()
-    parity(f"{name} step loss vs float32 oracle (absolute; -cosine in [-1, 1])", abs(float(loss.detach()) - float(ref)), 2e-2 * abs(float(ref)) + 2e-3)
+    parity(f"{name} step loss vs float32 oracle (absolute; -cosine in [-1, 1])", abs(float(loss.detach()) - float(ref)), 6e-4)  # measured 3.1e-4 (simsiam), 2.1e-4 (byol)
     first = float(loss.detach())
     for i in range(6):
         opt.step()
@@ -297,7 +297,7 @@ def test_barlow_twins_step_matches_oracle_and_lars_moves_it():
     opt.zero_grad()
     loss = model.training_step(batch, 0)
     loss.backward()
-    parity("Barlow Twins step loss vs float32 oracle (relative)", abs(float(loss.detach()) - float(ref)) / abs(float(ref)), 5e-2)
+    parity("Barlow Twins step loss vs float32 oracle (relative)", abs(float(loss.detach()) - float(ref)) / abs(float(ref)), 2e-4)  # measured 1.0e-4
     first = float(loss.detach())
     for grp in opt.param_groups:
         grp["lr"] = 0.2  # past the warm-up factor of epoch 0
@@ -338,7 +338,7 @@ def test_swav_step_runs_and_matches_oracle_loss():
     loss.backward()
     opt.step()
     # exp(score / 0.05) amplifies the bf16 encoder's score error 20-fold inside Sinkhorn
-    parity("SwaV step loss vs float32 oracle (relative)", abs(float(loss.detach()) - float(ref)) / abs(float(ref)), 5e-2)
+    parity("SwaV step loss vs float32 oracle (relative)", abs(float(loss.detach()) - float(ref)) / abs(float(ref)), 1e-4)  # measured 4.7e-5
     norms = model.prototypes.layers.weight.detach().norm(dim=1)
     assert norms.shape == (3000,)
 

@@ -24,7 +24,7 @@ def _close(got, ref, rel=1e-2, what=""):
     got, ref = got.float().cpu(), ref.float().cpu()
     scale = ref.abs().max().item() + 1e-12
     err = (got - ref).abs().max().item()
-    assert err <= rel * scale, f"{what}: max err {err:.4g} vs scale {scale:.4g}"
+    parity(f"{what}: max |err| / max |ref|", err / scale, rel)
 
 
 def _cos(a, b):
@@ -332,6 +332,49 @@ def test_vit_features_and_gradients_match_oracle(size):
     assert worst > 0.98
 
 
+@pytest.mark.parametrize("arch", ["vit_small_16", "vit_b_32"])
+def test_full_depth_forward_matches_oracle(arch):
+    """All 12 blocks of the two encoders BASELINE.json names (ViT-S/16: DINO / MSN / MAE configs[3]; ViT-B/32: the
+    reference's MAE / SimMIM encoder, scripts/WM811k_benchmark.py:876-957), batch 2, every token kept.  The bf16
+    residual stream's rounding accumulates over depth, so this is the case the 2- and 3-block tests cannot vouch for;
+    bound: 1e-3 cosine on every token of the encoder output, float32 oracle on the CPU."""
+    from oracle import vit as ov
+    from ssl_wafermap_amd import ops
+
+    torch.manual_seed(0)
+    g = torch.Generator().manual_seed(12)
+    x = _bf(torch.randn(2, 3, 224, 224, generator=g))
+    if arch == "vit_small_16":
+        from ssl_wafermap_amd.models.vit import vit_small
+
+        m = vit_small(16)
+        assert len(m.blocks) == 12
+    else:
+        from ssl_wafermap_amd.models.mae import MAEBackbone
+
+        m = MAEBackbone(224, 32, 12, 12, 768, 3072)
+        assert len(m.encoder.layers) == 12
+    with torch.no_grad():  # break the symmetry of zero biases / unit LayerNorms / zero class token
+        for p_ in m.parameters():
+            if p_.dim() == 1 or p_.shape[:2] == (1, 1):
+                p_.add_(torch.randn_like(p_) * 0.05)
+    m = m.to(DEV).eval()
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        if arch == "vit_small_16":
+            ref = ov.vit_features(x, sd, heads=6)                                  # [2, 384] class-token feature
+            got = m(ops.to_nhwc_bf16(x.to(DEV))).float().cpu()
+        else:
+            ref = ov.mae_encode(x, {"backbone." + k: v for k, v in sd.items()}, None, heads=12)  # [2, 50, 768]
+            got = m.encode(ops.to_nhwc_bf16(x.to(DEV))).float().cpu()
+    assert got.shape == ref.shape
+    rows_g, rows_r = got.reshape(-1, got.shape[-1]), ref.reshape(-1, ref.shape[-1])
+    worst = min(_cos(a, b) for a, b in zip(rows_g, rows_r))
+    rel = float((got - ref).norm() / ref.norm())
+    parity(f"{arch} full depth (12 blocks, batch 2) forward vs float32 oracle (1 - cosine, worst token)", 1 - worst, 1.7e-4)  # measured 6.8e-5 (ViT-S/16), 8.5e-5 (ViT-B/32); SURVEY 8d asks 1e-3
+    parity(f"{arch} full depth (12 blocks, batch 2) forward vs float32 oracle (relative L2)", rel, 2.3e-2)  # measured 1.16e-2 / 1.14e-2
+
+
 def test_dino_head_matches_oracle_with_per_view_batchnorm():
     from oracle import vit as ov
     from ssl_wafermap_amd import heads, ops
@@ -407,7 +450,8 @@ def test_dino_training_step_matches_oracle_and_learns(preset):
     opt.zero_grad()
     loss = model.training_step(batch, 0)
     loss.backward()
-    parity(f"DINO step loss vs float32 oracle [{preset}] (relative)", abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)), 5e-3)
+    parity(f"DINO step loss vs float32 oracle [{preset}] (relative)", abs(float(loss) - float(ref_loss)) / abs(float(ref_loss)),
+           {"vit_small_2blocks": 1.8e-4, "vit_tiny": 4.2e-4}[preset])  # measured 9.0e-5 / 2.1e-4
     pairs = [("backbone." + k, p_.grad, s_bb[k].grad) for k, p_ in model.backbone.named_parameters()]
     for k, p_ in model.head.named_parameters():
         if p_.requires_grad:
@@ -425,7 +469,8 @@ def test_dino_training_step_matches_oracle_and_learns(preset):
     med = float(np.median([c for c, _ in cos]))
     # bf16 activations + bf16 probabilities in attention against a float32 oracle; the rounding noise of the
     # activation gradients accumulates with depth (12 blocks of ViT-Tiny: median 0.96, worst 0.94 measured)
-    lo_worst, lo_med = (0.85, 0.94) if preset == "vit_tiny" else (0.9, 0.98)
+    # measured: tiny 0.9262 (blocks.9.norm1.bias, a near-zero gradient at random init) / 0.9491; small 0.9952 / 0.9979
+    lo_worst, lo_med = (0.853, 0.94) if preset == "vit_tiny" else (0.9904, 0.9959)
     parity(f"DINO parameter gradients vs float32 oracle [{preset}] (cosine, worst tensor {worst[1]})", worst[0], lo_worst, higher=True)
     parity(f"DINO parameter gradients vs float32 oracle [{preset}] (cosine, median)", med, lo_med, higher=True)
     # teacher moved by the EMA
@@ -492,13 +537,14 @@ def test_mae_training_step_matches_oracle_and_learns(preset):
     loss = model.criterion(pred, target)
     loss.backward()
     parity(f"MAE step loss vs float32 oracle [{preset}] (relative)",
-           abs(float(loss.detach()) - float(ref.detach())) / abs(float(ref.detach())), 5e-3)
+           abs(float(loss.detach()) - float(ref.detach())) / abs(float(ref.detach())),
+           {"vit_b_32_2blocks": 3.6e-5, "vit_small_16": 6.6e-4}[preset])  # measured 1.8e-5 / 3.3e-4
     pairs = [(k, p_.grad, sd[k].grad) for k, p_ in model.named_parameters()]
     top = max(float(r.norm() / math.sqrt(r.numel())) for _, _, r in pairs)
     cos = [(_cos(a, r), k) for k, a, r in pairs if float(r.norm() / math.sqrt(r.numel())) > 1e-3 * top]
     worst, med = min(cos), float(np.median([c for c, _ in cos]))
-    parity(f"MAE parameter gradients vs float32 oracle [{preset}] (cosine, worst tensor)", worst[0], 0.9, higher=True)
-    parity(f"MAE parameter gradients vs float32 oracle [{preset}] (cosine, median)", med, 0.98, higher=True)
+    parity(f"MAE parameter gradients vs float32 oracle [{preset}] (cosine, worst tensor)", worst[0], 0.9998, higher=True)  # measured 0.99994 / 0.99990
+    parity(f"MAE parameter gradients vs float32 oracle [{preset}] (cosine, median)", med, 0.99992, higher=True)  # measured 0.99997 / 0.99996
 
     (opt,), _ = model.configure_optimizers()
     for grp in opt.param_groups:
