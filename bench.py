@@ -296,6 +296,9 @@ def main():
     ap.add_argument("--no-kernel-timer", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="do not capture the step into hipGraphs")
     ap.add_argument("--no-overlap", action="store_true", help="N > 1: one graph + one exposed all-reduce (no stages)")
+    ap.add_argument("--sharded", action="store_true",
+                    help="knn_allpairs: the bank stays row-sharded (no all-gather of the embeddings); every step all-gathers "
+                         "the ranks' query batches, searches the local shard and merges the per-rank top-k lists")
     args = ap.parse_args()
 
     import numpy as np
@@ -381,6 +384,44 @@ def main():
         lo, hi = rank * per, min(KNN_N, (rank + 1) * per)
         g = torch.Generator(device=dev).manual_seed(7 + rank)
         shard = torch.nn.functional.normalize(torch.randn(hi - lo, KNN_D, generator=g, device=dev), dim=1).bfloat16()
+        if args.sharded:
+            # the memory-scalable form (distributed.sharded_knn_topk, what KNNBenchmarkModule uses when the bank does not
+            # fit one GPU): per step one all-gather of the query batches [world * bq, d], a local top-k against the shard
+            # with global indices, one all-gather of the [world * bq, k] candidate lists, merge (wm_knn_merge)
+            def sstep(i):
+                o = (i * bq) % max(hi - lo - bq, 1)
+                q = shard[o:o + bq].contiguous()
+                if world > 1:
+                    qs = [torch.empty_like(q) for _ in range(world)]
+                    dist.all_gather(qs, q)
+                    q = torch.cat(qs)
+                return wdist.sharded_knn_topk(q, shard, KNN_K, lo)
+
+            dt, gpu_ms, (sim, idx) = timed(sstep, args.warmup, args.steps)
+            mine = sim[rank * bq:(rank + 1) * bq]
+            if not (bool((mine[:, 0] > 0.99).all()) and bool((sim[:, :-1] >= sim[:, 1:]).all())):
+                raise SystemExit("knn_allpairs --sharded: self-retrieval / sortedness check failed")
+            qps = bq * world * args.steps / dt
+            us = gpu_ms * 1e3
+            nq = bq * world
+            bytes_ = (hi - lo) * KNN_D * 2 + nq * KNN_D * 2 + nq * KNN_K * 8   # per rank and step
+            hbm = nq <= 256
+            ach = bytes_ / us / 1e3 if hbm else 2.0 * nq * (hi - lo) * KNN_D / us / 1e6
+            finish({"metric": "queries/sec (all-pairs cosine kNN top-8, 811457 x 128 bf16)", "value": round(qps, 1),
+                    "unit": "queries/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                    "ms_per_step": round(1e3 * dt / args.steps, 4), "gpu_ms_per_step": round(gpu_ms, 4),
+                    "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+                    "config": {"workload": f"all-pairs kNN top-{KNN_K}, {KNN_N} x {KNN_D} bf16 rows sharded over {world} ranks, bank "
+                                           f"kept sharded: per step all-gather of {world} x {bq} queries, local top-k, all-gather "
+                                           "of the candidate lists, merge (BASELINE.json configs[4])",
+                               "sharded": True, "queries_per_step_per_gpu": bq, "bank_rows_per_gpu": hi - lo,
+                               "allpairs_extrapolated_s": round(KNN_N / qps, 3),
+                               "curve": "unmeasured beyond the GPUs of this run (the driver's SCALE runs use the default form)"},
+                    "roofline": {"bound": "hbm" if hbm else "mfma", "kernel": "knn_stream_b128 + knn_select + knn_merge_lists",
+                                 "achieved": round(ach, 1), "peak": HBM_PEAK_GBS if hbm else MFMA_BF16_PEAK_TFLOPS,
+                                 "unit": "GB/s" if hbm else "TFLOP/s",
+                                 "frac": round(ach / (HBM_PEAK_GBS if hbm else MFMA_BF16_PEAK_TFLOPS), 4), "traffic": None}})
+            return
         if world > 1:   # the one exchange of the path: every rank ends up with the whole 208-MB bank
             pad = torch.zeros(per, KNN_D, dtype=torch.bfloat16, device=dev)
             pad[: hi - lo] = shard

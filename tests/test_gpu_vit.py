@@ -119,7 +119,11 @@ def test_bias_act(rows, c, act, res):
 
 
 @pytest.mark.parametrize("rows,c,k,res", [(591, 384, 1152, False), (100, 768, 3072, False), (1000, 1536, 384, True),
-                                           (37, 512, 512, True), (5000, 384, 384, False), (64, 256, 2048, False)])
+                                           (37, 512, 512, True), (5000, 384, 384, False), (64, 256, 2048, False),
+                                           # 192-wide reductions: the register-resident panel kernel (csrc/panel.hip),
+                                           # forward when c = 192, input gradient when k = 192
+                                           (300, 192, 576, False), (5000, 192, 192, True), (131, 192, 768, False),
+                                           (1000, 768, 192, True), (25216, 192, 576, False)])
 def test_linear_bias_gradient_rides_in_wgrad(rows, c, k, res):
     from ssl_wafermap_amd import vit_ops
 
@@ -762,3 +766,47 @@ def test_fused_mlp_forward_is_bit_identical_to_the_two_launch_path(rows, with_re
     if with_res:
         ref = ref + res.float()
     assert float((y_f.float() - ref).abs().max()) <= 2e-2 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("rows,n,mode", [(128, 576, "bias"), (300, 192, "bias_res"), (4928, 768, "gelu"), (37, 768, "dgelu"),
+                                         (25216, 576, "plain"), (1000, 192, "dgrad_res")])
+def test_panel_linear_is_bit_identical_to_the_tiled_kernel(rows, n, mode, monkeypatch):
+    """csrc/panel.hip (192-wide reductions: token rows in registers, weight tiles streamed) against conv_igemm's EPI
+    instantiations on the same inputs: same k order, MFMA shape and bf16 roundings -> equal to the last bit, for every
+    epilogue (bias, residual, GELU + saved pre-activation, gelu'(pre) on the input gradient)."""
+    from ssl_wafermap_amd import _lib
+    from ssl_wafermap_amd._lib import check, ptr
+
+    lib = _lib.load()
+    st = torch.cuda.current_stream().cuda_stream
+    g = torch.Generator(device=DEV).manual_seed(rows + n)
+    x = torch.randn(rows, 192, generator=g, device=DEV).bfloat16()
+    w = (torch.randn(n, 192, generator=g, device=DEV) * 0.07).bfloat16()
+    bias = torch.randn(n, generator=g, device=DEV)
+    res = torch.randn(rows, n, generator=g, device=DEV).bfloat16()
+    pre_in = torch.randn(rows, n, generator=g, device=DEV).bfloat16()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("WM_LINEAR_PANEL", flag)
+        y = torch.full((rows, n), float("nan"), device=DEV).bfloat16()
+        pre = torch.full((rows, n), float("nan"), device=DEV).bfloat16()
+        geom = (rows, 1, 1, 192, n, 1, 1, 1, 1, 1, 0)
+        if mode == "bias":
+            check(lib.wm_conv2d_fwd_bias_res(ptr(x), ptr(w), ptr(bias), 0, ptr(y), *geom, st), "f")
+        elif mode == "bias_res":
+            check(lib.wm_conv2d_fwd_bias_res(ptr(x), ptr(w), ptr(bias), ptr(res), ptr(y), *geom, st), "f")
+        elif mode == "plain":
+            check(lib.wm_conv2d_fwd(ptr(x), ptr(w), ptr(y), *geom, st), "f")
+        elif mode == "gelu":
+            check(lib.wm_linear_bias_gelu_fwd(ptr(x), ptr(w), ptr(bias), ptr(pre), ptr(y), rows, 192, n, st), "g")
+        elif mode == "dgelu":   # dy [rows][192] . w_crsk [n][192] -> dx [rows][n], times gelu'(pre)
+            check(lib.wm_linear_dgrad_gelu(ptr(x), ptr(w), ptr(pre_in), ptr(y), rows, n, 192, st), "dg")
+        else:                   # input gradient + the shortcut's gradient
+            dgeom = (rows, 1, 1, n, 192, 1, 1, 1, 1, 1, 0)
+            check(lib.wm_conv2d_dgrad_add(ptr(x), ptr(w), ptr(res), ptr(y), *dgeom, st), "d")
+        torch.cuda.synchronize()
+        outs.append((y.clone(), pre.clone()))
+    assert not torch.isnan(outs[0][0].float()).any()
+    assert torch.equal(outs[0][0], outs[1][0])
+    if mode == "gelu":
+        assert torch.equal(outs[0][1], outs[1][1])
