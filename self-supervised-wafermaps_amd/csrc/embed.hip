@@ -37,10 +37,11 @@ __global__ __launch_bounds__(256) void l2norm_fwd(const TIn* __restrict__ x, int
   if (inv_norm && lane == 0) inv_norm[row] = 1.0f / denom;
 }
 
+template <typename TO>
 __global__ __launch_bounds__(256) void l2norm_bwd(const float* __restrict__ dy,
                                                   const float* __restrict__ y,
                                                   const float* __restrict__ inv_norm, int rows,
-                                                  int d, float* __restrict__ dx) {
+                                                  int d, TO* __restrict__ dx, const float* __restrict__ scale) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
@@ -49,8 +50,13 @@ __global__ __launch_bounds__(256) void l2norm_bwd(const float* __restrict__ dy,
   float dot = 0.f;
   for (int c = lane; c < d; c += 64) dot += dyr[c] * yr[c];
   dot = wave_sum(dot);
-  const float s = inv_norm[row];
-  for (int c = lane; c < d; c += 64) dx[(size_t)row * d + c] = (dyr[c] - yr[c] * dot) * s;
+  // scale: the (device) gradient of the scalar loss this normalisation feeds -- dy is then the unscaled gradient
+  const float s = inv_norm[row] * (scale != nullptr ? *scale : 1.f);
+  for (int c = lane; c < d; c += 64) {
+    const float v = (dyr[c] - yr[c] * dot) * s;
+    if constexpr (sizeof(TO) == 2) dx[(size_t)row * d + c] = f2bf(v);
+    else dx[(size_t)row * d + c] = v;
+  }
 }
 
 // ------------------------------------------------------------------ NT-Xent
@@ -295,10 +301,15 @@ extern "C" int wm_l2_normalize(const void* x, int in_dtype, int rows, int d, flo
 }
 
 extern "C" int wm_l2_normalize_bwd(const float* dy, const float* y, const float* inv_norm, int rows,
-                                   int d, float* dx, void* stream) {
+                                   int d, void* dx, int out_dtype, const float* scale_dev, void* stream) {
   WM_REQUIRE(dy && y && inv_norm && dx, WM_EINVAL);
   WM_REQUIRE(rows > 0 && d > 0, WM_EINVAL);
-  l2norm_bwd<<<wm_cdiv(rows, 4), 256, 0, static_cast<hipStream_t>(stream)>>>(dy, y, inv_norm, rows, d, dx);
+  WM_REQUIRE(out_dtype == WM_F32 || out_dtype == WM_BF16, WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (out_dtype == WM_F32)
+    l2norm_bwd<float><<<wm_cdiv(rows, 4), 256, 0, st>>>(dy, y, inv_norm, rows, d, static_cast<float*>(dx), scale_dev);
+  else
+    l2norm_bwd<uint16_t><<<wm_cdiv(rows, 4), 256, 0, st>>>(dy, y, inv_norm, rows, d, static_cast<uint16_t*>(dx), scale_dev);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

@@ -209,9 +209,10 @@ class _L2Normalize(torch.autograd.Function):
     def backward(ctx, dy):
         y, inv = ctx.saved_tensors
         dy = dy.contiguous().float()
-        dx = torch.empty_like(y)
-        check(_lib.load().wm_l2_normalize_bwd(ptr(dy), ptr(y), ptr(inv), y.shape[0], y.shape[1], ptr(dx),
-                                              stream_ptr()), "wm_l2_normalize_bwd")
+        out_dtype = ctx.in_dtype if ctx.in_dtype in (torch.float32, torch.bfloat16) else torch.float32
+        dx = torch.empty(y.shape, dtype=out_dtype, device=y.device)   # written in the input's dtype: no cast pass
+        check(_lib.load().wm_l2_normalize_bwd(ptr(dy), ptr(y), ptr(inv), y.shape[0], y.shape[1], ptr(dx), dtype_code(dx),
+                                              0, stream_ptr()), "wm_l2_normalize_bwd")
         return dx.to(ctx.in_dtype), None
 
 

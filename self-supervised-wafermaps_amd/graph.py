@@ -86,10 +86,17 @@ class GraphedTrainStep:
     def _body(self):
         """The whole step eagerly (warm-up; also the unstaged graph's body)."""
         loss, cuts = self._forward()
-        loss.backward()
+        self._backward(loss)
         for _, x, leaf in reversed(cuts):
             x.backward(leaf.grad)
         return loss
+
+    def _backward(self, loss):
+        """loss.backward() with a persistent unit gradient (torch would launch a ones_like fill per step)."""
+        one = getattr(self, "_one", None)
+        if one is None or one.dtype != loss.dtype or one.device != loss.device or one.shape != loss.shape:
+            one = self._one = torch.ones_like(loss.detach())
+        loss.backward(one)
 
     def _stage_bounds(self, cuts):
         """Arena offset of the first parameter of the module that follows each cut (None: not a single flat arena,
@@ -173,7 +180,7 @@ class GraphedTrainStep:
         else:
             with torch.cuda.graph(g0, capture_error_mode="thread_local"):
                 self.loss, cuts = self._forward()
-                self.loss.backward()
+                self._backward(self.loss)
             self.graphs = [g0]
             self._cuts = cuts   # keeps the stage-boundary activations and their gradients alive in the pool
             for _, x, leaf in reversed(cuts):

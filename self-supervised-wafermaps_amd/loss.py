@@ -51,6 +51,70 @@ class _NTXentCore(torch.autograd.Function):
         return dzn * grad_out, None, None, None
 
 
+class _NTXentProjections(torch.autograd.Function):
+    """L2 normalisation + NT-Xent on the STACKED projections z [2 b, d] (view-major, bf16 or float32) as one autograd
+    node: what `NTXentLoss.forward(z[:b], z[b:])` computes, without the slice / cat / cast round trip of two separately
+    passed halves (per step: a cat, a cast, two zero-filled gradient buffers, two copies and an add from autograd's
+    slice backward), and with the loss's incoming gradient applied inside the normalisation's backward kernel."""
+
+    @staticmethod
+    def forward(ctx, z, b_local, temperature, gather):
+        from . import _lib
+        from ._lib import check, ptr, stream_ptr
+
+        _lib.require_gpu(z)
+        z = z.contiguous()
+        rows, d = z.shape
+        zn = torch.empty((rows, d), dtype=torch.float32, device=z.device)
+        inv = torch.empty((rows,), dtype=torch.float32, device=z.device)
+        check(_lib.load().wm_l2_normalize(ptr(z), _lib.dtype_code(z), rows, d, 1e-12, ptr(zn), _lib.WM_F32, ptr(inv),
+                                          stream_ptr()), "wm_l2_normalize")
+        world = _world() if gather else 1
+        rank = dist.get_rank() if world > 1 else 0
+        b_global = b_local * world
+        zall = torch.cat([_all_gather_rows(zn[:b_local]), _all_gather_rows(zn[b_local:])], dim=0) if world > 1 else zn
+        lse, rows_loss = F_hip.ntxent_forward(zn, zall, b_local, b_global, rank * b_local, temperature)
+        lse_all = torch.cat([_all_gather_rows(lse[:b_local]), _all_gather_rows(lse[b_local:])], dim=0) if world > 1 else lse
+        ctx.save_for_backward(zn, inv, zall, lse_all)
+        ctx.meta = (b_local, b_global, rank * b_local, temperature, z.dtype)
+        return F_hip.vector_mean(rows_loss)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        from . import _lib
+        from ._lib import check, ptr, stream_ptr
+
+        zn, inv, zall, lse_all = ctx.saved_tensors
+        b_local, b_global, off, temperature, in_dtype = ctx.meta
+        dzn = F_hip.ntxent_backward(zn, zall, lse_all, b_local, b_global, off, temperature, 1.0 / (2 * b_local))
+        out_dtype = in_dtype if in_dtype in (torch.float32, torch.bfloat16) else torch.float32
+        dz = torch.empty(zn.shape, dtype=out_dtype, device=zn.device)
+        g = grad_out.detach().reshape(-1).to(torch.float32)
+        check(_lib.load().wm_l2_normalize_bwd(ptr(dzn), ptr(zn), ptr(inv), zn.shape[0], zn.shape[1], ptr(dz),
+                                              _lib.dtype_code(dz), ptr(g), stream_ptr()), "wm_l2_normalize_bwd")
+        return dz.to(in_dtype), None, None, None
+
+
+def stacked_views(z: torch.Tensor, b: int):
+    """(z[:b], z[b:]) of the projections of two views computed in ONE pass, each half remembering the stacked tensor: a
+    loss that is handed exactly these two objects (NTXentLoss without a memory bank) works on `z` itself."""
+    z0, z1 = z[:b], z[b:]
+    z0._hip_stacked = z1._hip_stacked = z
+    return z0, z1
+
+
+def _stacked_parent(out0: torch.Tensor, out1: torch.Tensor):
+    p = getattr(out0, "_hip_stacked", None)
+    if p is None or p is not getattr(out1, "_hip_stacked", None) or not p.is_cuda:
+        return None
+    b = out0.shape[0]
+    if p.dim() != 2 or p.shape[0] != 2 * b or out1.shape[0] != b or not p.is_contiguous():
+        return None
+    if out0.data_ptr() != p.data_ptr() or out1.data_ptr() != p.data_ptr() + b * p.shape[1] * p.element_size():
+        return None
+    return p
+
+
 class _NTXentBank(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, bank, temperature):
@@ -249,6 +313,9 @@ class NTXentLoss(nn.Module):
             if out0.requires_grad:
                 self._dequeue_and_enqueue(k.detach())                     # ... before this call's keys enter it
             return loss
+        parent = _stacked_parent(out0, out1)
+        if parent is not None and parent.dtype in (torch.float32, torch.bfloat16):
+            return _NTXentProjections.apply(parent, b, self.temperature, self.gather_distributed)
         z = torch.cat([out0, out1], dim=0).float().contiguous()
         zn = F_hip.l2_normalize(z)
         return _NTXentCore.apply(zn, b, self.temperature, self.gather_distributed)

@@ -5,7 +5,7 @@ from __future__ import annotations
 import torch
 
 from .. import heads, ops, optim
-from ..loss import NTXentLoss
+from ..loss import NTXentLoss, stacked_views
 from ..utils import debug
 from .knn import KNNBenchmarkModule
 from .resnet import create_model
@@ -47,7 +47,7 @@ class SimCLR(KNNBenchmarkModule):
         # z0 = forward(x0); z1 = forward(x1)
         with ops.bn_groups(2):
             z = self.forward(stacked)
-        loss = self.criterion(z[:b], z[b:])
+        loss = self.criterion(*stacked_views(z, b))
         self.log("train_loss_ssl", loss)
         return loss
 

@@ -17,7 +17,8 @@ def std_of_l2_normalized(z: torch.Tensor) -> torch.Tensor:
     rows, c = zn.shape
     if rows < 2 or not zn.is_cuda:
         return torch.std(zn.float(), dim=0).mean()
-    stats = torch.zeros(2, c, dtype=torch.float32, device=zn.device)
+    stats = torch.empty(2, c, dtype=torch.float32, device=zn.device)   # (the kernel accumulates: cleared by our own fill)
+    check(_lib.load().wm_fill_zero(ptr(stats), stats.numel() * 4, stream_ptr()), "wm_fill_zero")
     check(_lib.load().wm_colstats(ptr(zn), dtype_code(zn), rows, c, ptr(stats[0]), ptr(stats[1]), stream_ptr()),
           "wm_colstats")
     return F_hip.vector_mean(stats[1], scale=rows / (rows - 1.0), sqrt_of=True)

@@ -257,7 +257,8 @@ def _barlow_gather_case(rank, world, out_path):
     loss.backward()
     both = [torch.empty(1, device="cuda:0") for _ in range(world)]
     dist.all_gather(both, loss.detach().reshape(1))
-    assert torch.equal(both[0], both[1]), "the all-reduced correlation matrix gives every rank the same loss"
+    # every rank evaluates the loss on the same all-reduced matrix (its scalar is an atomically summed f32: last bits)
+    assert abs(float(both[0]) - float(both[1])) <= 1e-6 * abs(float(both[0])), (float(both[0]), float(both[1]))
     local = BarlowTwinsLoss(gather_distributed=False).to("cuda:0")(ad.detach(), bd.detach())
     assert abs(float(local) - float(loss.detach())) > 1e-3 * abs(float(loss.detach())), "gathered == local loss?"
     ca = torch.nn.functional.cosine_similarity(ad.grad.float().cpu().flatten(), ar.grad.flatten(), dim=0)

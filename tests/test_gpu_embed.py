@@ -731,3 +731,30 @@ def test_random_token_mask_on_device_equals_argsort():
     assert keep.shape == (6, 12) and mask.shape == (6, 38) and bool((keep[:, 0] == 0).all())
     both = torch.cat([keep, mask], dim=1).sort(dim=1).values
     assert torch.equal(both, torch.arange(50, device=DEV).expand(6, 50))
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16, torch.float32])
+def test_ntxent_on_stacked_views_equals_the_two_argument_form(dtype):
+    """SimCLR hands NTXentLoss the two halves of ONE stacked projection tensor (loss.stacked_views): the loss then
+    works on the stacked tensor as a single autograd node.  Same loss and the same projection gradient, to the bit,
+    as passing two unrelated tensors (cat + cast + two separate normalisations' worth of autograd nodes)."""
+    from ssl_wafermap_amd.loss import NTXentLoss, stacked_views
+
+    g = torch.Generator().manual_seed(3)
+    b, d = 96, 128
+    z = torch.randn(2 * b, d, generator=g).to(DEV).to(dtype)
+    crit = NTXentLoss(temperature=0.5)
+    za = z.clone().requires_grad_(True)
+    la = crit(*stacked_views(za, b))
+    assert type(la.grad_fn).__name__ == "_NTXentProjectionsBackward"
+    la.backward()
+    zb = z.clone().requires_grad_(True)
+    lb = crit(zb[:b], zb[b:])
+    assert type(lb.grad_fn).__name__ != "_NTXentProjectionsBackward"
+    lb.backward()
+    assert torch.equal(la.detach(), lb.detach())
+    assert torch.equal(za.grad, zb.grad)
+    # an upstream gradient other than 1 is applied inside the normalisation's backward kernel
+    zc = z.clone().requires_grad_(True)
+    (crit(*stacked_views(zc, b)) * 0.25).backward()
+    torch.testing.assert_close(zc.grad.float(), za.grad.float() * 0.25, rtol=1e-2 if dtype == torch.bfloat16 else 1e-6, atol=1e-9)
