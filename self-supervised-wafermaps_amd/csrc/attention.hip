@@ -26,6 +26,7 @@
 // Roofline: MFMA-issue/LDS bound, but ~8 % of a ViT-S block's FLOPs (4 S^2 64 per head vs the
 // 24 S 384^2 of its four Linear layers at S = 197): correctness first, tuning later.
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -311,6 +312,200 @@ __global__ __launch_bounds__(AT_BWD_THREADS) void attn_bwd(const uint16_t* __res
   }
 }
 
+// Backward for the LONG sequences (197 tokens: NT = 14), split by ROLE: blockIdx.y = 0 computes dQ (pass A above),
+// blockIdx.y = 1 computes dK / dV (pass B).  attn_bwd holds all four operands of a head in LDS -- 129 KB at 224 padded
+// rows, ONE block per CU, so ViT-Tiny's 384 (image, head) pairs run as two rounds on 256 CUs with the second half
+// empty (101 us per launch).  A role needs only TWO operands resident (dQ: K and V; dK / dV: Q and dO -- its own strips
+// come straight from global memory as MFMA fragments, prefetched one strip ahead): 66 KB, two blocks per CU, twice
+// the blocks.  Same MFMA work in total (both passes recompute S and dP anyway), same staging traffic.
+template <int NT, int HD>
+__global__ __launch_bounds__(AT_BWD_THREADS, 2) void attn_bwd_roles(const uint16_t* __restrict__ qkv, const uint16_t* __restrict__ out,
+                                                             const uint16_t* __restrict__ dout, const float* __restrict__ lse,
+                                                             int S, int H, float scale, uint16_t* __restrict__ dqkv) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t at_smem[];
+  constexpr int SP = NT * 16;
+  uint8_t* s0 = at_smem;                       // role 0: K      role 1: Q
+  uint8_t* s1 = s0 + SP * AT_ROWB;             // role 0: V      role 1: dO
+  float* s_lse = reinterpret_cast<float*>(s1 + SP * AT_ROWB);
+  float* s_delta = s_lse + SP;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const int role = blockIdx.y;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int fr = lane & 15, fg = lane >> 4;
+  constexpr int KS = HD / 32, DJ = HD / 16, CPR = HD / 8, NW = AT_BWD_THREADS / 64;
+  const size_t rs = (size_t)3 * H * HD, os = (size_t)H * HD;
+  const uint16_t* base = qkv + (size_t)b * S * rs + h * HD;
+  const uint16_t* obase = out + (size_t)b * S * os + h * HD;
+  const uint16_t* dobase = dout + (size_t)b * S * os + h * HD;
+  const float* lse_bh = lse + ((size_t)b * H + h) * S;
+  uint16_t* dq_base = dqkv + (size_t)b * S * rs + h * HD;
+
+  if (role == 0) {
+    // ---- dQ by query strips; K, V resident
+    bf16x8_t qn[KS], dn[KS], on[KS];   // the NEXT strip's fragments (requested before the current strip's MFMAs)
+    auto fetch = [&](int qs) {
+      const int q = qs * 16 + fr;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        qn[ks] = frag_global(base, rs, q, S, ks, fg);
+        dn[ks] = frag_global(dobase, os, q, S, ks, fg);
+        on[ks] = frag_global(obase, os, q, S, ks, fg);
+      }
+    };
+    fetch(wave);
+    stage_rows<HD>(base + (size_t)H * HD, rs, S, SP, s0);
+    stage_rows<HD>(base + (size_t)2 * H * HD, rs, S, SP, s1);
+    __syncthreads();
+    for (int qs = wave; qs < NT; qs += NW) {
+      const int q = qs * 16 + fr;
+      bf16x8_t qf[KS], df[KS];
+      float dl = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        qf[ks] = qn[ks];
+        df[ks] = dn[ks];
+        // delta[q] = sum_d dO[q][d] O[q][d]: this lane's 8 elements per k-slab, then the four lanes of the row
+#pragma unroll
+        for (int e = 0; e < 8; ++e) dl = fmaf((float)dn[ks][e], (float)on[ks][e], dl);
+      }
+      dl = wm_xor32_sum(wm_xor16_sum(dl));
+      const float lq = q < S ? lse_bh[q] : 0.f;
+      if (qs + NW < NT) fetch(qs + NW);
+      bf16x8_t dsf[NT / 2];
+#pragma unroll
+      for (int kk = 0; kk < NT / 2; ++kk) {
+        f32x4_t ds2[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int t = 2 * kk + u;
+          f32x4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int ks = 0; ks < KS; ++ks) {
+            a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(s0, t * 16 + fr, ks, fg), qf[ks], a, 0, 0, 0);
+            dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(s1, t * 16 + fr, ks, fg), df[ks], dp, 0, 0, 0);
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const int key = t * 16 + 4 * fg + e;
+            const float p = key < S ? expf(a[e] * scale - lq) : 0.f;
+            ds2[u][e] = p * (dp[e] - dl) * scale;
+          }
+        }
+        dsf[kk] = pack_slots(ds2[0], ds2[1]);
+        __builtin_amdgcn_sched_barrier(0);   // keep the next tile pair's fragment reads behind this one's MFMAs (registers)
+      }
+      f32x4_t dq[DJ];
+#pragma unroll
+      for (int j = 0; j < DJ; ++j) dq[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int kk = 0; kk < NT / 2; ++kk)
+#pragma unroll
+        for (int j = 0; j < DJ; ++j)
+          dq[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(s0, kk * 32, j, lane), dsf[kk], dq[j], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q < S) {
+        uint16_t* dst = dq_base + (size_t)q * rs + 4 * fg;
+#pragma unroll
+        for (int j = 0; j < DJ; ++j)
+          *reinterpret_cast<uint2*>(dst + j * 16) = make_uint2(pack_bf2(dq[j][0], dq[j][1]), pack_bf2(dq[j][2], dq[j][3]));
+      }
+    }
+    return;
+  }
+
+  // ---- dK, dV by key strips; Q, dO (and lse, delta of every query) resident
+  bf16x8_t kn[KS], vn[KS];
+  auto fetch_kv = [&](int ksn) {
+    const int key = ksn * 16 + fr;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kn[ks] = frag_global(base + (size_t)H * HD, rs, key, S, ks, fg);
+      vn[ks] = frag_global(base + (size_t)2 * H * HD, rs, key, S, ks, fg);
+    }
+  };
+  fetch_kv(wave);
+  stage_rows<HD>(base, rs, S, SP, s0);
+  for (int i = threadIdx.x; i < SP * CPR; i += AT_BWD_THREADS) {
+    const int r = i / CPR, c = i % CPR;
+    uint4 dv = make_uint4(0, 0, 0, 0), ov = make_uint4(0, 0, 0, 0);
+    if (r < S) {
+      dv = *reinterpret_cast<const uint4*>(dobase + (size_t)r * os + c * 8);
+      ov = *reinterpret_cast<const uint4*>(obase + (size_t)r * os + c * 8);
+    }
+    *reinterpret_cast<uint4*>(s1 + r * AT_ROWB + c * 16) = dv;
+    const uint32_t dw[4] = {dv.x, dv.y, dv.z, dv.w}, ow[4] = {ov.x, ov.y, ov.z, ov.w};
+    float d = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      d = fmaf(bf2f((uint16_t)(dw[e] & 0xffff)), bf2f((uint16_t)(ow[e] & 0xffff)), d);
+      d = fmaf(bf2f((uint16_t)(dw[e] >> 16)), bf2f((uint16_t)(ow[e] >> 16)), d);
+    }
+    d = group_sum<CPR>(d);
+    if (c == 0) {
+      s_delta[r] = d;
+      s_lse[r] = r < S ? lse_bh[r] : 0.f;
+    }
+  }
+  __syncthreads();
+  for (int ksn = wave; ksn < NT; ksn += NW) {
+    const int key = ksn * 16 + fr;
+    const bool keyok = key < S;
+    bf16x8_t kf[KS], vf[KS];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      kf[ks] = kn[ks];
+      vf[ks] = vn[ks];
+    }
+    if (ksn + NW < NT) fetch_kv(ksn + NW);
+    bf16x8_t pf[NT / 2], dsf[NT / 2];
+#pragma unroll
+    for (int kk = 0; kk < NT / 2; ++kk) {
+      f32x4_t p2[2], ds2[2];
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int t = 2 * kk + u;
+        f32x4_t a = {0.f, 0.f, 0.f, 0.f}, dp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+          a = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(s0, t * 16 + fr, ks, fg), kf[ks], a, 0, 0, 0);
+          dp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_rows<HD>(s1, t * 16 + fr, ks, fg), vf[ks], dp, 0, 0, 0);
+        }
+        const int q0 = t * 16 + 4 * fg;
+        const f32x4_t lq = *reinterpret_cast<const f32x4_t*>(s_lse + q0);
+        const f32x4_t dl = *reinterpret_cast<const f32x4_t*>(s_delta + q0);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float p = (keyok && q0 + e < S) ? expf(a[e] * scale - lq[e]) : 0.f;
+          p2[u][e] = p;
+          ds2[u][e] = p * (dp[e] - dl[e]) * scale;
+        }
+      }
+      pf[kk] = pack_slots(p2[0], p2[1]);
+      dsf[kk] = pack_slots(ds2[0], ds2[1]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    f32x4_t dv[DJ], dk[DJ];
+#pragma unroll
+    for (int j = 0; j < DJ; ++j) dv[j] = dk[j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kk = 0; kk < NT / 2; ++kk)
+#pragma unroll
+      for (int j = 0; j < DJ; ++j) {
+        dv[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(s1, kk * 32, j, lane), pf[kk], dv[j], 0, 0, 0);
+        dk[j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(frag_cols<HD>(s0, kk * 32, j, lane), dsf[kk], dk[j], 0, 0, 0);
+      }
+    if (keyok) {
+      uint16_t* dkp = dq_base + (size_t)key * rs + (size_t)H * HD + 4 * fg;
+      uint16_t* dvp = dkp + (size_t)H * HD;
+#pragma unroll
+      for (int j = 0; j < DJ; ++j) {
+        *reinterpret_cast<uint2*>(dkp + j * 16) = make_uint2(pack_bf2(dk[j][0], dk[j][1]), pack_bf2(dk[j][2], dk[j][3]));
+        *reinterpret_cast<uint2*>(dvp + j * 16) = make_uint2(pack_bf2(dv[j][0], dv[j][1]), pack_bf2(dv[j][2], dv[j][3]));
+      }
+    }
+  }
+}
+
 template <typename K>
 int at_set_lds(K kernel, int bytes) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -352,6 +547,28 @@ int launch_bwd(const void* qkv, const void* out, const void* dout, const float* 
 
 inline bool at_al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+template <int NT, int HD>
+int launch_bwd_roles(const void* qkv, const void* out, const void* dout, const float* lse, int B, int S, int H, float scale,
+                     void* dqkv, hipStream_t st) {
+  constexpr int lds = 2 * NT * 16 * AT_ROWB + 2 * NT * 16 * 4;
+  static bool attr = false;
+  if (!attr) {
+    const int rc = at_set_lds(&attn_bwd_roles<NT, HD>, lds);
+    if (rc != WM_OK) return rc;
+    attr = true;
+  }
+  attn_bwd_roles<NT, HD><<<dim3(B * H, 2), AT_BWD_THREADS, lds, st>>>(
+      static_cast<const uint16_t*>(qkv), static_cast<const uint16_t*>(out), static_cast<const uint16_t*>(dout), lse, S, H,
+      scale, static_cast<uint16_t*>(dqkv));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+inline bool at_roles() {  // WM_ATTN_BWD_ROLES=0: the one-block-per-head kernel for every length (A/B switch)
+  const char* e = getenv("WM_ATTN_BWD_ROLES");
+  return !(e != nullptr && atoi(e) == 0);
+}
+
 template <int HD>
 int dispatch_fwd(const void* qkv, int B, int S, int H, float scale, void* out, float* lse, hipStream_t st) {
   if (S <= 32) return launch_fwd<2, HD>(qkv, B, S, H, scale, out, lse, st);
@@ -367,6 +584,11 @@ int dispatch_bwd(const void* qkv, const void* out, const void* dout, const float
   if (S <= 32) return launch_bwd<2, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
   if (S <= 64) return launch_bwd<4, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
   if (S <= 128) return launch_bwd<8, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  // > 128 tokens: the four operands of a head no longer leave room for two blocks per CU -> split by role
+  if (at_roles()) {
+    if (S <= 224) return launch_bwd_roles<14, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+    return launch_bwd_roles<16, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
+  }
   if (S <= 224) return launch_bwd<14, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
   return launch_bwd<16, HD>(qkv, out, dout, lse, B, S, H, scale, dqkv, st);
 }
