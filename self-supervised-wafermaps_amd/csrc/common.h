@@ -115,6 +115,17 @@ __device__ __forceinline__ void wm_barrier() {
   asm volatile("" ::: "memory");
 }
 
+// XCD-aware launch order.  Workgroups are dealt round-robin over the 8 XCDs (workgroups b and b + 8 share an L2), so
+// neighbouring tiles -- which share operand rows, halos or whole operand panels -- miss in each other's L2 and every one
+// fetches its own copy from the fabric.  Remap the hardware's linear workgroup id so that each XCD walks a CONTIGUOUS
+// range of logical ids (bijective for any workgroup count: cdna_hip_programming.md, "XCD swizzle must be bijective").
+// Placement is a speed matter only; nothing depends on it for correctness.
+__device__ __forceinline__ uint32_t wm_xcd_swizzle(uint32_t pid, uint32_t nwg) {
+  const uint32_t q = nwg >> 3, r = nwg & 7u, xcd = pid & 7u;
+  const uint32_t base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (pid >> 3);
+}
+
 // LDS byte address of a __shared__ pointer (what M0 / ds instructions take).
 __device__ __forceinline__ uint32_t lds_addr(const void* p) {
   return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const uint8_t*)p;

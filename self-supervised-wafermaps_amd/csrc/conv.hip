@@ -79,6 +79,7 @@ struct ConvArgs {
   int act;
   // multiply-high forms of the divisions by DH * DW and by DW in the row decode (common.h)
   WmDiv d_dhw, d_dw, d_h2w2, d_w2;  // (the last two: DH/2 * DW/2 and DW/2, the parity-class order of MODE 2)
+  int xcd;  // 1: XCD-aware tile order (WM_XCD_SWIZZLE, default on)
 };
 
 __device__ __forceinline__ float cv_gelu(float v) { return wm_gelu(v); }
@@ -284,7 +285,18 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
-  const int m0 = blockIdx.x * BM, n0 = blockIdx.y * BN;
+  // tile of this workgroup: column tiles fastest (they share the whole pixel tile), pixel tiles next (neighbours share
+  // their halo rows), each XCD a contiguous range of that order (common.h: wm_xcd_swizzle)
+  // (not for MODE 2: its tiles are ordered by parity class and the classes cost different amounts -- three of the four
+  // classes of a 1x1 / stride-2 gradient only store zeros -- so a contiguous range per XCD would give one XCD all the
+  // expensive tiles: measured 18.6 -> 40 us on layer4's downsample, 128 -> 164 us on layer2.0's 3x3)
+  int bm = blockIdx.x, bn = blockIdx.y;
+  if (a.xcd && MODE != 2) {
+    const uint32_t lin = wm_xcd_swizzle(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
+    bm = (int)(lin / gridDim.y);
+    bn = (int)(lin - (uint32_t)bm * gridDim.y);
+  }
+  const int m0 = bm * BM, n0 = bn * BN;
   const int rowl = tid >> 3;                   // rows rowl + 32 i; (rowl + 32 i) & 7 == rowl & 7
   const int chunk = (tid & 7) ^ (rowl & 7);    // logical 16-byte chunk this lane fetches
 
@@ -674,10 +686,14 @@ __global__ __launch_bounds__(CV_THREADS, BNB ? 3 : 1) void conv3x3_patch(const C
   // ---- patches: 28 instructions x 8 pixel slots; wave w issues instructions w, w + 4, ...
   // (the two tile origins are decoded ONCE from the block index, as wave-uniform values: integer divisions by the
   // run-time image sizes per fetched piece and per stored chunk were a third of this kernel's instructions)
+  // (tile pairs in XCD-contiguous order: neighbouring tiles share their halo columns / rows through one L2)
+  // (measured neutral to slightly negative here, 157 -> 164 us forward: the 10 x 10 patches of neighbouring tile pairs
+  // overlap by two columns only; kept as an experiment switch, WM_XCD_SWIZZLE=2)
+  const int bx = a.xcd == 2 ? (int)wm_xcd_swizzle(blockIdx.x, gridDim.x) : (int)blockIdx.x;
   int tn[2], th0[2], tw0[2];
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int T = blockIdx.x * 2 + t;
+    const int T = bx * 2 + t;
     tn[t] = T / tiles_img;
     const int tr = T - tn[t] * tiles_img;
     const int th = tr / tw_n;
@@ -802,14 +818,14 @@ __global__ __launch_bounds__(CV_THREADS, BNB ? 3 : 1) void conv3x3_patch(const C
   if constexpr (BNB) {
     const int g = (int)(((long long)tn[0] * a.DH * a.DW) / a.stat_rpg);
     bnb_epilogue<64>(a, bnb, cv_smem, CS, reinterpret_cast<float*>(cv_smem + 128 * CS), g, 0,
-                     (int)blockIdx.x - g * (a.stat_rpg >> 7), tid);
+                     bx - g * (a.stat_rpg >> 7), tid);
     return;
   }
   if constexpr (MODE == 0) {
     if (a.stat != nullptr) {
       // both 8x8 tiles lie in one statistics group (host-checked: an even number of tiles per group)
       const int g = (int)(((long long)tn[0] * a.DH * a.DW) / a.stat_rpg);
-      float* slot = a.stat + ((size_t)(g * a.stat_nb + ((int)blockIdx.x - g * (a.stat_rpg >> 7))) * 2) * 64;
+      float* slot = a.stat + ((size_t)(g * a.stat_nb + (bx - g * (a.stat_rpg >> 7))) * 2) * 64;
       store_tile_with_stats<64>(cv_smem, CS, a.dst, 64, 0, reinterpret_cast<float*>(cv_smem + 128 * CS), slot, tid,
                                 [&](int row) -> size_t { return org[row >> 6] + (size_t)((row >> 3) & 7) * a.DW + (row & 7); });
       return;
@@ -1024,6 +1040,7 @@ struct WgradArgs {
   // multiply their dY fragments with an all-ones B operand (one extra MFMA per fragment and k-step),
   // so a Linear layer's bias gradient costs no extra pass over dY
   float* dbias;        // [nsplit][K] slabs, like dw
+  int xcd;             // 1: XCD-aware block order
 };
 
 constexpr int WG_PIX = 64;  // pixels per staged chunk (two MFMA k-steps)
@@ -1061,8 +1078,19 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int ct0 = blockIdx.x * NT;  // first 64-column tile
-  const int k0 = blockIdx.y * BMO;
+  // logical block (column-tile group, output-channel tile, row split): the blocks of one row split read the same dY
+  // and X rows -- keep them on one XCD (contiguous logical ranges per XCD: common.h wm_xcd_swizzle)
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (a.xcd) {
+    const uint32_t gxy = gridDim.x * gridDim.y;
+    const uint32_t lin = wm_xcd_swizzle(blockIdx.x + gridDim.x * blockIdx.y + gxy * blockIdx.z, gxy * gridDim.z);
+    bz = (int)(lin / gxy);
+    const uint32_t rem = lin - (uint32_t)bz * gxy;
+    by = (int)(rem / gridDim.x);
+    bx = (int)(rem - (uint32_t)by * gridDim.x);
+  }
+  const int ct0 = bx * NT;  // first 64-column tile
+  const int k0 = by * BMO;
   const int cout_w = SQ ? (wave >> 1) * 64 : (BMO == 128 ? wave * 32 : (wave >> 1) * 32);
   const int col_w = BMO == 128 ? 0 : (wave & 1) * 32;
   const int tile_w = SQ ? (wave & 1) : 0;  // first tile this wave multiplies
@@ -1072,7 +1100,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   const int a_pc = RA == 256 ? (lane & 15) : (lane & 7);   // physical 16-byte slot
   const int x_ro = lane >> 3, x_pc = lane & 7;             // X: 8 rows x 8 slots per instruction
 
-  const int chunk_begin = blockIdx.z * a.chunks_per_split;
+  const int chunk_begin = bz * a.chunks_per_split;
   int chunk_end = chunk_begin + a.chunks_per_split;
   if (chunk_end > a.total_chunks) chunk_end = a.total_chunks;
   const int iters = chunk_end - chunk_begin;  // >= 1: the host derives the split count from chunks_per_split
@@ -1160,7 +1188,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   // bias gradient: only column group 0, and only one of the waves that share a channel range
   // (BIAS is a template flag: carrying the extra accumulators in the convolution instantiations
   // cost them ~12 %)
-  const bool bias_wave = BIAS && blockIdx.x == 0 && (SQ ? (wave & 1) == 0 : (BMO == 128 || (wave & 1) == 0));
+  const bool bias_wave = BIAS && bx == 0 && (SQ ? (wave & 1) == 0 : (BMO == 128 || (wave & 1) == 0));
   f32x4_t bacc[MJ];
 #pragma unroll
   for (int i = 0; i < MJ; ++i) bacc[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
@@ -1222,7 +1250,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
 
   const size_t rsc = (size_t)a.R * a.S * a.C;
   const int fr = lane & 15, fg = lane >> 4;
-  float* slab = a.dw + (size_t)blockIdx.z * (size_t)a.K * rsc;
+  float* slab = a.dw + (size_t)bz * (size_t)a.K * rsc;
 #pragma unroll
   for (int i = 0; i < MJ; ++i)
 #pragma unroll
@@ -1239,7 +1267,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
 #pragma unroll
     for (int i = 0; i < MJ; ++i)
 #pragma unroll
-      for (int e = 0; e < 4; ++e) a.dbias[(size_t)blockIdx.z * a.K + k0 + cout_w + i * 16 + fg * 4 + e] = bacc[i][e];
+      for (int e = 0; e < 4; ++e) a.dbias[(size_t)bz * a.K + k0 + cout_w + i * 16 + fg * 4 + e] = bacc[i][e];
   }
 }
 
@@ -1412,6 +1440,11 @@ inline void wgrad_config(int C, int K, int R, int S, int& bmo, int& cpt, int& nt
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
+inline int xcd_order() {  // WM_XCD_SWIZZLE=0: hardware block order (A/B switch; read per call)
+  const char* e = getenv("WM_XCD_SWIZZLE");
+  return e != nullptr ? atoi(e) : 1;
+}
+
 }  // namespace
 
 // Geometry checks shared by the three entry points.  "x" is always the forward input
@@ -1499,6 +1532,7 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   if (rc != WM_OK) return rc;
   WM_REQUIRE(aligned16(x) && aligned16(w_krsc) && aligned16(y), WM_EALIGN);
   ConvArgs a;
+  a.xcd = xcd_order();
   a.src = static_cast<const uint16_t*>(x);
   a.wt = static_cast<const uint16_t*>(w_krsc);
   a.dst = static_cast<uint16_t*>(y);
@@ -1643,6 +1677,7 @@ static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const v
   WM_REQUIRE(C % 64 == 0, WM_EUNSUPPORTED);  // the stem needs no input gradient
   WM_REQUIRE(aligned16(dy) && aligned16(w_crsk) && aligned16(dx), WM_EALIGN);
   ConvArgs a;
+  a.xcd = xcd_order();
   a.src = static_cast<const uint16_t*>(dy);
   a.wt = static_cast<const uint16_t*>(w_crsk);
   a.dst = static_cast<uint16_t*>(dx);
@@ -1713,6 +1748,7 @@ extern "C" int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_krs
   WM_REQUIRE((long long)N * H * W * C < (1ll << 32) - (1 << 20) && (long long)N * P * Q * K < (1ll << 32) - (1 << 20),
              WM_EUNSUPPORTED);
   WgradArgs a;
+  a.xcd = xcd_order();
   a.dy = static_cast<const uint16_t*>(dy);
   a.x = static_cast<const uint16_t*>(x);
   a.dw = dw_krsc;
