@@ -287,14 +287,21 @@ __global__ __launch_bounds__(CV_THREADS) void conv_igemm(const ConvArgs a) {
   const int wm = WN == 2 ? wave >> 1 : wave, wn = WN == 2 ? wave & 1 : 0;
   // tile of this workgroup: column tiles fastest (they share the whole pixel tile), pixel tiles next (neighbours share
   // their halo rows), each XCD a contiguous range of that order (common.h: wm_xcd_swizzle)
-  // (not for MODE 2: its tiles are ordered by parity class and the classes cost different amounts -- three of the four
-  // classes of a 1x1 / stride-2 gradient only store zeros -- so a contiguous range per XCD would give one XCD all the
+  // (MODE 2: its tiles are ordered by parity class and the classes cost different amounts -- three of the four classes
+  // of a 1x1 / stride-2 gradient only store zeros -- so a plain contiguous range per XCD gives one XCD all the
   // expensive tiles: measured 18.6 -> 40 us on layer4's downsample, 128 -> 164 us on layer2.0's 3x3)
   int bm = blockIdx.x, bn = blockIdx.y;
-  if (a.xcd && MODE != 2) {
+  if (a.xcd) {
     const uint32_t lin = wm_xcd_swizzle(blockIdx.x + gridDim.x * blockIdx.y, gridDim.x * gridDim.y);
     bm = (int)(lin / gridDim.y);
     bn = (int)(lin - (uint32_t)bm * gridDim.y);
+    if constexpr (MODE == 2) {
+      // tiles are stored class by class (gridDim.x / 4 tiles each): walk the four classes INTERLEAVED, so that every
+      // XCD's contiguous range holds the same mix of cheap and expensive tiles and neighbours inside a class stay close
+      const int tpc = (int)(gridDim.x >> 2);
+      if (a.xcd == 3 && (gridDim.x & 3) == 0) bm = (bm & 3) * tpc + (bm >> 2);
+      else { bm = blockIdx.x; bn = blockIdx.y; }
+    }
   }
   const int m0 = bm * BM, n0 = bn * BN;
   const int rowl = tid >> 3;                   // rows rowl + 32 i; (rowl + 32 i) & 7 == rowl & 7

@@ -292,18 +292,54 @@ def _slab_buffers(owner: torch.Tensor, nsplit: int, numel: int, bias_k: int = 0)
     return ent
 
 
+# ---- weight gradients on a SIDE stream.  Nothing in the backward chain waits for a weight gradient: only the fold at
+# the end of the pass reads the slabs.  The chain itself alternates MFMA-bound launches (dgrad) with HBM-bound ones
+# (BatchNorm / LayerNorm backward), so the MFMA-bound wgrad launches run beside it on a second stream: fork = the side
+# stream waits for the point of the main stream where dy exists, join = the main stream waits for the side stream
+# before the fold (both are event waits, so a hipGraph capture records two parallel branches).  The operands are kept
+# referenced until the join: the caching allocator must not hand dy's memory to a later kernel of the main stream.
+# MEASURED SLOWER, hence off by default (WM_WGRAD_SIDE_STREAM=1 enables it): SimCLR 11.82 / 11.85 vs 11.75 ms per
+# step, DINO ViT-Tiny 10.48 vs 10.32, MAE ViT-S/16 5.06 vs 4.81 (hipGraph replay, one MI355X).  The wgrad workgroups take
+# CU slots and L2 from the chain's kernels; the chain is the critical path and gets slower by more than the weight
+# gradients cost when run in line.
+_SIDE = {"stream": None, "dirty": False, "keep": []}
+_SIDE_ON = os.environ.get("WM_WGRAD_SIDE_STREAM", "0") == "1"
+
+
+def _side_fork(*tensors):
+    st = _SIDE["stream"]
+    if st is None or st.device != tensors[0].device:
+        st = _SIDE["stream"] = torch.cuda.Stream(device=tensors[0].device)
+    st.wait_stream(torch.cuda.current_stream())
+    _SIDE["keep"].extend(tensors)
+    _SIDE["dirty"] = True
+    return st
+
+
+def side_join() -> None:
+    """The current stream waits for every weight-gradient launch issued on the side stream since the last join."""
+    if _SIDE["dirty"]:
+        torch.cuda.current_stream().wait_stream(_SIDE["stream"])
+        _SIDE["keep"].clear()
+        _SIDE["dirty"] = False
+
+
 def wgrad(dy, x, owner, n, h, w, c, k, r, s, p, q, stride, pad, bias_k: int = 0, name: str = "conv_wgrad"):
     """Launch the weight-gradient kernel of one layer into `owner`'s slab buffer.
     Returns (slabs, bias slabs or None, nsplit)."""
     ns = wgrad_splits(n, h, w, c, k, r, s, p, q, stride, pad)
     slabs, bslabs = _slab_buffers(owner, ns, k * r * s * c, bias_k)
     lib = _lib.load()
-    if bias_k > 0:
-        check(_run(name, 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_wgrad_bias, ptr(dy), ptr(x), ptr(slabs), ptr(bslabs),
-                   n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_wgrad_bias")
-    else:
-        check(_run(name, 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_wgrad, ptr(dy), ptr(x), ptr(slabs), n, h, w, c, k, r,
-                   s, p, q, stride, pad, stream_ptr()), "wm_conv2d_wgrad")
+    # the side stream only where the batched fold (which joins) consumes the slabs; wgrad_deliver joins otherwise
+    side = _SIDE_ON and dy.is_cuda and _arena_grad(owner) is not None
+    ctx = torch.cuda.stream(_side_fork(dy, x, slabs)) if side else contextlib.nullcontext()
+    with ctx:
+        if bias_k > 0:
+            check(_run(name, 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_wgrad_bias, ptr(dy), ptr(x), ptr(slabs), ptr(bslabs),
+                       n, h, w, c, k, r, s, p, q, stride, pad, stream_ptr()), "wm_conv2d_wgrad_bias")
+        else:
+            check(_run(name, 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_wgrad, ptr(dy), ptr(x), ptr(slabs), n, h, w, c, k, r,
+                       s, p, q, stride, pad, stream_ptr()), "wm_conv2d_wgrad")
     return slabs, bslabs, ns
 
 
@@ -329,6 +365,8 @@ def wgrad_deliver(weight, slabs, ns, k, c, r, s, bias=None, bslabs=None):
     bslot = _arena_grad(bias) if bias is not None else None
     dw = db = None
     fold_w = slot is not None and r * s in (1, 9) and c % 4 == 0
+    if not (fold_w and (bias is None or bslabs is None or bslot is not None)):
+        side_join()   # a finalize launch on this stream reads the slabs now
     if fold_w:
         _queue_fold(weight, slabs, ns, slot, k, c, r * s, bslabs if bslot is not None else None, bslot)
     else:
@@ -362,6 +400,7 @@ def drop_pending_folds() -> None:
     end-of-pass callback then).  Called by the optimisers' zero_grad(): the stale entries' slabs are simply overwritten
     by the next pass, and the next pass registers its callback again."""
     global _FOLD_QUEUED
+    side_join()
     for ent in _PENDING_FOLDS:
         ent[0]._hip_pending = 0
     _PENDING_FOLDS.clear()
@@ -373,6 +412,7 @@ def fold_wgrads() -> None:
     (and bias slabs into bias gradients): wm_wgrad_fold, one launch."""
     global _FOLD_QUEUED
     _FOLD_QUEUED = False
+    side_join()
     if not _PENDING_FOLDS:
         return
     try:
@@ -593,6 +633,7 @@ class _StemConv(torch.autograd.Function):
         dy = _as_nhwc(dy)
         lib = _lib.load()
         slabs, _, ns = wgrad(dy, xs, ctx.weight, n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2)
+        side_join()   # the finalize below reads the slabs on this stream (the stem is the last layer of the pass anyway)
         slot = _arena_grad(ctx.weight)
         if slot is not None:
             check(lib.wm_stem_wgrad_finalize(ptr(slabs), ns, k, ptr(slot), 1, stream_ptr()), "wm_stem_wgrad_finalize")

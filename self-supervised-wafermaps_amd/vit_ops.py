@@ -458,6 +458,7 @@ class _PatchEmbed(torch.autograd.Function):
             lib = _lib.load()
             # rows [m][k = p*p*3] x dy [m][d] as a 1 x 1 convolution; the slabs are [d][p][p][3] = KRSC of the patch filter
             slabs, _, ns = ops.wgrad(dy, rows, weight, m, 1, 1, k, d, 1, 1, 1, 1, 1, 0, name="gemm_wgrad")
+            ops.side_join()   # the finalize below reads the slabs on this stream
             slot = _arena_grad(weight)
             if slot is not None:
                 check(lib.wm_wgrad_finalize(ptr(slabs), ns, d, 3, p, p, ptr(slot), 1, stream_ptr()), "wm_wgrad_finalize")
