@@ -48,11 +48,20 @@ HBM_PEAK_GBS = 8000.0           # HBM3E, same table
 # HBM-side bytes per conv launch (mean over the implicit-GEMM launches of a step), rocprofv3 --pmc FETCH_SIZE and
 # WRITE_SIZE in separate passes of this script, FETCH_SIZE doubled per the gfx950 correction (calibrated on
 # sgd_step).  A PMC pass cannot run inside the timed region: this is the committed measurement of the file named
-# below, not a live one.  Algorithmic bytes (every operand once): 230 MB per launch.
-CONV_TRAFFIC_BYTES_PER_LAUNCH = 510.1e6
-CONV_TRAFFIC_SOURCE = "profiles/r02_hbm_traffic_simclr_r18_v2.md (rocprofv3 --pmc, separate passes; 260 launches of 4 steps)"
-# the same for the transformer workloads: {workload: (bytes per GEMM / attention launch, source)}; filled from PMC passes
-VIT_TRAFFIC = {}
+# below, not a live one.  Algorithmic bytes (every operand once): 230 MB per launch; round 2 measured 510 MB
+# (hardware block order: neighbouring tiles on different XCDs, every L2 fetching its own copy of shared operand rows).
+CONV_TRAFFIC_BYTES_PER_LAUNCH = 305.1e6
+CONV_TRAFFIC_SOURCE = ("profiles/r03_hbm_traffic_simclr_r18.md (rocprofv3 --pmc, separate passes; 264 conv launches of 4 "
+                       "steps; 36.3 GB per step over all kernels)")
+# the same for the transformer workloads: {workload: (bytes per GEMM / attention launch, source)}
+VIT_TRAFFIC = {
+    "dino_vit_tiny": (67.4e6, "profiles/r03_hbm_traffic_dino_vit_tiny.md (1044 GEMM / attention launches of 4 steps; "
+                              "22.6 GB per step over all kernels)"),
+    "mae_vit_small_16": (28.8e6, "profiles/r03_hbm_traffic_mae_vit_small_16.md (760 GEMM / attention launches of 4 steps; "
+                                 "9.2 GB per step over all kernels)"),
+}
+# one wm_knn_topk call, 64 bf16 queries: streaming kernel 210.1 MB + selection 9.5 MB (profiles/r03_hbm_traffic_knn_b64.md)
+KNN_B64_TRAFFIC_BYTES = 219.6e6
 R18_GFLOP_PER_SAMPLE = 21.76    # ResNet-18 fwd 3.627 GFLOP x 3 (fwd+bwd) x 2 views
 KNN_N, KNN_D, KNN_K = 811457, 128, 8
 
@@ -197,7 +206,8 @@ def knn_object(dev):
                                 "pipelined_hbm_frac": round(bytes_ / us_p / 1e3 / HBM_PEAK_GBS, 3),
                                 "hbm_GBs": round(bytes_ / us / 1e3, 1), "hbm_frac": round(bytes_ / us / 1e3 / HBM_PEAK_GBS, 3),
                                 "dense_TFLOPs": round(2.0 * bq * KNN_N * KNN_D / us / 1e6, 1),
-                                "allpairs_s": round(us * 1e-6 * (KNN_N / bq), 3)})
+                                "allpairs_s": round(us * 1e-6 * (KNN_N / bq), 3),
+                                "traffic": KNN_B64_TRAFFIC_BYTES if (dtype == "bf16" and bq == 64) else None})
     del bank32, bank16
     torch.cuda.empty_cache()
     return out
@@ -480,7 +490,7 @@ def main():
                              "achieved": round(bytes_ / us / 1e3, 1) if bq <= 256 else round(2.0 * bq * KNN_N * KNN_D / us / 1e6, 1),
                              "peak": HBM_PEAK_GBS if bq <= 256 else MFMA_BF16_PEAK_TFLOPS, "unit": "GB/s" if bq <= 256 else "TFLOP/s",
                              "frac": round((bytes_ / us / 1e3 / HBM_PEAK_GBS) if bq <= 256 else (2.0 * bq * KNN_N * KNN_D / us / 1e6 / MFMA_BF16_PEAK_TFLOPS), 4),
-                             "traffic": None}})
+                             "traffic": KNN_B64_TRAFFIC_BYTES if bq == 64 else None}})
         return
 
     # ------------------------------------------------------------------------------------------ training workloads
