@@ -280,7 +280,7 @@ int wm_linear_dgrad_gelu(const void* dy, const void* w_crsk, const void* pre, vo
  * activation living in LDS only (128 token rows per workgroup, 128 hidden units at a time).  x, y, residual
  * [rows][C] bf16; w1_krsc [H][C], w2_krsc [C][H] bf16 (forward layouts); b1 [H], b2 [C] f32.  Bit-identical to
  * wm_linear_bias_gelu_fwd followed by wm_conv2d_fwd_bias_res.  wm_mlp_fused_fwd_ok: 1 for the served shapes (C = 192,
- * H % 128 == 0: ViT-Tiny; wider x tiles do not fit beside the weight ring in 160 KB of LDS). */
+ * H % 128 == 0, rows <= 32 768: ViT-Tiny; one workgroup per CU -- beyond one round of the chip the two launches win). */
 int wm_mlp_fused_fwd_ok(int rows, int C, int H);
 int wm_mlp_fused_fwd(const void* x, const void* w1_krsc, const float* b1, const void* w2_krsc, const float* b2,
                      const void* residual, void* y, int rows, int C, int H, void* stream);

@@ -7,15 +7,23 @@
 // FLOP: 154 FLOP per byte against a ridge of 312 -- its HBM roofline is below half of the MFMA peak.  Fused, only x and
 // y move (and the two weight matrices, 590 KB, stay in L2): 1 536 FLOP per byte.
 //
-// Block = 128 token rows, 512 threads (8 waves: 4 row groups of 32 x 2 column halves).  LDS (128 KB, one block per CU,
-// two waves per SIMD):
-//   XS   [C/64 panels][128 rows][128 B]   the x tile, resident for the whole block            (48 KB at C = 192)
-//   HS   [2 panels][128 rows][128 B]      one 128-wide chunk of the hidden activation, bf16    (32 KB)
-//   ring 2 stages x 24 KB                 weight slices by global_load_lds: fc1 [128 hidden][64 c] or fc2 [C out][64 hidden]
+// Block = 128 token rows, 512 threads (8 waves: 4 row groups of 32 x 2 column halves).  One block per CU:
+//   x rows   REGISTERS: a lane's 16-byte pieces of its two token rows x six k-steps (48 VGPRs), loaded once from global
+//            memory as MFMA B-operand fragments (round 3; they used to occupy 48 KB of LDS)
+//   HS       [2 panels][128 rows][128 B]   one 128-wide chunk of the hidden activation, bf16    (32 KB)
+//   ring     5 stages x 24 KB              weight slices by global_load_lds: fc1 [128 hidden][64 c] or fc2 [C out][64 hidden]
 // Per hidden chunk: C/64 k-steps of fc1 (A = weight fragment, B = x fragment: a lane owns 4 consecutive hidden units of
-// one token), bias + GELU on the accumulators -> HS, then 2 k-steps of fc2 with HS as the token operand.  One
-// `s_waitcnt vmcnt(0); s_barrier; issue(next); compute(this)` step per slice, as conv_igemm.  All rows are 128 B with
-// the 16-byte chunk index XOR-swizzled by (row & 7) (conflict-free ds_read_b128 fragments).
+// one token), bias + GELU on the accumulators -> HS, then 2 k-steps of fc2 with HS as the token operand.  FOUR weight
+// slices are in flight ahead of the one being multiplied, retired by counted waits (2 DMA instructions per thread for an
+// fc1 slice, 3 for an fc2 slice).  All LDS rows are 128 B with the 16-byte chunk index XOR-swizzled by (row & 7)
+// (conflict-free ds_read_b128 fragments).
+// What bounds it (tools/probes/mlp_probe.py): NOT the weight stream -- going from the two-stage ring of round 2 to this
+// one moved a launch over 25 216 rows from 49.6 to 47.9 us, and three blocks alone on the chip still take 41 us.  A block
+// evaluates 128 x 768 exact GELUs (exp, rcp and a degree-5 polynomial: ~30 VALU slots each) with two waves per SIMD:
+// ~19 us of VALU time per block, barrier-synchronised with the MFMA phases of the same waves, plus 30 barriers.  The
+// two-launch path pays the same VALU work spread over all 256 CUs (59.8 us for both launches at these rows); at 39 424
+// rows (308 blocks, two rounds of one block per CU) the fused kernel loses (91.9 vs 82.7 us), so only the teacher /
+// inference passes (<= 256 row tiles) use it.
 // The arithmetic mirrors the two-launch path exactly (k order, MFMA shapes, bf16 rounding of the pre-activation and of
 // the staged outputs before bias / residual), so the result is BIT-IDENTICAL to wm_linear_bias_gelu_fwd followed by
 // wm_conv2d_fwd_bias_res (tests/test_gpu_vit.py).
@@ -39,18 +47,32 @@ struct MlpArgs {
   int rows, H;
 };
 
-__device__ __attribute__((aligned(256))) uint16_t mlp_zero_page[128];
+
+__device__ __forceinline__ void ml_wait(int n) {  // s_waitcnt vmcnt(n): the immediate is an instruction field
+  switch (n) {
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+  }
+}
 
 template <int C>
 __global__ __launch_bounds__(ML_THREADS) void mlp_fused_fwd(const MlpArgs a) {
-  static_assert(C % 64 == 0 && C <= 192, "x tile + ring must fit 160 KB of LDS");
-  constexpr int XP = C / 64;                       // x panels = fc1 k-steps per chunk
+  static_assert(C % 64 == 0 && C <= 192, "x fragments in registers; the fc2 slice must fit a ring stage");
+  constexpr int XP = C / 64;                       // fc1 k-steps (64 wide) per chunk
+  constexpr int KS = C / 32;                       // MFMA k-steps over C
   constexpr int STEPS = XP + 2;                    // slices per hidden chunk
   constexpr int STAGE = C * ML_ROWB;               // fc2 slice [C rows][64 k] (>= the 16 KB fc1 slice)
+  constexpr int NST = 5;                           // ring stages: four slices in flight ahead of the current one
   constexpr int OJ = C / 2 / 16;                   // 16-column output fragments per wave (half of C)
   extern __shared__ __attribute__((aligned(16))) uint8_t ml_smem[];
-  uint8_t* XS = ml_smem;
-  uint8_t* HS = XS + XP * ML_PANEL;
+  uint8_t* HS = ml_smem;
   uint8_t* RING = HS + 2 * ML_PANEL;
   const uint32_t ring_base = lds_addr(RING);
 
@@ -62,23 +84,13 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_fused_fwd(const MlpArgs a) {
   const int rl = tid >> 3;            // row inside a 64-row DMA instruction
   const int slot = tid & 7;           // physical 16-byte slot of the lane
 
-  // ---- x tile: 2 * XP instructions per thread
-  {
-    const uint32_t xs_base = lds_addr(XS);
-#pragma unroll
-    for (int i = 0; i < 2 * XP; ++i) {
-      const int pn = i >> 1, row = (i & 1) * 64 + rl;
-      const int chunk = slot ^ (row & 7);
-      const uint16_t* src = (m0 + row < a.rows) ? a.x + (size_t)(m0 + row) * C + pn * 64 + chunk * 8 : mlp_zero_page + chunk * 8;
-      glds16_at(src, xs_base + pn * ML_PANEL + ((i & 1) * 64 + wave * 8) * ML_ROWB);
-    }
-  }
   const int nchunks = a.H / ML_HC;
   const int nsteps = nchunks * STEPS;
-  // slice of step s -> ring stage s & 1
+  // slice of step s -> ring stage s % NST; DMA instructions per thread: 2 (fc1) or C / 64 (fc2)
+  auto n_instr = [&](int s) { return (s % STEPS) < XP ? 2 : C / 64; };
   auto issue = [&](int s) {
     const int hc = s / STEPS, k = s - hc * STEPS;
-    const uint32_t stage = ring_base + (uint32_t)(s & 1) * STAGE;
+    const uint32_t stage = ring_base + (uint32_t)(s % NST) * STAGE;
     if (k < XP) {  // fc1: rows = hidden hc*128 + r, columns k*64 ..
 #pragma unroll
       for (int i = 0; i < 2; ++i) {
@@ -95,6 +107,20 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_fused_fwd(const MlpArgs a) {
       }
     }
   };
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nsteps) issue(s);
+
+  // ---- the block's token rows as MFMA B-operand fragments (rows past the end repeat the last row; never stored)
+  bf16x8_t xr[2][KS];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    int row = m0 + wm * 32 + i * 16 + fr;
+    row = row < a.rows ? row : a.rows - 1;
+    const uint16_t* xp = a.x + (size_t)row * C + fg * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) xr[i][ks] = *reinterpret_cast<const bf16x8_t*>(xp + ks * 32);
+  }
 
   f32x4_t acc1[4][2];      // fc1: 64 hidden x 32 tokens per wave
   f32x4_t acc2[OJ][2];     // fc2: C/2 outputs x 32 tokens per wave
@@ -112,65 +138,71 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_fused_fwd(const MlpArgs a) {
     return *reinterpret_cast<const bf16x8_t*>(base + row * ML_ROWB + ((c ^ (row & 7)) << 4));
   };
 
-  issue(0);
-  for (int s = 0; s < nsteps; ++s) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    wm_barrier();
-    if (s + 1 < nsteps) issue(s + 1);
-    else wm_barrier();  // (a phase between the retiring wait and the reads when nothing is issued: see conv3x3_patch)
-    const int hc = s / STEPS, k = s - hc * STEPS;
-    const uint8_t* stage = RING + (s & 1) * STAGE;
-    if (k < XP) {
-      const uint8_t* xp = XS + k * ML_PANEL;
+  for (int hc = 0; hc < nchunks; ++hc) {
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t xf[2], wf[4];
+    for (int k = 0; k < STEPS; ++k) {
+      const int s = hc * STEPS + k;
+      // slice s has landed; the slices s + 1 .. s + 3 (issued before it was needed) may stay in flight
+      {
+        int later = 0;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) xf[i] = frag(xp, wm * 32 + i * 16 + fr, ks);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) wf[j] = frag(stage, wn * 64 + j * 16 + fr, ks);
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int i = 0; i < 2; ++i) acc1[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xf[i], acc1[j][i], 0, 0, 0);
+        for (int d = 1; d < NST - 1; ++d)
+          if (s + d < nsteps) later += n_instr(s + d);
+        ml_wait(s == 0 ? 0 : later);   // (step 0: the x rows are needed right away as well)
       }
-      if (k == XP - 1) {
-        // hidden chunk complete: pre = bf16(bf16(acc) + b1) (the two-launch path stages bf16 accumulators, then adds
-        // the bias), h = bf16(gelu(pre)) -> HS; the barrier of the next step orders it before fc2's reads
+      wm_barrier();   // everyone's pieces of slice s; the stage of slice s - 1 has been read by all
+      if (s + NST - 1 < nsteps) issue(s + NST - 1);
+      const uint8_t* stage = RING + (s % NST) * STAGE;
+      if (k < XP) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int hl = wn * 64 + j * 16 + fg * 4;  // hidden unit inside the chunk
-          const float4 bb = *reinterpret_cast<const float4*>(a.b1 + hc * ML_HC + hl);
-          const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8_t wf[4];
 #pragma unroll
-          for (int i = 0; i < 2; ++i) {
-            const int row = wm * 32 + i * 16 + fr;
-            float h[4];
+          for (int j = 0; j < 4; ++j) wf[j] = frag(stage, wn * 64 + j * 16 + fr, ks);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              const float pre = bf2f(f2bf(bf2f(f2bf(acc1[j][i][e])) + bv[e]));
-              h[e] = wm_gelu(pre);
+          for (int j = 0; j < 4; ++j)
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              acc1[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], xr[i][k * 2 + ks], acc1[j][i], 0, 0, 0);
+        }
+        if (k == XP - 1) {
+          // hidden chunk complete: pre = bf16(bf16(acc) + b1) (the two-launch path stages bf16 accumulators, then adds
+          // the bias), h = bf16(gelu(pre)) -> HS; the barrier of the next step orders it before fc2's reads
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int hl = wn * 64 + j * 16 + fg * 4;  // hidden unit inside the chunk
+            const float4 bb = *reinterpret_cast<const float4*>(a.b1 + hc * ML_HC + hl);
+            const float bv[4] = {bb.x, bb.y, bb.z, bb.w};
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+              const int row = wm * 32 + i * 16 + fr;
+              float h[4];
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float pre = bf2f(f2bf(bf2f(f2bf(acc1[j][i][e])) + bv[e]));
+                h[e] = wm_gelu(pre);
+              }
+              const int cl = (hl & 63) >> 3;  // 16-byte chunk inside the 64-wide panel
+              *reinterpret_cast<uint2*>(HS + (hl >> 6) * ML_PANEL + row * ML_ROWB + ((cl ^ (row & 7)) << 4) + (fg & 1) * 8) =
+                  make_uint2(pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3]));
+              acc1[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             }
-            const int cl = (hl & 63) >> 3;  // 16-byte chunk inside the 64-wide panel
-            *reinterpret_cast<uint2*>(HS + (hl >> 6) * ML_PANEL + row * ML_ROWB + ((cl ^ (row & 7)) << 4) + (fg & 1) * 8) =
-                make_uint2(pack_bf2(h[0], h[1]), pack_bf2(h[2], h[3]));
-            acc1[j][i] = f32x4_t{0.f, 0.f, 0.f, 0.f};
           }
         }
-      }
-    } else {
-      const uint8_t* hp = HS + (k - XP) * ML_PANEL;
+      } else {
+        const uint8_t* hp = HS + (k - XP) * ML_PANEL;
 #pragma unroll
-      for (int ks = 0; ks < 2; ++ks) {
-        bf16x8_t hf[2], wf[OJ];
+        for (int ks = 0; ks < 2; ++ks) {
+          bf16x8_t hf[2], wf[OJ];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) hf[i] = frag(hp, wm * 32 + i * 16 + fr, ks);
+          for (int i = 0; i < 2; ++i) hf[i] = frag(hp, wm * 32 + i * 16 + fr, ks);
 #pragma unroll
-        for (int j = 0; j < OJ; ++j) wf[j] = frag(stage, wn * (C / 2) + j * 16 + fr, ks);
+          for (int j = 0; j < OJ; ++j) wf[j] = frag(stage, wn * (C / 2) + j * 16 + fr, ks);
 #pragma unroll
-        for (int j = 0; j < OJ; ++j)
+          for (int j = 0; j < OJ; ++j)
 #pragma unroll
-          for (int i = 0; i < 2; ++i) acc2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], hf[i], acc2[j][i], 0, 0, 0);
+            for (int i = 0; i < 2; ++i) acc2[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[j], hf[i], acc2[j][i], 0, 0, 0);
+        }
       }
     }
   }
@@ -178,7 +210,7 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_fused_fwd(const MlpArgs a) {
 
   // ---- output: bf16 accumulators staged in LDS ([row][C] + 16 B pad), then bias (+ residual) on coalesced 16-byte rows
   constexpr int CS = C * 2 + 16;
-  static_assert(128 * CS <= (XP + 2) * ML_PANEL, "output staging fits XS + HS");
+  static_assert(128 * CS <= 2 * ML_PANEL + NST * STAGE, "output staging fits HS + ring");
 #pragma unroll
   for (int j = 0; j < OJ; ++j)
 #pragma unroll
@@ -216,7 +248,10 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_fused_fwd(const MlpArgs a) {
 
 }  // namespace
 
-extern "C" int wm_mlp_fused_fwd_ok(int rows, int C, int H) { return rows > 0 && C == 192 && H > 0 && H % 128 == 0 ? 1 : 0; }
+// (rows <= 256 row tiles: one block per CU, so beyond one round of the chip the two-launch path is faster)
+extern "C" int wm_mlp_fused_fwd_ok(int rows, int C, int H) {
+  return rows > 0 && rows <= 256 * 128 && C == 192 && H > 0 && H % 128 == 0 ? 1 : 0;
+}
 
 extern "C" int wm_mlp_fused_fwd(const void* x, const void* w1_krsc, const float* b1, const void* w2_krsc, const float* b2,
                                 const void* residual, void* y, int rows, int C, int H, void* stream) {
@@ -226,7 +261,7 @@ extern "C" int wm_mlp_fused_fwd(const void* x, const void* w1_krsc, const float*
   WM_REQUIRE(al(x) && al(w1_krsc) && al(b1) && al(w2_krsc) && al(b2) && al(y) && (residual == nullptr || al(residual)), WM_EALIGN);
   MlpArgs a{static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w1_krsc), b1, static_cast<const uint16_t*>(w2_krsc),
             b2, static_cast<const uint16_t*>(residual), static_cast<uint16_t*>(y), rows, H};
-  constexpr int lds = (192 / 64 + 2) * ML_PANEL + 2 * 192 * ML_ROWB;
+  constexpr int lds = 2 * ML_PANEL + 5 * 192 * ML_ROWB;
   static bool attr = false;
   if (!attr) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_fwd<192>),
