@@ -54,7 +54,10 @@ class GraphedTrainStep:
         self.graph = None
         self.loss = None
         self._last_params = None
-        self._warmup = warmup
+        # an EMA teacher's weight layouts come into being lazily in the FIRST eager step and are refreshed as one batched
+        # launch (with a descriptor table built on the host) from the SECOND step on: two eager steps before capture
+        has_teacher = any(not p.requires_grad for p in model.parameters())
+        self._warmup = max(warmup, 2) if has_teacher else warmup
 
     def _upload(self, params_per_group):
         # the replayed kernel indexes the store and the output with these values: bounds-check every upload

@@ -672,16 +672,18 @@ class DINOLoss(nn.Module):
         if _world() > 1:
             # lightly: batch_center = mean over (views, batch), all-reduced and divided by world size
             mean = teacher.float().mean(dim=0, keepdim=True)
+            if self._center_mean is None:
+                # allocated by the first EAGER step (the capture's warm-up): not from a graph's private pool
+                self._center_mean = torch.zeros_like(self.center)
             if torch.cuda.is_available() and teacher.is_cuda and torch.cuda.is_current_stream_capturing():
                 # inside a hipGraph capture (graph.GraphedTrainStep): the collective cannot be part of the graph (gloo
                 # is a host call; RCCL inside a captured step is not relied on).  The local mean is parked in a
                 # persistent buffer by the graph; finish_center_update() -- called by the step after the replay --
                 # does the exchange and the moving average.
-                if self._center_mean is None:
-                    self._center_mean = torch.zeros_like(self.center)
                 self._center_mean.copy_(mean.view_as(self.center))
-                self._center_pending = True
+                self._center_pending = True   # stays set: every REPLAY parks a new mean without running this code again
                 return
+            self._center_pending = False      # an eager step: nothing is parked
             dist.all_reduce(mean)
             mean /= _world()
             self.center.mul_(self.center_momentum).add_(mean.view_as(self.center), alpha=1 - self.center_momentum)

@@ -282,3 +282,60 @@ def test_barlow_twins_gather_distributed_world2(tmp_path):
                d["cos"], 0.995, higher=True)
         parity(f"Barlow Twins gather_distributed world 2, rank {r}: projection gradients (max |err| / max |ref|)",
                d["gmax"], 0.05)
+
+
+def _dino_center_case(rank, world, graphed, out_path):
+    """Two data-parallel DINO ViT-Tiny steps: the loss's centre is a cross-rank quantity (lightly all-reduces the batch
+    centre).  Under hipGraph replay the collective is deferred to `post_graph_step` (loss.DINOLoss.finish_center_update)."""
+    from ssl_wafermap_amd import distributed as wdist
+    from ssl_wafermap_amd.data import WaferMapDataset
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.graph import GraphedTrainStep
+    from ssl_wafermap_amd.models import DINOViT
+    from ssl_wafermap_amd.transforms import MultiCropTransform
+
+    B = 4
+    wafers, labels = synthetic_wafers(64, seed=5)
+    ds = WaferMapDataset(wafers, labels, transform=MultiCropTransform(), device="cuda:0")
+    torch.manual_seed(7)
+    model = DINOViT(None, 9, batch_size=B * world, log_rep_std=False, backbone="vit_tiny").to("cuda:0").train()
+    (opt,), _ = model.configure_optimizers()
+    sync = wdist.GradSync(opt)
+    wdist.broadcast_state(model, opt)
+    rng = np.random.default_rng(100 + rank)
+    idx = [np.arange(B) + (2 * i + rank) * B for i in range(3)]
+    if graphed:
+        g = GraphedTrainStep(model, opt, ds, B, warmup=1, fmt="nhwc_bf16").capture(idx[0], np.random.default_rng(1), sync)
+        assert model.criterion._center_pending and model.criterion._center_mean is not None
+        for i in range(2):
+            g.step(idx[i], rng, sync)
+    else:
+        for i in range(2):
+            batch = ds.get_batch(idx[i], rng, fmt="nhwc_bf16")
+            opt.zero_grad()
+            loss = model.training_step(batch, i)
+            loss.backward()
+            sync.start()
+            sync.wait()
+            opt.step()
+    torch.cuda.synchronize()
+    c = model.criterion.center.detach().float().reshape(-1)
+    both = [torch.empty_like(c) for _ in range(world)]
+    dist.all_gather(both, c)
+    assert torch.equal(both[0], both[1]), "the centre is a global quantity: identical on every rank"
+    assert float(c.abs().max()) > 0
+    if rank == 0:
+        torch.save(c.cpu(), f"{out_path}.{int(graphed)}")
+
+
+def test_dino_center_under_graph_replay_equals_eager_world2(tmp_path):
+    """the deferred cross-rank half of the DINO centre update (graph replay) against the eager step, two ranks."""
+    from parity_log import parity
+
+    out = str(tmp_path / "center")
+    for graphed in (True, False):
+        mp.spawn(_entry, args=(2, _free_port(), _dino_center_case, (graphed, out)), nprocs=2, join=True)
+    a, b = torch.load(out + ".1"), torch.load(out + ".0")
+    # same decisions, weights and batches; the ViT path keeps f32 atomics in the LayerNorm parameter gradients, so the
+    # second step's teacher differs in the last bits between any two runs
+    parity("DINO centre after 2 data-parallel steps, graph replay vs eager (relative L2)", float((a - b).norm() / b.norm()), 2e-3)
