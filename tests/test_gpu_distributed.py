@@ -338,4 +338,5 @@ def test_dino_center_under_graph_replay_equals_eager_world2(tmp_path):
     a, b = torch.load(out + ".1"), torch.load(out + ".0")
     # same decisions, weights and batches; the ViT path keeps f32 atomics in the LayerNorm parameter gradients, so the
     # second step's teacher differs in the last bits between any two runs
-    parity("DINO centre after 2 data-parallel steps, graph replay vs eager (relative L2)", float((a - b).norm() / b.norm()), 2e-3)
+    parity("DINO centre after 2 data-parallel steps, graph replay vs eager (relative L2)", float((a - b).norm() / b.norm()), 1e-4,
+           note="measured 0 (identical); the bound leaves room for the f32-atomic LayerNorm gradient sums of the ViT path")
