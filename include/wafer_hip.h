@@ -46,6 +46,9 @@ const char* wm_error_string(int code);
  * lightly's std_of_l2_normalized monitor, :239), one block, fixed summation order. */
 int wm_fill_zero(void* p, size_t bytes, void* stream);
 int wm_mean_f32(const float* x, long long n, float scale, int sqrt_of, float* out, void* stream);
+/* y = x * *scale_dev over n bf16 elements (n % 8 == 0, 16-byte aligned): the device-resident upstream gradient of a scalar
+ * loss applied to the gradient tensor its forward pass saved (no host read of the scalar, no f32 round trip through HBM). */
+int wm_scale_bf16(const void* x, long long n, const float* scale_dev, void* y, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Two-view augmentation.

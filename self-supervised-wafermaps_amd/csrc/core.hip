@@ -72,6 +72,34 @@ __global__ __launch_bounds__(1024) void mean_kernel(const float* __restrict__ x,
 }
 }  // namespace
 
+namespace {
+// y = x * *scale (bf16 -> bf16 through f32): the upstream gradient of a scalar loss applied to a saved gradient tensor
+__global__ __launch_bounds__(256) void scale_bf16_kernel(const uint16_t* __restrict__ x, long long n8, const float* __restrict__ scale,
+                                                        uint16_t* __restrict__ y) {
+  const float s = *scale;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+    const uint4 v = reinterpret_cast<const uint4*>(x)[i];
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      o[q] = pack_bf2(bf2f((uint16_t)(w[q] & 0xffff)) * s, bf2f((uint16_t)(w[q] >> 16)) * s);
+    reinterpret_cast<uint4*>(y)[i] = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+}  // namespace
+
+extern "C" int wm_scale_bf16(const void* x, long long n, const float* scale_dev, void* y, void* stream) {
+  WM_REQUIRE(x && y && scale_dev && n > 0, WM_EINVAL);
+  WM_REQUIRE(n % 8 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0, WM_EALIGN);
+  const long long n8 = n / 8;
+  const long long blocks = (n8 + 255) / 256;
+  scale_bf16_kernel<<<(unsigned)(blocks < 4096 ? blocks : 4096), 256, 0, static_cast<hipStream_t>(stream)>>>(
+      static_cast<const uint16_t*>(x), n8, scale_dev, static_cast<uint16_t*>(y));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
 extern "C" int wm_fill_zero(void* p, size_t bytes, void* stream) {
   WM_REQUIRE(p && bytes > 0, WM_EINVAL);
   WM_REQUIRE(bytes % 4 == 0 && (reinterpret_cast<uintptr_t>(p) & 3) == 0, WM_EALIGN);

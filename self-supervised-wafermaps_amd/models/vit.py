@@ -165,12 +165,19 @@ class VisionTransformer(nn.Module):
         tok = torch.cat(toks, dim=0)
         for blk in self.blocks:
             tok = blk(tok, 0, 0, segments=segments)
-        cls, off = [], 0
-        for n, seq in segments:
-            idx = torch.zeros((n, 1), dtype=torch.int64, device=tok.device)
-            cls.append(vit_ops.gather_rows(tok[off:off + n * seq], idx, n, seq))
-            off += n * seq
-        return self.norm(torch.cat(cls, dim=0))
+        # the class-token rows of all segments in ONE gather over the concatenated rows (one zero-filled gradient buffer
+        # and one scatter in the backward pass, instead of a slice + gather per segment)
+        rows = tok.shape[0]
+
+        def build():
+            parts, off = [], 0
+            for n, seq in segments:
+                parts.append(off + torch.arange(n, dtype=torch.int64, device=tok.device) * seq)
+                off += n * seq
+            return torch.cat(parts).reshape(1, -1).contiguous()
+
+        idx = vit_ops.cached_index(("cls_rows", tuple(segments), str(tok.device)), build)
+        return self.norm(vit_ops.gather_rows(tok, idx, 1, rows))
 
     def forward(self, x):
         """images [N, 3, S, S] -> class-token features [N, D] (bf16), as dino's forward()."""
@@ -178,7 +185,7 @@ class VisionTransformer(nn.Module):
         for blk in self.blocks:
             tok = blk(tok, n, seq)
         # LayerNorm is per token: normalise only the class tokens
-        idx = torch.zeros((n, 1), dtype=torch.int64, device=tok.device)
+        idx = vit_ops.cached_index(("cls0", n, str(tok.device)), lambda: torch.zeros((n, 1), dtype=torch.int64, device=tok.device))
         cls = vit_ops.gather_rows(tok, idx, n, seq)
         return self.norm(cls)
 

@@ -26,6 +26,29 @@ def _bf16_rows(x: torch.Tensor) -> torch.Tensor:
     return x.contiguous()
 
 
+def _zeros(shape, dtype, device) -> torch.Tensor:
+    """torch.zeros by the library's own fill kernel (keeps framework launches out of the captured step)."""
+    t = torch.empty(shape, dtype=dtype, device=device)
+    nbytes = t.numel() * t.element_size()
+    if nbytes % 4 or not t.is_cuda:
+        return t.zero_()
+    check(_lib.load().wm_fill_zero(ptr(t), nbytes, stream_ptr()), "wm_fill_zero")
+    return t
+
+
+_INDEX_CACHE = {}
+
+
+def cached_index(key, build) -> torch.Tensor:
+    """A constant int64 index tensor (class-token rows, patch rows of a token grid) built once per (shape, device)."""
+    t = _INDEX_CACHE.get(key)
+    if t is None:
+        if len(_INDEX_CACHE) > 256:
+            _INDEX_CACHE.clear()
+        t = _INDEX_CACHE[key] = build()
+    return t
+
+
 def _grad_target(p: torch.Tensor):
     """(buffer the kernels accumulate into, value to hand to autograd)."""
     slot = _arena_grad(p)
@@ -496,7 +519,12 @@ class _TokensAssemble(torch.autograd.Function):
         s = np_ + 1
         dpos = torch.empty(s * d, dtype=torch.float32, device=dx.device)
         check(_lib.load().wm_colsum_bf16(ptr(dx), n, s * d, ptr(dpos), 0, stream_ptr()), "wm_colsum_bf16")
-        dpatch = dx.view(n, s, d)[:, 1:].reshape(n * np_, d)
+        # the patch rows (every token but the class token of each image) by the row-gather kernel: a strided slice +
+        # reshape would be an ATen copy kernel
+        idx = cached_index(("patch_rows", n, np_, str(dx.device)),
+                           lambda: torch.arange(1, s, dtype=torch.int64, device=dx.device).repeat(n, 1).contiguous())
+        dpatch = torch.empty((n * np_, d), dtype=torch.bfloat16, device=dx.device)
+        check(_lib.load().wm_gather_rows(ptr(dx), ptr(idx), n, s, np_, d, ptr(dpatch), stream_ptr()), "wm_gather_rows")
         cls_shape, pos_shape = ctx.shapes
         return dpatch, dpos[:d].reshape(cls_shape), dpos.reshape(pos_shape), None, None
 
@@ -525,7 +553,7 @@ class _GatherRows(torch.autograd.Function):
         (idx,) = ctx.saved_tensors
         b, s, k, c = ctx.geom
         dy = _bf16_rows(dy)
-        dx = torch.zeros((b * s, c), dtype=torch.bfloat16, device=dy.device)
+        dx = _zeros((b * s, c), torch.bfloat16, dy.device)
         check(_lib.load().wm_scatter_rows(ptr(dy), ptr(idx), b, s, k, c, ptr(dx), stream_ptr()), "wm_scatter_rows")
         return dx, None, None, None
 
@@ -608,7 +636,7 @@ class _DinoLoss(torch.autograd.Function):
         d = student.shape[1]
         if student.shape[0] != vs * b or tuple(probs.shape) != (vt * b, d) or probs.dtype != torch.float32:
             raise ValueError(f"dino_loss: student {tuple(student.shape)}, probs {tuple(probs.shape)} {probs.dtype}")
-        loss = torch.zeros(1, dtype=torch.float32, device=student.device)
+        loss = _zeros((1,), torch.float32, student.device)
         dstudent = torch.empty_like(student)
         check(_lib.load().wm_dino_loss_fwd_bwd(ptr(student), ptr(probs.contiguous()), vs, vt, b, d, temp_s, ptr(loss),
                                                ptr(dstudent), stream_ptr()), "wm_dino_loss_fwd_bwd")
@@ -618,6 +646,12 @@ class _DinoLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         (dstudent,) = ctx.saved_tensors
+        if dstudent.numel() % 8 == 0 and g.numel() == 1 and g.is_cuda:
+            # the loss's upstream gradient stays on the device: one launch instead of cast, multiply, cast
+            out = torch.empty_like(dstudent)
+            gs = g.detach().reshape(1).to(torch.float32)
+            check(_lib.load().wm_scale_bf16(ptr(dstudent), dstudent.numel(), ptr(gs), ptr(out), stream_ptr()), "wm_scale_bf16")
+            return out, None, None, None, None, None
         return (dstudent.float() * g).to(torch.bfloat16), None, None, None, None, None
 
 

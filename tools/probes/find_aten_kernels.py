@@ -47,24 +47,27 @@ for i in range(3):
 torch.cuda.synchronize()
 from torch.profiler import ProfilerActivity, profile  # noqa: E402
 
-with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], record_shapes=True) as prof:
     for i in range(2):
         step(3 + i)
     torch.cuda.synchronize()
 agg = collections.Counter()
+LAUNCHERS = ("aten::copy_", "aten::fill_", "aten::add_", "aten::add", "aten::mul", "aten::mul_", "aten::cat", "aten::index",
+             "aten::_to_copy", "aten::zero_", "aten::div", "aten::div_", "aten::sum", "aten::mean", "aten::clone",
+             "aten::index_select", "aten::gather", "aten::scatter_", "aten::sub", "aten::neg", "aten::where")
 for ev in prof.events():
-    n = ev.name
-    if not (n.startswith("aten::") or "Memcpy" in n or "Memset" in n):
+    if ev.name not in LAUNCHERS and "Memcpy" not in ev.name:
         continue
-    if n in ("aten::empty", "aten::empty_like", "aten::view", "aten::reshape", "aten::as_strided", "aten::detach", "aten::slice",
-             "aten::select", "aten::empty_strided", "aten::_unsafe_view", "aten::alias", "aten::t", "aten::transpose",
-             "aten::expand", "aten::unsqueeze", "aten::squeeze", "aten::narrow", "aten::permute", "aten::result_type",
-             "aten::is_nonzero", "aten::item", "aten::_local_scalar_dense", "aten::lift_fresh", "aten::detach_", "aten::to",
-             "aten::contiguous", "aten::view_as", "aten::unbind", "aten::split", "aten::chunk", "aten::flatten",
-             "aten::resolve_conj", "aten::resolve_neg", "aten::set_", "aten::stride", "aten::size"):
-        continue
-    frames = [f for f in (ev.stack or []) if "ssl_wafermap_amd" in f or "self-supervised" in f or "bench" in f]
-    where = frames[0].strip()[-110:] if frames else "(autograd engine / no python frame)"
-    agg[(n, where)] += 1
-for (n, where), c in sorted(agg.items(), key=lambda t: -t[1])[:70]:
-    print(f"{c / 2:7.1f}/step  {n:32s} {where}")
+    # a kernel-launching ATen op: who called it?  (the chain of enclosing profiler ranges: autograd nodes, custom Functions)
+    chain, par = [], ev.cpu_parent
+    while par is not None and len(chain) < 6:
+        chain.append(par.name)
+        par = par.cpu_parent
+    shape = ""
+    try:
+        shape = str(ev.input_shapes)[:60]
+    except Exception:
+        pass
+    agg[(ev.name, " < ".join(chain)[:150], shape)] += 1
+for (n, where, shape), c in sorted(agg.items(), key=lambda t: -t[1])[:80]:
+    print(f"{c / 2:6.1f}/step  {n:16s} {shape:60s} {where}")
