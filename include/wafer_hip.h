@@ -287,6 +287,18 @@ int wm_linear_dgrad_gelu(const void* dy, const void* w_crsk, const void* pre, vo
 int wm_mlp_fused_fwd_ok(int rows, int C, int H);
 int wm_mlp_fused_fwd(const void* x, const void* w1_krsc, const float* b1, const void* w2_krsc, const float* b2,
                      const void* residual, void* y, int rows, int C, int H, void* stream);
+/* The same with the block's LayerNorm folded in (forward passes that keep nothing for a backward pass): the normalised
+ * rows exist only as register fragments of the workgroup that multiplies them.
+ *   wm_ln_linear_fwd     y = LayerNorm(x) W^T + bias                      (norm1 -> qkv; served: C = 192, N >= 384, N % 64 == 0)
+ *   wm_ln_mlp_fused_fwd  y = fc2(gelu(fc1(LayerNorm(x)) + b1)) + b2 (+ residual)   (norm2 -> MLP; shapes of wm_mlp_fused_fwd)
+ * Same arithmetic as wm_layernorm_fwd followed by the unfused launches (two-pass statistics, bf16 rounding of the
+ * normalised rows). */
+int wm_ln_linear_fwd_ok(int rows, int C, int N);
+int wm_ln_linear_fwd(const void* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_krsc,
+                     const float* bias, void* y, int rows, int C, int N, void* stream);
+int wm_ln_mlp_fused_fwd(const void* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w1_krsc,
+                        const float* b1, const void* w2_krsc, const float* b2, const void* residual, void* y, int rows,
+                        int C, int H, void* stream);
 
 /* f32 OIHW master weights -> bf16 [K][R][S][C] and/or [C][R][S][K] (either may be NULL). */
 int wm_weights_prepare(const float* w_oihw, int K, int C, int R, int S, void* w_krsc, void* w_crsk,

@@ -50,6 +50,10 @@ class WmViewParams(ctypes.Structure):
 SIGNATURES = {
     "wm_version": (c_int, []),
     "wm_error_string": (c_char_p, [c_int]),
+    "wm_ln_linear_fwd_ok": (c_int, [c_int, c_int, c_int]),
+    "wm_ln_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
+    "wm_ln_mlp_fused_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
+                                    c_void_p, c_int, c_int, c_int, c_void_p]),
     "wm_scale_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
     "wm_fill_zero": (c_int, [c_void_p, c_size_t, c_void_p]),
     "wm_mean_f32": (c_int, [c_void_p, c_longlong, c_float, c_int, c_void_p, c_void_p]),

@@ -1593,7 +1593,7 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   a.nkt = R * S * (C / 64);
   if (R == 1 && S == 1 && stride == 1 && pad == 0 && stat == nullptr && wm_panel_ok(a.M, C, K, residual != nullptr)) {
     // Linear with a 192-wide input (ViT-Tiny): token rows resident in registers, weight tiles streamed (panel.hip)
-    WmPanelArgs pa{a.src, a.wt, bias, a.res, nullptr, a.pre_out, a.dst, a.M, K, a.act, 0, 0};
+    WmPanelArgs pa{a.src, a.wt, bias, a.res, nullptr, a.pre_out, a.dst, a.M, K, a.act, 0, nullptr, nullptr, 0.f, 0};
     return wm_panel_launch(pa, st);
   }
   if (residual == nullptr && conv_patch_ok(a)) return launch_patch<0>(a, st);
@@ -1720,7 +1720,7 @@ static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const v
   if (R == 1 && S == 1 && stride == 1 && pad == 0 && bnb == nullptr &&
       wm_panel_ok(a.M, K, C, residual != nullptr || pre_in != nullptr)) {
     // input gradient of a Linear with 192 OUTPUT features: dx = dy [rows][192] . w_crsk^T, w_crsk [C][192]
-    WmPanelArgs pa{a.src, a.wt, nullptr, a.res, a.pre_in, nullptr, a.dst, a.M, C, a.act, 0, 0};
+    WmPanelArgs pa{a.src, a.wt, nullptr, a.res, a.pre_in, nullptr, a.dst, a.M, C, a.act, 0, nullptr, nullptr, 0.f, 0};
     return wm_panel_launch(pa, st);
   }
   if (pre_in != nullptr)

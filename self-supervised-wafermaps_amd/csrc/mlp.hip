@@ -28,6 +28,7 @@
 // the staged outputs before bias / residual), so the result is BIT-IDENTICAL to wm_linear_bias_gelu_fwd followed by
 // wm_conv2d_fwd_bias_res (tests/test_gpu_vit.py).
 #include "common.h"
+#include "ln_regs.h"
 
 namespace {
 
@@ -45,6 +46,9 @@ struct MlpArgs {
   const uint16_t* res;  // [rows][C] or NULL
   uint16_t* y;          // [rows][C]
   int rows, H;
+  const float* ln_gamma;  // optional LayerNorm of the token rows first ([C]); the residual stays the un-normalised input
+  const float* ln_beta;
+  float ln_eps;
 };
 
 
@@ -121,6 +125,8 @@ __global__ __launch_bounds__(ML_THREADS) void mlp_fused_fwd(const MlpArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xr[i][ks] = *reinterpret_cast<const bf16x8_t*>(xp + ks * 32);
   }
+
+  if (a.ln_gamma != nullptr) wm_ln_fragments<KS>(xr, a.ln_gamma, a.ln_beta, a.ln_eps, fg);
 
   f32x4_t acc1[4][2];      // fc1: 64 hidden x 32 tokens per wave
   f32x4_t acc2[OJ][2];     // fc2: C/2 outputs x 32 tokens per wave
@@ -253,14 +259,34 @@ extern "C" int wm_mlp_fused_fwd_ok(int rows, int C, int H) {
   return rows > 0 && rows <= 256 * 128 && C == 192 && H > 0 && H % 128 == 0 ? 1 : 0;
 }
 
+static int mlp_launch(const void* x, const void* w1_krsc, const float* b1, const void* w2_krsc, const float* b2,
+                      const void* residual, void* y, int rows, int C, int H, const float* ln_gamma, const float* ln_beta,
+                      float ln_eps, void* stream);
+
 extern "C" int wm_mlp_fused_fwd(const void* x, const void* w1_krsc, const float* b1, const void* w2_krsc, const float* b2,
                                 const void* residual, void* y, int rows, int C, int H, void* stream) {
+  return mlp_launch(x, w1_krsc, b1, w2_krsc, b2, residual, y, rows, C, H, nullptr, nullptr, 0.f, stream);
+}
+
+// y = fc2(gelu(fc1(LayerNorm(x)) + b1)) + b2 (+ residual): the second half of a pre-norm transformer block in one launch
+// (residual = x gives x + mlp(norm2(x))); the normalised rows exist only as register fragments.
+extern "C" int wm_ln_mlp_fused_fwd(const void* x, const float* ln_gamma, const float* ln_beta, float ln_eps,
+                                   const void* w1_krsc, const float* b1, const void* w2_krsc, const float* b2,
+                                   const void* residual, void* y, int rows, int C, int H, void* stream) {
+  WM_REQUIRE(ln_gamma && ln_beta, WM_EINVAL);
+  WM_REQUIRE((reinterpret_cast<uintptr_t>(ln_gamma) & 15) == 0 && (reinterpret_cast<uintptr_t>(ln_beta) & 15) == 0, WM_EALIGN);
+  return mlp_launch(x, w1_krsc, b1, w2_krsc, b2, residual, y, rows, C, H, ln_gamma, ln_beta, ln_eps, stream);
+}
+
+static int mlp_launch(const void* x, const void* w1_krsc, const float* b1, const void* w2_krsc, const float* b2,
+                      const void* residual, void* y, int rows, int C, int H, const float* ln_gamma, const float* ln_beta,
+                      float ln_eps, void* stream) {
   WM_REQUIRE(x && w1_krsc && b1 && w2_krsc && b2 && y, WM_EINVAL);
   WM_REQUIRE(wm_mlp_fused_fwd_ok(rows, C, H), WM_EUNSUPPORTED);
   auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
   WM_REQUIRE(al(x) && al(w1_krsc) && al(b1) && al(w2_krsc) && al(b2) && al(y) && (residual == nullptr || al(residual)), WM_EALIGN);
   MlpArgs a{static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w1_krsc), b1, static_cast<const uint16_t*>(w2_krsc),
-            b2, static_cast<const uint16_t*>(residual), static_cast<uint16_t*>(y), rows, H};
+            b2, static_cast<const uint16_t*>(residual), static_cast<uint16_t*>(y), rows, H, ln_gamma, ln_beta, ln_eps};
   constexpr int lds = 2 * ML_PANEL + 5 * 192 * ML_ROWB;
   static bool attr = false;
   if (!attr) {

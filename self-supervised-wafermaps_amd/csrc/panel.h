@@ -15,6 +15,9 @@ struct WmPanelArgs {
   int rows, N;
   int act;                 // 0: (+ bias) (+ residual); 1: + bias, pre_out, GELU; 2: * gelu'(pre_in)
   int tiles_per_block;     // set by wm_panel_launch
+  const float* ln_gamma;   // optional LayerNorm applied to the token rows first (on the register fragments): [192]
+  const float* ln_beta;
+  float ln_eps;
   int debug;               // WM_PANEL_DEBUG bits (timing experiments): 1 no stores, 2 no MFMAs, 4 no staging, 8 no x rows
 };
 

@@ -23,6 +23,7 @@
 // leaves room for one block per CU only.
 #include "common.h"
 #include "panel.h"
+#include "ln_regs.h"
 #include <stdlib.h>
 
 namespace {
@@ -47,7 +48,9 @@ __device__ __forceinline__ void pn_wait(int n) {
   }
 }
 
-template <int C>
+// LN: LayerNorm of the token rows on the register fragments first (its own instantiation: the normalisation's
+// temporaries would otherwise raise the plain kernel's register count from 94 to 252 and halve its blocks per CU)
+template <int C, bool LN>
 __global__ __launch_bounds__(PN_THREADS, 2) void linear_panel(const WmPanelArgs a) {
   static_assert(C % 64 == 0 && C <= 192, "x fragments must fit the register budget of two blocks per CU");
   constexpr int XP = C / 64;                  // 64-wide k panels = DMA instructions per thread and tile
@@ -92,6 +95,7 @@ __global__ __launch_bounds__(PN_THREADS, 2) void linear_panel(const WmPanelArgs 
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) xf[i][ks] = *reinterpret_cast<const bf16x8_t*>(xr + ks * 32);
   }
+  if constexpr (LN) wm_ln_fragments<KS>(xf, a.ln_gamma, a.ln_beta, a.ln_eps, fg);
   // the block's bias slice -> LDS (the loop below must not consume ordinary loads: with DMA instructions in flight
   // every such use drains the whole queue)
   if (a.bias != nullptr) {
@@ -194,8 +198,11 @@ int wm_panel_launch(WmPanelArgs a, hipStream_t st) {
   constexpr int lds = PN_STAGES * (192 / 64) * PN_PANEL + PN_MAX_N * 4;
   static bool attr = false;
   if (!attr) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_panel<192>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_panel<192, false>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (e == hipSuccess)
+      e = hipFuncSetAttribute(reinterpret_cast<const void*>(&linear_panel<192, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     if (e != hipSuccess) return (int)e;
     attr = true;
   }
@@ -215,7 +222,24 @@ int wm_panel_launch(WmPanelArgs a, hipStream_t st) {
     const char* f = getenv("WM_PANEL_SPLIT");
     if (f && atoi(f) > 0 && tiles % atoi(f) == 0) { split = atoi(f); a.tiles_per_block = tiles / split; }
   }
-  linear_panel<192><<<dim3(rowtiles, split), PN_THREADS, lds, st>>>(a);
+  if (a.ln_gamma != nullptr) linear_panel<192, true><<<dim3(rowtiles, split), PN_THREADS, lds, st>>>(a);
+  else linear_panel<192, false><<<dim3(rowtiles, split), PN_THREADS, lds, st>>>(a);
   WM_LAUNCH_CHECK();
   return WM_OK;
+}
+
+// y = LayerNorm(x; gamma, beta, eps) W^T + bias in ONE launch, for forward passes that keep nothing for a backward pass
+// (DINO teacher, inference): the normalised rows exist only as register fragments.  x [rows][192] bf16, w_krsc [N][192]
+// bf16, bias [N] f32 or NULL, y [rows][N] bf16.
+extern "C" int wm_ln_linear_fwd_ok(int rows, int C, int N) { return wm_panel_ok(rows, C, N, false) ? 1 : 0; }
+
+extern "C" int wm_ln_linear_fwd(const void* x, const float* ln_gamma, const float* ln_beta, float ln_eps, const void* w_krsc,
+                                const float* bias, void* y, int rows, int C, int N, void* stream) {
+  WM_REQUIRE(x && ln_gamma && ln_beta && w_krsc && y, WM_EINVAL);
+  WM_REQUIRE(wm_panel_ok(rows, C, N, false), WM_EUNSUPPORTED);
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  WM_REQUIRE(al(x) && al(ln_gamma) && al(ln_beta) && al(w_krsc) && al(y) && (bias == nullptr || al(bias)), WM_EALIGN);
+  WmPanelArgs pa{static_cast<const uint16_t*>(x), static_cast<const uint16_t*>(w_krsc), bias, nullptr, nullptr, nullptr,
+                 static_cast<uint16_t*>(y), rows, N, 0, 0, ln_gamma, ln_beta, ln_eps, 0};
+  return wm_panel_launch(pa, static_cast<hipStream_t>(stream));
 }

@@ -29,8 +29,9 @@ class Attention(nn.Module):
         self.qkv = hnn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = hnn.Linear(dim, dim, bias=True)
 
-    def forward(self, x, batch: int, seq: int, residual, segments=None):
-        qkv = self.qkv(x)
+    def forward(self, x, batch: int, seq: int, residual, segments=None, qkv=None):
+        if qkv is None:
+            qkv = self.qkv(x)
         if segments is not None:  # several (batch, seq) groups row-concatenated in x
             a = vit_ops.attention_segments(qkv, segments, self.num_heads, self.scale)
         else:
@@ -61,8 +62,18 @@ class Block(nn.Module):
         self.mlp = Mlp(dim, int(dim * mlp_ratio))
 
     def forward(self, x, batch: int, seq: int, segments=None):
-        h, skip = self.norm1.forward_skip(x)
-        x = self.attn(h, batch, seq, residual=skip, segments=segments)
+        # passes that record no gradient (EMA teacher, inference) on shapes the fused kernels serve: LayerNorm folded
+        # into the qkv GEMM and into the one-launch MLP -- the normalised rows never reach memory
+        qkv = vit_ops.ln_linear(x, self.norm1.weight, self.norm1.bias, self.norm1.eps, self.attn.qkv.weight, self.attn.qkv.bias)
+        if qkv is not None:
+            x = self.attn(None, batch, seq, residual=x, segments=segments, qkv=qkv)
+        else:
+            h, skip = self.norm1.forward_skip(x)
+            x = self.attn(h, batch, seq, residual=skip, segments=segments)
+        y = vit_ops.ln_mlp_gelu(x, self.norm2.weight, self.norm2.bias, self.norm2.eps, self.mlp.fc1.weight, self.mlp.fc1.bias,
+                                self.mlp.fc2.weight, self.mlp.fc2.bias)
+        if y is not None:
+            return y
         h, skip = self.norm2.forward_skip(x)
         return self.mlp(h, residual=skip)
 

@@ -359,6 +359,56 @@ def mlp_gelu(x: torch.Tensor, fc1_weight: torch.Tensor, fc1_bias: torch.Tensor, 
     return _MlpGelu.apply(x, fc1_weight, fc1_bias, fc2_weight, fc2_bias, residual)
 
 
+def _no_grad_for(*tensors) -> bool:
+    return not (torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors))
+
+
+def ln_linear(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: torch.Tensor, eps: float, weight: torch.Tensor,
+              bias: Optional[torch.Tensor]):
+    """Linear(LayerNorm(x)) as ONE launch (wm_ln_linear_fwd: the normalised rows exist only as register fragments), for
+    passes that record no gradient and shapes the kernel serves (192-wide rows: ViT-Tiny's norm1 -> qkv).  Returns None
+    when it does not apply: the caller runs the two launches."""
+    if os.environ.get("WM_LN_FUSED", "1") == "0" or not _no_grad_for(x, ln_weight, ln_bias, weight, bias):
+        return None
+    if not (x.is_cuda and x.dim() == 2):
+        return None
+    rows, c = x.shape
+    n = weight.shape[0]
+    lib = _lib.load()
+    if weight.shape[1] != c or not lib.wm_ln_linear_fwd_ok(rows, c, n):
+        return None
+    xb = _bf16_rows(x)
+    krsc, _ = ops._WCACHE.get(weight, kind="linear")
+    y = torch.empty((rows, n), dtype=torch.bfloat16, device=x.device)
+    check(ops._run("gemm_fwd", 2.0 * rows * c * n, lib.wm_ln_linear_fwd, ptr(xb), ptr(ln_weight.detach()), ptr(ln_bias.detach()),
+                   float(eps), ptr(krsc), ptr(bias.detach()) if bias is not None else 0, ptr(y), rows, c, n, stream_ptr()),
+          "wm_ln_linear_fwd")
+    return y
+
+
+def ln_mlp_gelu(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: torch.Tensor, eps: float, fc1_weight: torch.Tensor,
+                fc1_bias: torch.Tensor, fc2_weight: torch.Tensor, fc2_bias: torch.Tensor):
+    """x + fc2(gelu(fc1(LayerNorm(x)))): the second half of a pre-norm block as ONE launch (wm_ln_mlp_fused_fwd), under the
+    same conditions as ln_linear; None when it does not apply."""
+    if os.environ.get("WM_LN_FUSED", "1") == "0" or os.environ.get("WM_MLP_FUSED", "1") == "0":
+        return None
+    if not _no_grad_for(x, ln_weight, ln_bias, fc1_weight, fc1_bias, fc2_weight, fc2_bias) or not (x.is_cuda and x.dim() == 2):
+        return None
+    rows, c = x.shape
+    hid = fc1_weight.shape[0]
+    lib = _lib.load()
+    if fc2_weight.shape[0] != c or not lib.wm_mlp_fused_fwd_ok(rows, c, hid):
+        return None
+    xb = _bf16_rows(x)
+    k1, _ = ops._WCACHE.get(fc1_weight, kind="linear")
+    k2, _ = ops._WCACHE.get(fc2_weight, kind="linear")
+    y = torch.empty((rows, c), dtype=torch.bfloat16, device=x.device)
+    check(ops._run("gemm_fwd", 4.0 * rows * c * hid, lib.wm_ln_mlp_fused_fwd, ptr(xb), ptr(ln_weight.detach()),
+                   ptr(ln_bias.detach()), float(eps), ptr(k1), ptr(fc1_bias.detach()), ptr(k2), ptr(fc2_bias.detach()), ptr(xb),
+                   ptr(y), rows, c, hid, stream_ptr()), "wm_ln_mlp_fused_fwd")
+    return y
+
+
 class _Attention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv, b, s, h, hd, scale):

@@ -810,3 +810,36 @@ def test_panel_linear_is_bit_identical_to_the_tiled_kernel(rows, n, mode, monkey
     assert torch.equal(outs[0][0], outs[1][0])
     if mode == "gelu":
         assert torch.equal(outs[0][1], outs[1][1])
+
+
+@pytest.mark.parametrize("rows_per", [(2, 197), (5, 37), (130, 197)])
+def test_layernorm_folded_into_the_gemms_matches_the_separate_launches(rows_per, monkeypatch):
+    """No-grad passes of a ViT-Tiny block (EMA teacher, inference): norm1 inside the qkv GEMM (wm_ln_linear_fwd) and norm2
+    inside the one-launch MLP (wm_ln_mlp_fused_fwd) -- the normalised rows exist only as register fragments -- against
+    the separate LayerNorm launches.  Same arithmetic (two-pass statistics, bf16 rounding of the normalised rows); the
+    statistics are summed in a different lane order, so single bf16 roundings may flip."""
+    from ssl_wafermap_amd.models.vit import Block
+
+    b, s = rows_per
+    torch.manual_seed(b * s)
+    blk = Block(192, 3).to(DEV).eval()
+    with torch.no_grad():
+        for p_ in blk.parameters():
+            if p_.dim() == 1:
+                p_.add_(torch.randn_like(p_) * 0.1)
+    x = (torch.randn(b * s, 192, device=DEV) * 1.5 + 0.3).bfloat16()
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("WM_LN_FUSED", flag)
+        with torch.no_grad():
+            outs.append(blk(x, b, s).float())
+    ref, got = outs[1], outs[0]
+    parity("LayerNorm folded into qkv / MLP vs separate launches, ViT-Tiny block (relative L2)",
+           float((got - ref).norm() / ref.norm()), 4e-4)  # measured 0 / 3.9e-5 / 1.9e-4
+    parity("LayerNorm folded into qkv / MLP vs separate launches, ViT-Tiny block (max |err| / max |ref|)",
+           float((got - ref).abs().max() / ref.abs().max()), 8e-3)
+    # with gradients recorded the block takes the unfused path (the normalised rows are needed by the backward pass)
+    xg = x.clone().requires_grad_(True)
+    monkeypatch.setenv("WM_LN_FUSED", "1")
+    y = blk(xg, b, s)
+    assert y.grad_fn is not None
