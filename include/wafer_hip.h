@@ -504,6 +504,13 @@ int wm_layernorm_bwd(const void* x, const void* dy, const float* gamma, const fl
  * dx = bf16(LN'(dy)) + dres, dres bf16 [rows][C].  Replaces the accumulation pass autograd runs for the two uses of x. */
 int wm_layernorm_bwd_add(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
                          long long rows, int C, const void* dres, void* dx, float* dgamma, float* dbeta, void* stream);
+/* LayerNorm backward with the parameter-gradient sums as per-block SLOTS instead of f32 atomics (bit-reproducible):
+ * part [2][wm_layernorm_bwd_blocks(rows, C)][C] f32 -- the dgamma slots, then the dbeta slots, every slot overwritten; the
+ * caller adds them in slot order (wm_wgrad_fold / wm_wgrad_finalize with K = 1, RS = 1).  dres as in
+ * wm_layernorm_bwd_add, may be NULL. */
+int wm_layernorm_bwd_blocks(long long rows, int C);
+int wm_layernorm_bwd_parts(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
+                           long long rows, int C, const void* dres, void* dx, float* part, void* stream);
 
 /* y = act(x + bias) (+ residual).  act: 0 identity, 1 exact GELU (erf), 2 ReLU (the bias-carrying heads:
  * lightly MoCoProjectionHead).  bias / residual may be NULL. */

@@ -54,6 +54,9 @@ SIGNATURES = {
     "wm_ln_linear_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p]),
     "wm_ln_mlp_fused_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p,
                                     c_void_p, c_int, c_int, c_int, c_void_p]),
+    "wm_layernorm_bwd_blocks": (c_int, [c_longlong, c_int]),
+    "wm_layernorm_bwd_parts": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p,
+                                       c_void_p, c_void_p]),
     "wm_scale_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
     "wm_fill_zero": (c_int, [c_void_p, c_size_t, c_void_p]),
     "wm_mean_f32": (c_int, [c_void_p, c_longlong, c_float, c_int, c_void_p, c_void_p]),

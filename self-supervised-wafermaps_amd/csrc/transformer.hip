@@ -132,7 +132,10 @@ __global__ __launch_bounds__(TF_THREADS) void ln_bwd(const uint16_t* __restrict_
                                                      const float* __restrict__ gamma, const float* __restrict__ mean,
                                                      const float* __restrict__ rstd, long long rows, int C,
                                                      const uint16_t* __restrict__ dres, uint16_t* __restrict__ dx,
-                                                     float* __restrict__ dgamma, float* __restrict__ dbeta) {
+                                                     float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                     float* __restrict__ part) {
+  // part (optional, round 3): [2][gridDim.x][C] f32 -- the block STORES its per-channel sums into its own slot instead
+  // of adding them to dgamma / dbeta with f32 atomics; the batched fold adds the slots in order (bit-reproducible)
   // dres (optional): the gradient that reaches x along the residual connection around the normalised branch
   // (x -> LN -> f -> + x); added here so autograd needs no separate accumulation pass over the activation
   __shared__ float red[2 * 2048];
@@ -240,6 +243,13 @@ __global__ __launch_bounds__(TF_THREADS) void ln_bwd(const uint16_t* __restrict_
       }
     }
     __syncthreads();
+  }
+  if (part != nullptr) {
+    for (int c = threadIdx.x; c < C; c += TF_THREADS) {
+      part[(size_t)blockIdx.x * C + c] = red[c];
+      part[((size_t)gridDim.x + blockIdx.x) * C + c] = red[2048 + c];
+    }
+    return;
   }
   for (int c = threadIdx.x; c < C; c += TF_THREADS) {
     atomicAdd(dgamma + c, red[c]);
@@ -872,10 +882,16 @@ extern "C" int wm_layernorm_fwd(const void* x, const float* gamma, const float* 
   return WM_OK;
 }
 
+static int ln_bwd_blocks(long long rows, int C) {
+  const int rpb = C <= 256 ? 32 : C <= 512 ? 16 : C <= 1024 ? 8 : 4;
+  const long long blocks = (rows + rpb - 1) / rpb;
+  return (int)(blocks > 768 ? 768 : blocks);  // 3 resident blocks per CU: one round; short atomic chains
+}
+
 static int layernorm_bwd_impl(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
                               long long rows, int C, const void* dres, void* dx, float* dgamma, float* dbeta,
-                              void* stream) {
-  WM_REQUIRE(x && dy && gamma && mean && rstd && dx && dgamma && dbeta, WM_EINVAL);
+                              void* stream, float* part = nullptr) {
+  WM_REQUIRE(x && dy && gamma && mean && rstd && dx && ((dgamma && dbeta) || part), WM_EINVAL);
   WM_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
   WM_REQUIRE(C <= 64 * 8 * LN_MAXV, WM_EUNSUPPORTED);
   WM_REQUIRE(al16(x) && al16(dy) && al16(dx) && al16(gamma) && al16(dres), WM_EALIGN);
@@ -884,14 +900,11 @@ static int layernorm_bwd_impl(const void* x, const void* dy, const float* gamma,
   const uint16_t* dp = static_cast<const uint16_t*>(dy);
   const uint16_t* rp = static_cast<const uint16_t*>(dres);
   uint16_t* op = static_cast<uint16_t*>(dx);
-  auto grid = [&](int rows_per_block) {
-    long long blocks = (rows + rows_per_block - 1) / rows_per_block;
-    return (int)(blocks > 768 ? 768 : blocks);  // 3 resident blocks per CU: one round; short atomic chains
-  };
-  if (C <= 256) ln_bwd<32, 1, 4><<<grid(32), TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta);
-  else if (C <= 512) ln_bwd<64, 1, 4><<<grid(16), TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta);
-  else if (C <= 1024) ln_bwd<64, 2, 2><<<grid(8), TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta);
-  else ln_bwd<64, 4, 1><<<grid(4), TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta);
+  const int nb = ln_bwd_blocks(rows, C);
+  if (C <= 256) ln_bwd<32, 1, 4><<<nb, TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta, part);
+  else if (C <= 512) ln_bwd<64, 1, 4><<<nb, TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta, part);
+  else if (C <= 1024) ln_bwd<64, 2, 2><<<nb, TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta, part);
+  else ln_bwd<64, 4, 1><<<nb, TF_THREADS, 0, st>>>(xp, dp, gamma, mean, rstd, rows, C, rp, op, dgamma, dbeta, part);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -907,6 +920,20 @@ extern "C" int wm_layernorm_bwd_add(const void* x, const void* dy, const float* 
                                     float* dgamma, float* dbeta, void* stream) {
   WM_REQUIRE(dres, WM_EINVAL);
   return layernorm_bwd_impl(x, dy, gamma, mean, rstd, rows, C, dres, dx, dgamma, dbeta, stream);
+}
+
+// The same with the parameter-gradient sums as per-block slots: part [2][wm_layernorm_bwd_blocks(rows, C)][C] f32
+// (dgamma slots, then dbeta slots), every slot overwritten; the caller adds the slots in order (wm_wgrad_fold /
+// wm_wgrad_finalize with K = 1).  dres may be NULL.
+extern "C" int wm_layernorm_bwd_blocks(long long rows, int C) {
+  if (rows <= 0 || C <= 0 || C % 8) return 0;
+  return ln_bwd_blocks(rows, C);
+}
+extern "C" int wm_layernorm_bwd_parts(const void* x, const void* dy, const float* gamma, const float* mean,
+                                      const float* rstd, long long rows, int C, const void* dres, void* dx,
+                                      float* part, void* stream) {
+  WM_REQUIRE(part, WM_EINVAL);
+  return layernorm_bwd_impl(x, dy, gamma, mean, rstd, rows, C, dres, dx, nullptr, nullptr, stream, part);
 }
 
 extern "C" int wm_bias_act_fwd(const void* x, const float* bias, const void* residual, int act, long long rows, int C,

@@ -58,6 +58,43 @@ def _grad_target(p: torch.Tensor):
     return g, g
 
 
+def _ln_backward(x, dy, gamma, beta, mean, rstd, dskip):
+    """LayerNorm backward (+ the residual-path gradient `dskip` of a pre-norm block) -> (dx, dgamma, dbeta) with the
+    parameter gradients None when they went straight into a fused optimiser's gradient arena.  Round 3: with arena slots
+    the per-block channel sums are STORED as slots [2][blocks][C] (wm_layernorm_bwd_parts) and added in order by the
+    backward pass's batched fold (ops.fold_wgrads) -- no f32 atomics, bit-reproducible; WM_LN_SLOTS=0: the atomic form."""
+    rows, c = x.shape
+    lib = _lib.load()
+    dx = torch.empty_like(x)
+    sg, sb = _arena_grad(gamma), _arena_grad(beta)
+    if sg is not None and sb is not None and c % 4 == 0 and os.environ.get("WM_LN_SLOTS", "1") != "0":
+        nb = int(lib.wm_layernorm_bwd_blocks(rows, c))
+        idx = getattr(gamma, "_hip_pending", 0)       # a LayerNorm applied twice in one pass gets two buffers
+        bufs = getattr(gamma, "_hip_ln_parts", None)
+        if bufs is None:
+            bufs = gamma._hip_ln_parts = []
+        while len(bufs) <= idx:
+            bufs.append(None)
+        part = bufs[idx]
+        if part is None or part.numel() != 2 * nb * c or part.device != x.device:
+            part = bufs[idx] = torch.empty(2 * nb * c, dtype=torch.float32, device=x.device)
+        check(lib.wm_layernorm_bwd_parts(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), rows, c,
+                                         ptr(dskip) if dskip is not None else 0, ptr(dx), ptr(part), stream_ptr()),
+              "wm_layernorm_bwd_parts")
+        ops._queue_fold(gamma, part[: nb * c], nb, sg, 1, c, 1)
+        ops._queue_fold(beta, part[nb * c:], nb, sb, 1, c, 1)
+        return dx, None, None
+    dg, dg_ret = _grad_target(gamma)
+    db, db_ret = _grad_target(beta)
+    if dskip is None:
+        check(lib.wm_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), rows, c, ptr(dx), ptr(dg),
+                                   ptr(db), stream_ptr()), "wm_layernorm_bwd")
+    else:
+        check(lib.wm_layernorm_bwd_add(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), rows, c, ptr(dskip), ptr(dx),
+                                       ptr(dg), ptr(db), stream_ptr()), "wm_layernorm_bwd_add")
+    return dx, dg_ret, db_ret
+
+
 class _LayerNorm(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gamma, beta, eps):
@@ -77,13 +114,7 @@ class _LayerNorm(torch.autograd.Function):
     def backward(ctx, dy):
         x, mean, rstd = ctx.saved_tensors
         gamma, beta = ctx.params
-        rows, c = x.shape
-        dy = _bf16_rows(dy)
-        dx = torch.empty_like(x)
-        dg, dg_ret = _grad_target(gamma)
-        db, db_ret = _grad_target(beta)
-        check(_lib.load().wm_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), rows, c, ptr(dx), ptr(dg),
-                                           ptr(db), stream_ptr()), "wm_layernorm_bwd")
+        dx, dg_ret, db_ret = _ln_backward(x, _bf16_rows(dy), gamma, beta, mean, rstd, None)
         return dx, dg_ret, db_ret, None
 
 
@@ -119,17 +150,8 @@ class _LayerNormSkip(torch.autograd.Function):
         lib = _lib.load()
         if dy is None:  # the normalised branch was not used
             return dskip, None, None, None
-        dy = _bf16_rows(dy)
-        dx = torch.empty_like(x)
-        dg, dg_ret = _grad_target(gamma)
-        db, db_ret = _grad_target(beta)
-        if dskip is None:
-            check(lib.wm_layernorm_bwd(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), rows, c, ptr(dx), ptr(dg),
-                                       ptr(db), stream_ptr()), "wm_layernorm_bwd")
-        else:
-            dskip = _bf16_rows(dskip)
-            check(lib.wm_layernorm_bwd_add(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), rows, c, ptr(dskip), ptr(dx),
-                                           ptr(dg), ptr(db), stream_ptr()), "wm_layernorm_bwd_add")
+        dx, dg_ret, db_ret = _ln_backward(x, _bf16_rows(dy), gamma, beta, mean, rstd,
+                                          _bf16_rows(dskip) if dskip is not None else None)
         return dx, dg_ret, db_ret, None
 
 

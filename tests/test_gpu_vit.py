@@ -843,3 +843,34 @@ def test_layernorm_folded_into_the_gemms_matches_the_separate_launches(rows_per,
     monkeypatch.setenv("WM_LN_FUSED", "1")
     y = blk(xg, b, s)
     assert y.grad_fn is not None
+
+
+def test_layer_norm_parameter_gradients_as_slots_are_bit_reproducible(monkeypatch):
+    """With a fused optimiser owning the gradient slots, the LayerNorm backward stores its per-block channel sums as slots
+    that the pass's batched fold adds in order (wm_layernorm_bwd_parts): two runs give identical bits, and the values equal
+    the atomic form's up to summation order."""
+    from ssl_wafermap_amd import nn as wnn
+    from ssl_wafermap_amd import optim
+
+    def run(slots: str):
+        monkeypatch.setenv("WM_LN_SLOTS", slots)
+        torch.manual_seed(0)
+        ln = wnn.LayerNorm(192, eps=1e-6).to(DEV)
+        with torch.no_grad():
+            ln.weight.uniform_(0.5, 1.5)
+            ln.bias.uniform_(-0.2, 0.2)
+        opt = optim.AdamW(ln.parameters(), lr=1e-3)
+        g = torch.Generator(device=DEV).manual_seed(1)
+        x = (torch.randn(39424, 192, generator=g, device=DEV) * 2).bfloat16().requires_grad_(True)
+        dy = torch.randn(39424, 192, generator=g, device=DEV).bfloat16()
+        opt.zero_grad()
+        y, skip = ln.forward_skip(x)
+        torch.autograd.backward([y, skip], [dy, dy])
+        torch.cuda.synchronize()
+        return ln.weight.grad.clone(), ln.bias.grad.clone(), x.grad.clone()
+
+    a, b, c = run("1"), run("1"), run("0")
+    assert all(torch.equal(u, v) for u, v in zip(a, b)), "slot form: two runs must agree to the bit"
+    assert torch.equal(a[2], c[2])                                    # dx does not depend on the reduction form
+    for u, v, what in ((a[0], c[0], "dgamma"), (a[1], c[1], "dbeta")):
+        parity(f"LayerNorm {what}: slots + ordered fold vs f32 atomics (relative L2)", float((u - v).norm() / v.norm()), 1e-5)
