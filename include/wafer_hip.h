@@ -508,6 +508,11 @@ int wm_layernorm_bwd_add(const void* x, const void* dy, const float* gamma, cons
  * part [2][wm_layernorm_bwd_blocks(rows, C)][C] f32 -- the dgamma slots, then the dbeta slots, every slot overwritten; the
  * caller adds them in slot order (wm_wgrad_fold / wm_wgrad_finalize with K = 1, RS = 1).  dres as in
  * wm_layernorm_bwd_add, may be NULL. */
+/* Column sums likewise: wm_bias_act_bwd_parts = wm_bias_act_bwd with the bias gradient as per-block slots
+ * part [wm_colsum_blocks(rows, C)][C] f32 (act WM_ACT_NONE: the plain column sum of dy; x, bias, dx unused). */
+int wm_colsum_blocks(long long rows, int C);
+int wm_bias_act_bwd_parts(const void* x, const float* bias, const void* dy, int act, long long rows, int C, void* dx,
+                          float* part, void* stream);
 int wm_layernorm_bwd_blocks(long long rows, int C);
 int wm_layernorm_bwd_parts(const void* x, const void* dy, const float* gamma, const float* mean, const float* rstd,
                            long long rows, int C, const void* dres, void* dx, float* part, void* stream);

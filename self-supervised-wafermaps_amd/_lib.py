@@ -57,6 +57,8 @@ SIGNATURES = {
     "wm_layernorm_bwd_blocks": (c_int, [c_longlong, c_int]),
     "wm_layernorm_bwd_parts": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_void_p, c_void_p,
                                        c_void_p, c_void_p]),
+    "wm_colsum_blocks": (c_int, [c_longlong, c_int]),
+    "wm_bias_act_bwd_parts": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p, c_void_p]),
     "wm_scale_bf16": (c_int, [c_void_p, c_longlong, c_void_p, c_void_p, c_void_p]),
     "wm_fill_zero": (c_int, [c_void_p, c_size_t, c_void_p]),
     "wm_mean_f32": (c_int, [c_void_p, c_longlong, c_float, c_int, c_void_p, c_void_p]),

@@ -302,7 +302,9 @@ template <int MODE>
 __global__ __launch_bounds__(TF_THREADS) void colsum_kernel(const uint16_t* __restrict__ x, const float* __restrict__ bias,
                                                             const uint16_t* __restrict__ dy, long long rows, int C,
                                                             int CB, int rows_per_block, uint16_t* __restrict__ dx,
-                                                            float* __restrict__ out) {
+                                                            float* __restrict__ out, float* __restrict__ part) {
+  // part (optional): [gridDim.x][C] f32 -- the block STORES its column sums into its own slot (no f32 atomics; the
+  // caller adds the slots in order)
   __shared__ float red[TF_THREADS * 8];
   const int nch = C >> 3;
   const int RL = TF_THREADS / CB;
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(TF_THREADS) void colsum_kernel(const uint16_t* __re
       for (int e = 0; e < 8; ++e) acc[e] += fd[e];
     }
   }
-  if (out == nullptr) return;
+  if (out == nullptr && part == nullptr) return;
 #pragma unroll
   for (int e = 0; e < 8; ++e) red[threadIdx.x * 8 + e] = on ? acc[e] : 0.f;
   __syncthreads();
@@ -370,7 +372,8 @@ __global__ __launch_bounds__(TF_THREADS) void colsum_kernel(const uint16_t* __re
     for (int e = 0; e < 8; ++e) {
       float s = 0.f;
       for (int j = 0; j < RL; ++j) s += red[(j * CB + cl) * 8 + e];
-      atomicAdd(out + ch * 8 + e, s);
+      if (part != nullptr) part[(size_t)blockIdx.x * C + ch * 8 + e] = s;
+      else atomicAdd(out + ch * 8 + e, s);
     }
   }
 }
@@ -380,22 +383,28 @@ __global__ __launch_bounds__(TF_THREADS) void zero_f32(float* p, long long n) {
     p[i] = 0.f;
 }
 
-template <int MODE>
-int launch_colsum(const void* x, const float* bias, const void* dy, long long rows, int C, void* dx, float* out,
-                  hipStream_t st) {
+inline void colsum_geometry(long long rows, int C, int& CB, int& slabs, int& rb, long long& rpb) {
   const int nch = C >> 3;
-  const int CB = nch <= 64 ? nch : 64;
-  const int slabs = wm_cdiv(nch, CB);
+  CB = nch <= 64 ? nch : 64;
+  slabs = wm_cdiv(nch, CB);
   // ~768 blocks in total (3 per CU), at least 64 rows each: every block ends with one f32 atomic per
   // channel on the SAME addresses, and a chain of N same-address atomics costs ~0.1 us x N
-  int rb = wm_cdiv(768, slabs);
-  long long rpb = (rows + rb - 1) / rb;
+  rb = wm_cdiv(768, slabs);
+  rpb = (rows + rb - 1) / rb;
   if (rpb < 64) rpb = 64;
-  rb = wm_cdiv(rows, rpb);
+  rb = (int)wm_cdiv(rows, rpb);
+}
+
+template <int MODE>
+int launch_colsum(const void* x, const float* bias, const void* dy, long long rows, int C, void* dx, float* out,
+                  hipStream_t st, float* part = nullptr) {
+  int CB, slabs, rb;
+  long long rpb;
+  colsum_geometry(rows, C, CB, slabs, rb, rpb);
   dim3 grid(rb, slabs);
   colsum_kernel<MODE><<<grid, TF_THREADS, 0, st>>>(static_cast<const uint16_t*>(x), bias,
                                                     static_cast<const uint16_t*>(dy), rows, C, CB, (int)rpb,
-                                                    static_cast<uint16_t*>(dx), out);
+                                                    static_cast<uint16_t*>(dx), out, part);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -974,6 +983,29 @@ extern "C" int wm_bias_act_bwd(const void* x, const float* bias, const void* dy,
   WM_REQUIRE(x && dx, WM_EINVAL);
   return act == WM_ACT_GELU ? launch_colsum<2>(x, bias, dy, rows, C, dx, dbias, st)
                             : launch_colsum<3>(x, bias, dy, rows, C, dx, dbias, st);
+}
+
+// Slot forms (bit-reproducible): part [wm_colsum_blocks(rows, C)][C] f32, every slot overwritten; add the slots in order
+// (wm_wgrad_fold / wm_wgrad_finalize with K = 1, RS = 1).
+extern "C" int wm_colsum_blocks(long long rows, int C) {
+  if (rows <= 0 || C <= 0 || C % 8) return 0;
+  int CB, slabs, rb;
+  long long rpb;
+  colsum_geometry(rows, C, CB, slabs, rb, rpb);
+  return rb;
+}
+
+extern "C" int wm_bias_act_bwd_parts(const void* x, const float* bias, const void* dy, int act, long long rows, int C,
+                                     void* dx, float* part, void* stream) {
+  WM_REQUIRE(dy && part, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && C > 0 && C % 8 == 0, WM_EINVAL);
+  WM_REQUIRE(al16(x) && al16(dy) && al16(dx) && al16(bias), WM_EALIGN);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (act == WM_ACT_NONE) return launch_colsum<1>(nullptr, nullptr, dy, rows, C, nullptr, nullptr, st, part);
+  WM_REQUIRE(act == WM_ACT_GELU || act == WM_ACT_RELU, WM_EUNSUPPORTED);
+  WM_REQUIRE(x && dx, WM_EINVAL);
+  return act == WM_ACT_GELU ? launch_colsum<2>(x, bias, dy, rows, C, dx, nullptr, st, part)
+                            : launch_colsum<3>(x, bias, dy, rows, C, dx, nullptr, st, part);
 }
 
 extern "C" int wm_colsum_bf16(const void* x, long long rows, int C, float* out, int accumulate, void* stream) {

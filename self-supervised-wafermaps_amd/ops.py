@@ -416,15 +416,30 @@ def fold_wgrads() -> None:
     if not _PENDING_FOLDS:
         return
     try:
-        rows = tuple((bs.data_ptr() if bs is not None else 0, bg.data_ptr() if bg is not None else 0, 0, sl.data_ptr(),
-                      slot.data_ptr(), k, c, rs, ns) for _, sl, ns, slot, k, c, rs, bs, bg in _PENDING_FOLDS)
+        # One launch folds every entry whose gradient slot is distinct: its blocks read-modify-write the slots
+        # concurrently.  A parameter used TWICE in the pass (the patch-embedding bias of a multi-resolution forward,
+        # shared weights) has two entries for one slot: the second goes into a second launch behind the first (in order
+        # of use: the sums stay reproducible).
+        waves = []
+        for _, sl, ns, slot, k, c, rs, bs, bg in _PENDING_FOLDS:
+            row = (bs.data_ptr() if bs is not None else 0, bg.data_ptr() if bg is not None else 0, 0, sl.data_ptr(),
+                   slot.data_ptr(), k, c, rs, ns)
+            targets = {slot.data_ptr()} | ({bg.data_ptr()} if bg is not None else set())
+            for wave in waves:
+                if not (wave[1] & targets):
+                    wave[0].append(row)
+                    wave[1] |= targets
+                    break
+            else:
+                waves.append([[row], set(targets)])
         dev = _PENDING_FOLDS[0][1].device
     finally:
         for ent in _PENDING_FOLDS:
             ent[0]._hip_pending = 0
         _PENDING_FOLDS.clear()
-    tab, n, tiles = _desc_table(rows, dev, per_tap=True)
-    check(_lib.load().wm_wgrad_fold(ptr(tab), n, tiles, stream_ptr()), "wm_wgrad_fold")
+    for rows, _ in waves:
+        tab, n, tiles = _desc_table(tuple(rows), dev, per_tap=True)
+        check(_lib.load().wm_wgrad_fold(ptr(tab), n, tiles, stream_ptr()), "wm_wgrad_fold")
 
 
 def _arena_grad(p: torch.Tensor):

@@ -58,6 +58,21 @@ def _grad_target(p: torch.Tensor):
     return g, g
 
 
+def _part_buffer(owner: torch.Tensor, attr: str, numel: int, device) -> torch.Tensor:
+    """A persistent f32 slot buffer of `owner` (one per use of the parameter inside one backward pass)."""
+    idx = getattr(owner, "_hip_pending", 0)
+    bufs = getattr(owner, attr, None)
+    if bufs is None:
+        bufs = []
+        setattr(owner, attr, bufs)
+    while len(bufs) <= idx:
+        bufs.append(None)
+    part = bufs[idx]
+    if part is None or part.numel() != numel or part.device != device:
+        part = bufs[idx] = torch.empty(numel, dtype=torch.float32, device=device)
+    return part
+
+
 def _ln_backward(x, dy, gamma, beta, mean, rstd, dskip):
     """LayerNorm backward (+ the residual-path gradient `dskip` of a pre-norm block) -> (dx, dgamma, dbeta) with the
     parameter gradients None when they went straight into a fused optimiser's gradient arena.  Round 3: with arena slots
@@ -69,15 +84,7 @@ def _ln_backward(x, dy, gamma, beta, mean, rstd, dskip):
     sg, sb = _arena_grad(gamma), _arena_grad(beta)
     if sg is not None and sb is not None and c % 4 == 0 and os.environ.get("WM_LN_SLOTS", "1") != "0":
         nb = int(lib.wm_layernorm_bwd_blocks(rows, c))
-        idx = getattr(gamma, "_hip_pending", 0)       # a LayerNorm applied twice in one pass gets two buffers
-        bufs = getattr(gamma, "_hip_ln_parts", None)
-        if bufs is None:
-            bufs = gamma._hip_ln_parts = []
-        while len(bufs) <= idx:
-            bufs.append(None)
-        part = bufs[idx]
-        if part is None or part.numel() != 2 * nb * c or part.device != x.device:
-            part = bufs[idx] = torch.empty(2 * nb * c, dtype=torch.float32, device=x.device)
+        part = _part_buffer(gamma, "_hip_ln_parts", 2 * nb * c, x.device)   # (applied twice in one pass: two buffers)
         check(lib.wm_layernorm_bwd_parts(ptr(x), ptr(dy), ptr(gamma), ptr(mean), ptr(rstd), rows, c,
                                          ptr(dskip) if dskip is not None else 0, ptr(dx), ptr(part), stream_ptr()),
               "wm_layernorm_bwd_parts")
@@ -187,9 +194,20 @@ class _BiasAct(torch.autograd.Function):
         dout = _bf16_rows(dout)
         bias = ctx.bias
         db = db_ret = None
+        lib = _lib.load()
+        slot = _arena_grad(bias) if (bias is not None and bias.requires_grad) else None
+        if slot is not None and c % 4 == 0 and os.environ.get("WM_LN_SLOTS", "1") != "0":
+            # bias gradient as per-block slots added in order by the pass's batched fold (no f32 atomics)
+            nb = int(lib.wm_colsum_blocks(rows, c))
+            part = _part_buffer(bias, "_hip_bias_parts", nb * c, dout.device)
+            dx = dout if ctx.act == ACT_NONE else torch.empty_like(dout)
+            check(lib.wm_bias_act_bwd_parts(ptr(x) if ctx.act != ACT_NONE else 0, ptr(bias) if ctx.act != ACT_NONE else 0,
+                                            ptr(dout), ctx.act, rows, c, ptr(dx) if ctx.act != ACT_NONE else 0, ptr(part),
+                                            stream_ptr()), "wm_bias_act_bwd_parts")
+            ops._queue_fold(bias, part, nb, slot, 1, c, 1)
+            return dx, None, (dout if ctx.has_res else None), None
         if bias is not None and bias.requires_grad:
             db, db_ret = _grad_target(bias)
-        lib = _lib.load()
         if ctx.act == ACT_NONE:
             if db is not None:
                 check(lib.wm_bias_act_bwd(0, 0, ptr(dout), ACT_NONE, rows, c, 0, ptr(db), stream_ptr()), "wm_bias_act_bwd")

@@ -874,3 +874,28 @@ def test_layer_norm_parameter_gradients_as_slots_are_bit_reproducible(monkeypatc
     assert torch.equal(a[2], c[2])                                    # dx does not depend on the reduction form
     for u, v, what in ((a[0], c[0], "dgamma"), (a[1], c[1], "dbeta")):
         parity(f"LayerNorm {what}: slots + ordered fold vs f32 atomics (relative L2)", float((u - v).norm() / v.norm()), 1e-5)
+
+
+def test_parameter_used_twice_in_one_pass_folds_both_uses():
+    """The pass's batched fold read-modify-writes every gradient slot from its own blocks: two entries for ONE slot (a
+    parameter applied twice in the pass: the patch-embedding bias of a multi-resolution forward, a shared Linear) must
+    not share a launch.  Found when the bias column sums moved into the fold: the second use was lost (error 0.41)."""
+    from ssl_wafermap_amd import nn as wnn
+    from ssl_wafermap_amd import optim, vit_ops
+
+    torch.manual_seed(0)
+    lin = wnn.Linear(192, 384, bias=True).to(DEV)
+    extra = torch.nn.Parameter(torch.randn(384, device=DEV) * 0.1)
+    opt = optim.AdamW(list(lin.parameters()) + [extra], lr=1e-3)
+    opt.zero_grad()
+    g = torch.Generator(device=DEV).manual_seed(1)
+    xs = [torch.randn(r, 192, generator=g, device=DEV).bfloat16() for r in (13824, 25088)]
+    dys = [torch.randn(x.shape[0], 384, generator=g, device=DEV).bfloat16() for x in xs]
+    outs = [vit_ops.bias_act(lin(x), extra) for x in xs]          # Linear (+ its bias) and a second bias, each used twice
+    torch.autograd.backward(outs, dys)
+    torch.cuda.synchronize()
+    ref_w = sum(d.float().t() @ x.float() for d, x in zip(dys, xs))
+    ref_b = sum(d.float().sum(0) for d in dys)
+    parity("shared Linear weight gradient, two uses in one pass (relative L2)", float((lin.weight.grad - ref_w).norm() / ref_w.norm()), 1e-5)
+    parity("shared Linear bias gradient, two uses in one pass (relative L2)", float((lin.bias.grad - ref_b).norm() / ref_b.norm()), 1e-5)
+    parity("bias_act bias gradient, two uses in one pass (relative L2)", float((extra.grad - ref_b).norm() / ref_b.norm()), 1e-5)
