@@ -607,8 +607,13 @@ class _TokensAssemble(torch.autograd.Function):
         n, np_, d = ctx.geom
         dx = _bf16_rows(dx)
         s = np_ + 1
+        # sum over the images of the [s * d] token rows: per-block slots added in order (no f32 atomics)
+        lib = _lib.load()
         dpos = torch.empty(s * d, dtype=torch.float32, device=dx.device)
-        check(_lib.load().wm_colsum_bf16(ptr(dx), n, s * d, ptr(dpos), 0, stream_ptr()), "wm_colsum_bf16")
+        nb = int(lib.wm_colsum_blocks(n, s * d))
+        part = torch.empty(nb * s * d, dtype=torch.float32, device=dx.device)
+        check(lib.wm_bias_act_bwd_parts(0, 0, ptr(dx), ACT_NONE, n, s * d, 0, ptr(part), stream_ptr()), "wm_bias_act_bwd_parts")
+        check(lib.wm_wgrad_finalize(ptr(part), nb, 1, s * d, 1, 1, ptr(dpos), 0, stream_ptr()), "wm_wgrad_finalize")
         # the patch rows (every token but the class token of each image) by the row-gather kernel: a strided slice +
         # reshape would be an ATen copy kernel
         idx = cached_index(("patch_rows", n, np_, str(dx.device)),

@@ -211,3 +211,50 @@ def test_bs256_step_is_bit_reproducible():
     e, g = run(False), run(True)
     for (le, ge, pe), (lg, gg, pg) in zip(e, g):
         assert le == lg and torch.equal(ge, gg) and torch.equal(pe, pg)
+
+
+@pytest.mark.parametrize("which", ["dino_vit_tiny", "mae_vit_small_16"])
+def test_transformer_steps_are_bit_reproducible_in_their_gradients(which):
+    """Round 3, second half: the transformer steps' parameter gradients no longer pass through f32 atomics either
+    (LayerNorm and bias column sums as per-block slots added by the pass's ordered fold, positional-embedding sums by an
+    ordered finalize; Linear weight gradients were slabs already).  Two runs of the same two steps: identical gradient
+    arenas and parameters.  (The scalar loss VALUES of the DINO / MSE kernels are still atomically summed: compared to
+    1e-6.)"""
+    from ssl_wafermap_amd.data import WaferMapDataset
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.models import MAE, DINOViT
+    from ssl_wafermap_amd.transforms import BaseViewTransform, MultiCropTransform
+
+    B = 8
+
+    def run():
+        torch.manual_seed(3)
+        if which == "dino_vit_tiny":
+            wafers, labels = synthetic_wafers(64, seed=2)
+            ds = WaferMapDataset(wafers, labels, transform=MultiCropTransform(), device=DEV)
+            model = DINOViT(None, 9, batch_size=B, log_rep_std=False, backbone="vit_tiny")
+        else:
+            wafers, labels = synthetic_wafers(64, seed=2, fixed_size=52)
+            ds = WaferMapDataset(wafers, labels, transform=BaseViewTransform(n_views=1, denoise=True), device=DEV)
+            model = MAE(None, 9, batch_size=B, log_rep_std=False, backbone="vit_small_16")
+        model = model.to(DEV).train()
+        (opt,), _ = model.configure_optimizers()
+        rng = np.random.default_rng(5)
+        gen = torch.Generator(device=DEV).manual_seed(11)
+        out = []
+        for i in range(2):
+            batch = ds.get_batch(np.arange(B) + i * B, rng, fmt="nhwc_bf16")
+            opt.zero_grad()
+            loss = model.training_step(batch, i, generator=gen) if which != "dino_vit_tiny" else model.training_step(batch, i)
+            loss.backward()
+            opt.step()
+            torch.cuda.synchronize()
+            out.append((float(loss.detach()), torch.cat([a.clone() for a in opt.grad_arenas]),
+                        torch.cat([p.detach().reshape(-1).float() for p in model.parameters()]).clone()))
+        return out
+
+    a, b = run(), run()
+    for (la, ga, pa), (lb, gb, pb) in zip(a, b):
+        assert abs(la - lb) <= 1e-6 * abs(la), (la, lb)
+        assert torch.equal(ga, gb), float((ga - gb).abs().max())
+        assert torch.equal(pa, pb)
