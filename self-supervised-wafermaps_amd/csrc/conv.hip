@@ -1432,11 +1432,10 @@ inline void wgrad_config(int C, int K, int R, int S, int& bmo, int& cpt, int& nt
     // three taps per block where the dY tile is the larger share of the traffic (C <= 128 with K = 128)
     // and for the 512-channel layers, two for 256 channels, one for the stride-2 128 -> 256 layer
     nt = (coltiles % 2 == 0 && C > 128) ? 2 : 1;
-    if (R * S == 9) {
-      if (C <= 128 && K == 128) nt = 3;
-      else if (C == 128) nt = 1;
-      else if (C >= 512) nt = 3;
-    }
+    // 3x3: three taps per block everywhere.  (Round 1 measured one tap per block best for the stride-2 128 -> 256 layer
+    // and two for 256 channels -- with f32 atomics and hardware block order.  With slabs and the blocks of a row split on
+    // one XCD, tools/bench_conv.py at batch 512: layer3.0 105.5 -> 73.0 us, layer3 3x3 145.7 -> 132.1 us.)
+    if (R * S == 9) nt = 3;
     if (nt == 3 && coltiles % 3 != 0) nt = 1;
     if (nt == 2 && coltiles % 2 != 0) nt = 1;
     return;
