@@ -98,15 +98,18 @@ __global__ __launch_bounds__(AT_FWD_THREADS) void attn_fwd(const uint16_t* __res
   const uint16_t* base = qkv + (size_t)b * S * rs + h * HD;
   // this wave's first query strip: requested before the K / V staging so that it is in flight under it
   bf16x8_t qf[KS];
+  // gridDim.y blocks share the query strips of one (image, head) (each stages K and V itself): 197 tokens are 13 strips
+  // for 8 waves, i.e. two serial strips per block -- with two blocks per head every wave has one
+  const int qs0 = wave + (int)blockIdx.y * (AT_FWD_THREADS / 64);
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_global(base, rs, wave * 16 + fr, S, ks, fg);
+  for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_global(base, rs, qs0 * 16 + fr, S, ks, fg);
   stage_rows<HD>(base + (size_t)H * HD, rs, S, SP, sk);
   stage_rows<HD>(base + (size_t)2 * H * HD, rs, S, SP, sv);
   __syncthreads();
 
-  for (int qs = wave; qs < NT; qs += AT_FWD_THREADS / 64) {
+  for (int qs = qs0; qs < NT; qs += (AT_FWD_THREADS / 64) * (int)gridDim.y) {
     const int q = qs * 16 + fr;
-    if (qs != wave) {
+    if (qs != qs0) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) qf[ks] = frag_global(base, rs, q, S, ks, fg);
     }
@@ -522,8 +525,16 @@ int launch_fwd(const void* qkv, int B, int S, int H, float scale, void* out, flo
     if (rc != WM_OK) return rc;
     attr = true;
   }
-  attn_fwd<NT, HD><<<B * H, AT_FWD_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), S, H, scale,
-                                               static_cast<uint16_t*>(out), lse);
+  static int qsplit = -1;  // WM_ATTN_FWD_SPLIT (experiment switch)
+  if (qsplit < 0) {
+    const char* e = getenv("WM_ATTN_FWD_SPLIT");
+    qsplit = e ? atoi(e) : 0;
+  }
+  // default: two blocks per head beyond 8 strips while the (image, head) pairs alone do not fill the chip's 512 block
+  // slots -- 128 x 197 x 3 heads: 26.6 -> 23.0 us; with 6 heads (768 pairs) the doubled K / V staging loses: 38.6 -> 43.7
+  const int ys = qsplit > 0 ? qsplit : ((NT > 8 && (long long)B * H <= 512) ? 2 : 1);
+  attn_fwd<NT, HD><<<dim3(B * H, ys), AT_FWD_THREADS, lds, st>>>(static_cast<const uint16_t*>(qkv), S, H, scale,
+                                                             static_cast<uint16_t*>(out), lse);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
