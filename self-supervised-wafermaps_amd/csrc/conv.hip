@@ -1375,8 +1375,17 @@ inline void wgrad_plan(const WgradArgs& a, int BMO, int NT, int& nsplit, int& ch
     target = e ? atoi(e) : 512;
   }
   // Linear layers (1 x 1 on a 1 x 1 image: the transformer GEMMs): the output tile is small and every split ends in
-  // a K x C f32 slab, so half the blocks (measured on DINO ViT-Tiny with atomics: 3.06 vs 3.57 ms of wgrad per step)
-  const int tgt = (a.R * a.S == 1 && a.H * a.W == 1 && target == 512) ? 256 : target;
+  // a K x C f32 slab (round 2, with atomics: half the blocks, 3.06 vs 3.57 ms of wgrad per DINO ViT-Tiny step).
+  // Re-measured with slabs (round 3, ms per step at 256 / 512 blocks): DINO ViT-Tiny 9.79 / 9.53, DINO ViT-S 19.68 / 18.62
+  // (39 424 token rows: the slab traffic is small beside the operands), MAE ViT-S/16 4.64 / 4.74 (3 200 and 12 608 rows:
+  // there every extra split is mostly slab bytes).  So: the full target from 16 384 rows on, half of it below.
+  static int target_lin = -1;
+  if (target_lin < 0) {
+    const char* e = getenv("WM_WGRAD_BLOCKS_LINEAR");
+    target_lin = e ? atoi(e) : 0;
+  }
+  int tgt = target;
+  if (a.R * a.S == 1 && a.H * a.W == 1 && target == 512) tgt = target_lin > 0 ? target_lin : (total_chunks >= 256 ? 512 : 256);
   nsplit = tgt / (colgroups * ktiles);
   if (nsplit < 1) nsplit = 1;
   if (nsplit > total_chunks) nsplit = total_chunks;
