@@ -239,16 +239,18 @@ int wm_conv2d_dgrad_add(const void* dy, const void* w_crsk, const void* residual
  *   stat_part f32 [G][stat_tiles][2][C] = per-tile (sum g, sum g * bn_y) per channel, stat_tiles = rows of dx per
  *        group / 128 (plain stores into the tile's slot; wm_bn_train_bwd_from_stats adds the slots in order and forms
  *        sum g * xhat = invstd * (sum g y - mean * sum g) in double)
- * mask = relu_x > 0 when relu_x (the convolution's own forward input, shape of dx) is given; else recomputed from
- * bn_y as bf16(bn_y * gamma * invstd + beta - mean * gamma * invstd) > 0 (a BatchNorm without shortcut).
+ * mask = relu_x > 0 when relu_x (the convolution's own forward input, shape of dx) is given; or the bits of relu_mask
+ * ([pixels][C / 8] bytes written by wm_bn_train_fwd* for that tensor: 1/16 of its bytes; give one of the two); else
+ * recomputed from bn_y as bf16(bn_y * gamma * invstd + beta - mean * gamma * invstd) > 0 (a BatchNorm without shortcut).
  * bn_y has the shape of dx; save_mean / save_invstd [G][C] over G equal groups of images.
  * wm_conv2d_dgrad_bnstat_ok: 1 when the shape is served (every 128-row tile inside one statistics group). */
 int wm_conv2d_dgrad_bnstat_ok(int N, int H, int W, int C, int K, int R, int S, int P, int Q, int stride, int pad,
                               int G);
 int wm_conv2d_dgrad_bnstat(const void* dy, const void* w_crsk, const void* residual, void* dx, int N, int H, int W,
                            int C, int K, int R, int S, int P, int Q, int stride, int pad, const void* bn_y,
-                           const void* relu_x, const float* gamma, const float* beta, const float* save_mean,
-                           const float* save_invstd, int G, float* stat_part, int stat_tiles, void* stream);
+                           const void* relu_x, const void* relu_mask, const float* gamma, const float* beta,
+                           const float* save_mean, const float* save_invstd, int G, float* stat_part, int stat_tiles,
+                           void* stream);
 /* Weight gradient: sum over pixels of dy (x) x, split over pixel ranges.  Split z STORES its partial sums into slab z
  * of dw_slabs (f32 [nsplit][K][R][S][C], nsplit = wm_conv2d_wgrad_splits(same geometry)): no atomics, nothing to zero;
  * wm_wgrad_fold / wm_wgrad_finalize / wm_stem_wgrad_finalize sum the slabs in a fixed order (bit-reproducible). */
@@ -342,18 +344,20 @@ int wm_cast_f32_bf16(const float* x, long long n, void* y, void* stream);
  * concatenated batch).  out = relu?(bn(y) (+ residual)).  running_* are updated once per group in
  * order (torch momentum convention, unbiased variance); save_mean/save_invstd are [G][C].
  * num_batches_tracked (torch's int64 buffer, may be NULL) is incremented by G inside the finalize kernel.
+ * relu_mask (may be NULL): [rows][C / 8] bytes, bit e of byte (row, chunk) = output channel 8 chunk + e is > 0 -- the
+ * ReLU's backward mask for wm_conv2d_dgrad_bnstat at 1/16 of the tensor's bytes.
  * C % 8 == 0, C <= 2048, rows % G == 0. */
 size_t wm_bn_workspace_bytes(long long rows, int C, int G);
 int wm_bn_train_fwd(const void* y, const void* residual, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, long long* num_batches_tracked, long long rows, int C, int G, float eps,
-                    float momentum, int relu, float* save_mean, float* save_invstd, void* out,
+                    float momentum, int relu, float* save_mean, float* save_invstd, void* out, void* relu_mask,
                     void* workspace, size_t workspace_bytes, void* stream);
 /* Training forward whose statistics were accumulated by wm_conv2d_fwd_stats. */
 int wm_bn_train_fwd_from_stats(const void* y, const void* residual, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, long long* num_batches_tracked,
                                long long rows, int C, int G, float eps, float momentum, int relu, float* save_mean,
                                float* save_invstd,
-                               void* out, const float* stat_part, int stat_tiles, void* workspace,
+                               void* out, void* relu_mask, const float* stat_part, int stat_tiles, void* workspace,
                                size_t workspace_bytes, void* stream);
 /* Statistics only: mean / invstd / running stats and the [G][C] scale, shift of the normalisation, for a
  * consumer that applies it itself (the fused stem below).  stat_part NULL: computed from y here. */

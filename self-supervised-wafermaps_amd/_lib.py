@@ -113,7 +113,7 @@ SIGNATURES = {
     "wm_conv2d_fwd_stats_tiles": (c_int, [c_int] * 12),
     "wm_conv2d_dgrad_bnstat_ok": (c_int, [c_int] * 12),
     "wm_conv2d_dgrad_bnstat": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p] + [c_int] * 11 +
-                               [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
+                               [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_int, c_void_p]),
     "wm_bn_train_bwd_from_stats": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p, c_void_p, c_int,
@@ -143,12 +143,12 @@ SIGNATURES = {
     "wm_bn_train_fwd": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_float,
-         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
+         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p],
     ),
     "wm_bn_train_fwd_from_stats": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_float, c_float,
-         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
+         c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_size_t, c_void_p],
     ),
     "wm_bn_train_stats": (
         c_int,

@@ -358,7 +358,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply(const uint16_t* __restric
                                                        const float* __restrict__ scale,
                                                        const float* __restrict__ shift,
                                                        long long rows, int C, int rows_per_group,
-                                                       int relu, int cshift, uint16_t* __restrict__ out) {
+                                                       int relu, int cshift, uint16_t* __restrict__ out,
+                                                       uint8_t* __restrict__ relu_mask) {
+  // relu_mask (optional): [rows][C / 8] bytes, bit e of byte (row, chunk) = output channel 8 chunk + e is > 0 -- what
+  // the consuming convolution's dgrad epilogue needs of this tensor for the ReLU's backward (1/16 of its bytes)
   const int cpr = C >> 3;
   const long long total = rows * cpr;
   int cur_g = -1;
@@ -400,7 +403,16 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply(const uint16_t* __restric
 #pragma unroll
       for (int e = 0; e < 8; ++e) f[e] = fmaxf(f[e], 0.f);
     }
-    *reinterpret_cast<uint4*>(out + row * C + c0) = pack8(f);
+    const uint4 pk = pack8(f);
+    *reinterpret_cast<uint4*>(out + row * C + c0) = pk;
+    if (relu_mask != nullptr) {
+      float r8[8];
+      unpack8(pk, r8);  // the stored (rounded) values decide, exactly as a test of the tensor itself would
+      uint32_t m = 0;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) m |= (r8[e] > 0.f ? 1u : 0u) << e;
+      relu_mask[row * cpr + (c0 >> 3)] = (uint8_t)m;
+    }
   }
 }
 
@@ -687,16 +699,16 @@ inline int stream_grid(long long items) {
 }
 
 inline void launch_bn_apply(const void* y, const void* residual, const float* scale, const float* shift, long long rows,
-                            int C, int rpg, int relu, void* out, hipStream_t st) {
+                            int C, int rpg, int relu, void* out, hipStream_t st, void* relu_mask = nullptr) {
   int csh = 0;
   if (chunk_pow2(C, &csh))
     bn_apply<true><<<stream_grid(rows * (C >> 3)), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(residual), scale, shift, rows, C, rpg, relu, csh,
-        static_cast<uint16_t*>(out));
+        static_cast<uint16_t*>(out), static_cast<uint8_t*>(relu_mask));
   else
     bn_apply<false><<<stream_grid(rows * (C >> 3)), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(residual), scale, shift, rows, C, rpg, relu, csh,
-        static_cast<uint16_t*>(out));
+        static_cast<uint16_t*>(out), static_cast<uint8_t*>(relu_mask));
 }
 
 // ---- wide, short matrices (projection heads: C > 2048, a few hundred rows): one thread per channel walks
@@ -814,7 +826,7 @@ extern "C" size_t wm_bn_workspace_bytes(long long rows, int C, int G) {
 extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float* gamma,
                                const float* beta, float* running_mean, float* running_var,
                                long long* num_batches_tracked, long long rows, int C, int G, float eps, float momentum, int relu,
-                               float* save_mean, float* save_invstd, void* out, void* workspace,
+                               float* save_mean, float* save_invstd, void* out, void* relu_mask, void* workspace,
                                size_t workspace_bytes, void* stream) {
   WM_REQUIRE(y && out && save_mean && save_invstd && workspace, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
@@ -823,6 +835,7 @@ extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float*
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rpg = (int)(rows / G);
   if (bn_wide(rows, C, G)) {
+    WM_REQUIRE(relu_mask == nullptr, WM_EUNSUPPORTED);
     bn_col_fwd<<<wm_cdiv(C, BN_THREADS), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(residual), gamma, beta, running_mean, running_var,
         num_batches_tracked, rpg, C, G, eps, momentum, relu, 1, save_mean, save_invstd, static_cast<uint16_t*>(out));
@@ -841,7 +854,7 @@ extern "C" int wm_bn_train_fwd(const void* y, const void* residual, const float*
   bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, rpg, 0, gamma, beta, eps, momentum, running_mean,
                                                    running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   WM_LAUNCH_CHECK();
-  launch_bn_apply(y, residual, scale, shift, rows, C, rpg, relu, out, st);
+  launch_bn_apply(y, residual, scale, shift, rows, C, rpg, relu, out, st, relu_mask);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -852,9 +865,9 @@ extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, c
                                           const float* beta, float* running_mean, float* running_var,
                                           long long* num_batches_tracked, long long rows, int C, int G, float eps,
                                           float momentum, int relu,
-                                          float* save_mean, float* save_invstd, void* out, const float* stat_part,
-                                          int stat_tiles, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
+                                          float* save_mean, float* save_invstd, void* out, void* relu_mask,
+                                          const float* stat_part, int stat_tiles, void* workspace,
+                                          size_t workspace_bytes, void* stream) {
   WM_REQUIRE(y && out && save_mean && save_invstd && workspace && stat_part, WM_EINVAL);
   WM_REQUIRE(stat_tiles > 0, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
@@ -870,7 +883,7 @@ extern "C" int wm_bn_train_fwd_from_stats(const void* y, const void* residual, c
   bn_fwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(const_cast<float*>(part), nblk, G, C, rpg, 0, gamma, beta, eps, momentum,
                                                    running_mean, running_var, num_batches_tracked, save_mean, save_invstd, scale, shift);
   WM_LAUNCH_CHECK();
-  launch_bn_apply(y, residual, scale, shift, rows, C, rpg, relu, out, st);
+  launch_bn_apply(y, residual, scale, shift, rows, C, rpg, relu, out, st, relu_mask);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

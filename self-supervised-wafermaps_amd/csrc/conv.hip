@@ -62,6 +62,8 @@ struct ConvArgs {
   // (bn_y, gradient, mask) and the mask / dz handling of the BatchNorm backward apply pass disappear.
   const uint16_t* bn_y;
   const uint16_t* bn_x;
+  const uint8_t* bn_mask;  // alternative to bn_x: [pixels][DC / 8] bytes, bit e = (bn_x channel 8 chunk + e > 0), written by
+                           // the BatchNorm forward (wm_bn_train_fwd*): 1/16 of the bytes of bn_x
   const float* bn_mean;    // [G][DC]
   const float* bn_invstd;  // [G][DC]
   const float* bn_gamma;   // [DC]
@@ -167,6 +169,7 @@ template <int BNC>
 struct BnbRegs {
   static constexpr int NIT = 128 * (BNC / 8) / CV_THREADS;
   u32x4_t yv[NIT], rv[NIT], xv[NIT];
+  uint32_t mk[NIT];   // ReLU mask byte of the pass (bn_mask form)
   size_t pixs[NIT];
 };
 // Plain (compiler-tracked) loads: the k-loop's asm statements clobber "memory", so hipcc cannot sink these below the
@@ -188,6 +191,7 @@ __device__ __forceinline__ void bnb_prefetch(const ConvArgs& a, BnbRegs<BNC>& R,
     bnb_load16(R.yv[it], a.bn_y + pix * a.DC + c0);
     if (a.res != nullptr) bnb_load16(R.rv[it], a.res + pix * a.DC + c0);
     if (a.bn_x != nullptr) bnb_load16(R.xv[it], a.bn_x + pix * a.DC + c0);
+    R.mk[it] = a.bn_mask != nullptr ? a.bn_mask[pix * (a.DC >> 3) + (c0 >> 3)] : 0u;
   }
 }
 
@@ -202,7 +206,8 @@ __device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, const BnbRegs<BN
   const int c0 = n0 + chl * 8;
   // ReLU mask recomputed from the BatchNorm input (no shortcut): bn_y * scale + shift > 0 with the forward's scale and
   // shift.  (The forward rounds to bf16 before its ReLU; that rounding changes the sign test only for |value| < 2^-133.)
-  const bool remask = a.bn_x == nullptr;
+  const bool remask = a.bn_x == nullptr && a.bn_mask == nullptr;
+  const bool bitmask = a.bn_mask != nullptr;
   float sc[8], sh[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e) sc[e] = sh[e] = 0.f;
@@ -241,7 +246,8 @@ __device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, const BnbRegs<BN
         const float y = __builtin_bit_cast(float, h ? (yy[q] & 0xffff0000u) : (yy[q] << 16));
         // (x is a bf16 pattern: > 0 <=> the 16-bit pattern is a positive non-zero number)
         const bool keep = remask ? fmaf(y, sc[e], sh[e]) > 0.f
-                                 : __builtin_bit_cast(float, h ? (xx[q] & 0xffff0000u) : (xx[q] << 16)) > 0.f;
+                          : bitmask ? ((R.mk[it] >> e) & 1u) != 0u
+                                    : __builtin_bit_cast(float, h ? (xx[q] & 0xffff0000u) : (xx[q] << 16)) > 0.f;
         v = keep ? v : 0.f;
         s1[e] += v;
         s2[e] = fmaf(v, y, s2[e]);
@@ -1562,6 +1568,7 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
   a.pre_out = static_cast<uint16_t*>(pre_out);
   a.act = pre_out != nullptr ? 1 : 0;
   a.bn_y = a.bn_x = nullptr;
+  a.bn_mask = nullptr;
   a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr;
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (C == 16) {
@@ -1613,6 +1620,7 @@ static int conv_fwd_impl(const void* x, const void* w_krsc, void* y, int N, int 
 struct BnbArgs {  // BatchNorm-backward epilogue (ConvArgs: bn_*)
   const void* bn_y;
   const void* bn_x;
+  const void* bn_mask;
   const float *mean, *invstd, *gamma, *beta;
   int G;
   float* stat;
@@ -1668,17 +1676,18 @@ extern "C" int wm_conv2d_dgrad_bnstat_ok(int N, int H, int W, int C, int K, int 
 
 extern "C" int wm_conv2d_dgrad_bnstat(const void* dy, const void* w_crsk, const void* residual, void* dx, int N, int H,
                                       int W, int C, int K, int R, int S, int P, int Q, int stride, int pad,
-                                      const void* bn_y, const void* relu_x, const float* gamma, const float* beta,
-                                      const float* save_mean, const float* save_invstd, int G, float* stat_part,
-                                      int stat_tiles, void* stream) {
+                                      const void* bn_y, const void* relu_x, const void* relu_mask, const float* gamma,
+                                      const float* beta, const float* save_mean, const float* save_invstd, int G,
+                                      float* stat_part, int stat_tiles, void* stream) {
   WM_REQUIRE(bn_y && save_mean && save_invstd && stat_part, WM_EINVAL);
   WM_REQUIRE(G > 0 && stat_tiles == (int)((long long)N * H * W / G / 128), WM_EINVAL);  // one slot per 128-row tile
-  WM_REQUIRE(relu_x || (gamma && beta), WM_EINVAL);
+  WM_REQUIRE(relu_x || relu_mask || (gamma && beta), WM_EINVAL);
+  WM_REQUIRE(!(relu_x && relu_mask), WM_EINVAL);
   WM_REQUIRE(wm_conv2d_dgrad_bnstat_ok(N, H, W, C, K, R, S, P, Q, stride, pad, G), WM_EUNSUPPORTED);
   WM_REQUIRE(aligned16(bn_y) && aligned16(save_mean) && aligned16(save_invstd) && (relu_x == nullptr || aligned16(relu_x)) &&
                  (residual == nullptr || aligned16(residual)),
              WM_EALIGN);
-  BnbArgs b{bn_y, relu_x, save_mean, save_invstd, gamma, beta, G, stat_part, stat_tiles};
+  BnbArgs b{bn_y, relu_x, relu_mask, save_mean, save_invstd, gamma, beta, G, stat_part, stat_tiles};
   return conv_dgrad_impl(dy, w_crsk, dx, residual, N, H, W, C, K, R, S, P, Q, stride, pad, stream, nullptr, &b);
 }
 
@@ -1710,11 +1719,13 @@ static int conv_dgrad_impl(const void* dy, const void* w_crsk, void* dx, const v
   a.pre_out = nullptr;
   a.act = pre_in != nullptr ? 2 : 0;
   a.bn_y = a.bn_x = nullptr;
+  a.bn_mask = nullptr;
   a.bn_mean = a.bn_invstd = a.bn_gamma = a.bn_beta = nullptr;
   if (bnb != nullptr) {
     WM_REQUIRE(pre_in == nullptr, WM_EUNSUPPORTED);
     a.bn_y = static_cast<const uint16_t*>(bnb->bn_y);
     a.bn_x = static_cast<const uint16_t*>(bnb->bn_x);
+    a.bn_mask = static_cast<const uint8_t*>(bnb->bn_mask);
     a.bn_mean = bnb->mean; a.bn_invstd = bnb->invstd; a.bn_gamma = bnb->gamma; a.bn_beta = bnb->beta;
     a.stat = bnb->stat; a.stat_nb = bnb->stat_nb;
     if (stride == 1) {

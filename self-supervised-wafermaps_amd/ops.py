@@ -498,15 +498,17 @@ class BnLink:
     backward checks that the gradient it receives is exactly that tensor (same storage, unmodified: no other consumer
     contributed) and then skips its reduction pass, its mask and the dz copy (wm_bn_train_bwd_from_stats)."""
 
-    __slots__ = ("y", "mean", "invstd", "gamma", "beta", "groups", "has_res", "stats", "ready", "g_ptr", "g_version")
+    __slots__ = ("y", "mean", "invstd", "gamma", "beta", "groups", "has_res", "stats", "ready", "g_ptr", "g_version", "mask")
 
-    def __init__(self, y, mean, invstd, gamma, beta, groups, has_res, stats):
+    def __init__(self, y, mean, invstd, gamma, beta, groups, has_res, stats, mask=None):
         self.y, self.mean, self.invstd, self.gamma, self.beta = y, mean, invstd, gamma, beta
         self.groups, self.has_res, self.stats = groups, has_res, stats
+        self.mask = mask   # uint8 [rows][C / 8]: bits of (output > 0), written by the forward apply pass (shortcut case)
         self.ready, self.g_ptr, self.g_version = False, 0, -1
 
 
 _BN_FUSE_BWD = os.environ.get("WM_BN_FUSE_BWD", "1") != "0"  # A/B switch: 0 keeps the separate reduction pass
+_BN_BITMASK = os.environ.get("WM_BN_BITMASK", "1") != "0"    # A/B switch: 0 = the dgrad epilogue re-reads the output tensor
 
 
 def _out_hw(h, w, r, s, stride, pad):
@@ -564,7 +566,8 @@ class _Conv2d(torch.autograd.Function):
                 tiles = n * h * w // link.groups // 128
                 check(_run("conv_dgrad", 2.0 * n * p * q * k * r * s * c, lib.wm_conv2d_dgrad_bnstat, dy.data_ptr(), ptr(crsk),
                            dres.data_ptr() if dres is not None else 0, dx.data_ptr(), n, h, w, c, k, r, s, p, q, stride, pad,
-                           link.y.data_ptr(), x.data_ptr() if link.has_res else 0, ptr(link.gamma), ptr(link.beta),
+                           link.y.data_ptr(), x.data_ptr() if (link.has_res and link.mask is None) else 0,
+                           ptr(link.mask) if (link.has_res and link.mask is not None) else 0, ptr(link.gamma), ptr(link.beta),
                            ptr(link.mean), ptr(link.invstd), link.groups, ptr(link.stats.get(link.groups, tiles, dy.device)),
                            tiles, stream_ptr()), "wm_conv2d_dgrad_bnstat")
                 link.ready, link.g_ptr, link.g_version = True, dx.data_ptr(), dx._version
@@ -713,26 +716,32 @@ class _BatchNorm(torch.autograd.Function):
                 raise ValueError("batch_norm: rows not divisible by groups")
             mean = torch.empty((groups, c), dtype=torch.float32, device=y.device)
             invstd = torch.empty_like(mean)
+            will_link = (bwd_stats is not None and relu and y.dim() == 4 and gamma is not None and beta is not None
+                         and stats_fusable(rows, groups) and ctx.needs_input_grad[0])
+            # shortcut case: the consuming convolution's dgrad epilogue needs (output > 0); as bits that is 1/16 of the
+            # bytes of the output tensor it would otherwise re-read
+            mask = None
+            if will_link and residual is not None and c % 8 == 0 and c <= 2048 and _BN_BITMASK:
+                mask = torch.empty((rows, c // 8), dtype=torch.uint8, device=y.device)
             if stats is not None and stats.buf is not None and stats_fusable(rows, groups):
                 check(lib.wm_bn_train_fwd_from_stats(y.data_ptr(), ptr(residual) if residual is not None else 0,
                                                      ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
                                                      ptr(counter), rows, c,
                                                      groups, eps, momentum, int(relu), ptr(mean), ptr(invstd),
-                                                     out.data_ptr(), ptr(stats.buf), stats.tiles, ptr(ws),
+                                                     out.data_ptr(), ptr(mask), ptr(stats.buf), stats.tiles, ptr(ws),
                                                      ws.numel(), stream_ptr()), "wm_bn_train_fwd_from_stats")
             else:
                 check(lib.wm_bn_train_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma),
                                           ptr(beta), ptr(running_mean), ptr(running_var), ptr(counter), rows, c, groups, eps,
-                                          momentum, int(relu), ptr(mean), ptr(invstd), out.data_ptr(), ptr(ws), ws.numel(),
-                                          stream_ptr()), "wm_bn_train_fwd")
+                                          momentum, int(relu), ptr(mean), ptr(invstd), out.data_ptr(), ptr(mask), ptr(ws),
+                                          ws.numel(), stream_ptr()), "wm_bn_train_fwd")
             # a ReLU'd BN without residual recomputes its mask from y in the backward: `out` is not needed
             mask_from_y = relu and residual is None and gamma is not None and beta is not None
             ctx.save_for_backward(y, out if (relu and not mask_from_y) else None, mean, invstd)
             ctx.affine = (gamma, beta)
             ctx.meta = (rows, c, groups, relu, residual is not None, mask_from_y)
-            if (bwd_stats is not None and relu and y.dim() == 4 and gamma is not None and beta is not None
-                    and stats_fusable(rows, groups) and ctx.needs_input_grad[0]):
-                ctx.link = BnLink(y, mean, invstd, gamma, beta, groups, residual is not None, bwd_stats)
+            if will_link:
+                ctx.link = BnLink(y, mean, invstd, gamma, beta, groups, residual is not None, bwd_stats, mask)
         else:
             check(lib.wm_bn_eval_fwd(y.data_ptr(), ptr(residual) if residual is not None else 0, ptr(gamma), ptr(beta),
                                      ptr(running_mean), ptr(running_var), rows, c, eps, int(relu), out.data_ptr(),

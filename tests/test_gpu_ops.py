@@ -533,14 +533,15 @@ def test_backward_exception_does_not_strand_weight_gradients():
     assert float(conv.weight.grad.abs().sum()) > 0.0
 
 
-def _block_stack_grads(fuse: bool, seed: int = 0):
+def _block_stack_grads(fuse: bool, seed: int = 0, bitmask: bool = True):
     """Three BasicBlocks (identity, stride-2 + downsample, identity) on two statistics groups: parameter and input
-    gradients of sum(out * t).  fuse: BatchNorm-backward sums inside the consuming convolution's dgrad epilogue."""
+    gradients of sum(out * t).  fuse: BatchNorm-backward sums inside the consuming convolution's dgrad epilogue;
+    bitmask: the epilogue's ReLU mask (shortcut case) from the forward's bit mask instead of the output tensor."""
     from ssl_wafermap_amd import ops
     from ssl_wafermap_amd.models.resnet import BasicBlock
 
-    old = ops._BN_FUSE_BWD
-    ops._BN_FUSE_BWD = fuse
+    old, old_mask = ops._BN_FUSE_BWD, ops._BN_BITMASK
+    ops._BN_FUSE_BWD, ops._BN_BITMASK = fuse, bitmask
     try:
         torch.manual_seed(seed)
         blocks = torch.nn.Sequential(BasicBlock(64, 64), BasicBlock(64, 128, 2), BasicBlock(128, 128)).to(DEV).train()
@@ -556,7 +557,17 @@ def _block_stack_grads(fuse: bool, seed: int = 0):
         torch.cuda.synchronize()
         return [x.grad.float()] + [p.grad.float() for p in blocks.parameters()], out.detach().float()
     finally:
-        ops._BN_FUSE_BWD = old
+        ops._BN_FUSE_BWD, ops._BN_BITMASK = old, old_mask
+
+
+def test_relu_bit_mask_is_bit_identical_to_rereading_the_output():
+    """The BatchNorm forward's ReLU bit mask (1 byte per 8 channels, from the rounded stored outputs) against the dgrad
+    epilogue testing the output tensor itself: the same predicate, so every gradient is bit-identical."""
+    a, oa = _block_stack_grads(True, bitmask=True)
+    b, ob = _block_stack_grads(True, bitmask=False)
+    assert torch.equal(oa, ob)
+    for u, v in zip(a, b):
+        assert torch.equal(u, v), u.shape
 
 
 def test_bn_backward_fused_into_dgrad_epilogue_matches_separate_pass():
