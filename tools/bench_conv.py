@@ -33,8 +33,9 @@ def main():
     ap.add_argument("--only", type=int, default=-1)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--modes", default="fwd,dgrad,wgrad")
+    ap.add_argument("--lib", default=None, help="another build of the library (ablation builds: -DWM_CONV_ABLATE=n)")
     a = ap.parse_args()
-    lib = _lib.load()
+    lib = _lib.load(a.lib) if a.lib else _lib.load()
     dev = torch.device("cuda:0")
     st = torch.cuda.current_stream().cuda_stream
     g = torch.Generator(device="cuda").manual_seed(0)
