@@ -647,8 +647,11 @@ __device__ __forceinline__ int key_id(unsigned long long key) { return key != 0u
 // batches issued round-robin on streams the selection runs under the following streaming kernel.  (Parking the whole
 // run lists in LDS saved the second trip to memory of step 2 but cost 37 KB and 178 registers: same 51 us for one
 // call, 40.0 instead of 39.0 us per batch pipelined.)
-template <int DT, int K>
-__global__ __launch_bounds__(256, K == 8 ? 6 : 1) void knn_select(const uint8_t* __restrict__ query,
+// TH = 1024 (k <= 8, the default): sixteen waves per query -- one run head per thread and all 512 candidate rows rescored
+// in ONE round of dependent loads instead of four, still 64 registers per lane: 51.4 -> 48.4 us per call, 40.1 -> 39.0 us
+// per batch pipelined over three streams (tools/bench_knn_pipeline.py, WM_KNN_SELECT_THREADS=256 / 1024 on one box).
+template <int DT, int K, int TH = 256>
+__global__ __launch_bounds__(TH, (K == 8 && TH == 256) ? 6 : 1) void knn_select(const uint8_t* __restrict__ query,
                                                   const uint8_t* __restrict__ bank, int n, int d,
                                                   int rowbytes, const float* __restrict__ part_sim,
                                                   const int* __restrict__ part_idx, int nslices,
@@ -656,8 +659,10 @@ __global__ __launch_bounds__(256, K == 8 ? 6 : 1) void knn_select(const uint8_t*
                                                   int kout, float* __restrict__ out_sim,
                                                   int* __restrict__ out_idx) {
   extern __shared__ __attribute__((aligned(16))) uint8_t sl_smem[];
-  unsigned long long* hk = reinterpret_cast<unsigned long long*>(sl_smem);  // [4K] wave winners
-  int* topg = reinterpret_cast<int*>(hk + 4 * K);                           // [K] selected runs, then groups
+  static_assert(TH == 256 || (TH == 1024 && K == 8), "256 threads, or 1024 for k <= 8");
+  constexpr int NW = TH / 64;                                               // waves
+  unsigned long long* hk = reinterpret_cast<unsigned long long*>(sl_smem);  // [NW K] wave winners
+  int* topg = reinterpret_cast<int*>(hk + NW * K);                          // [K] selected runs, then groups
   float* cv = reinterpret_cast<float*>(topg + K);                           // [K*64]
   int* ci = reinterpret_cast<int*>(cv + K * 64);                            // [K*64]
   float* qf = reinterpret_cast<float*>(ci + K * 64);                        // [d]
@@ -669,20 +674,22 @@ __global__ __launch_bounds__(256, K == 8 ? 6 : 1) void knn_select(const uint8_t*
   if (stamps) kout = -kout;
   stamp[0] = __builtin_amdgcn_s_memrealtime();
 
-  for (int c = tid; c < d; c += 256) {
+  for (int c = tid; c < d; c += TH) {
     if constexpr (DT == WM_BF16) qf[c] = bf2f(reinterpret_cast<const uint16_t*>(query + (size_t)q * rowbytes)[c]);
     else qf[c] = reinterpret_cast<const float*>(query + (size_t)q * rowbytes)[c];
   }
   // 1. heads (and, K = 8, the whole lists) of this lane's two runs
   {
-    unsigned long long head[2] = {0ull, 0ull};
+    constexpr int U = 512 / TH > 0 ? 512 / TH : 1;  // runs per lane (nslices <= 512: host-checked)
+    unsigned long long head[U];
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int run = tid + 256 * u;
+    for (int u = 0; u < U; ++u) {
+      const int run = tid + TH * u;
+      head[u] = 0ull;
       if (run < nslices) head[u] = group_key(part_sim[qbase + (size_t)run * K], part_idx[qbase + (size_t)run * K]);
     }
     unsigned long long win[K];
-    wave_topk<2, K>(head, win);
+    wave_topk<U, K>(head, win);
     if (lane == 0) {
 #pragma unroll
       for (int t = 0; t < K; ++t) hk[wv * K + t] = win[t];
@@ -692,9 +699,12 @@ __global__ __launch_bounds__(256, K == 8 ? 6 : 1) void knn_select(const uint8_t*
   stamp[1] = __builtin_amdgcn_s_memrealtime();
   // 2. wave 0: the K runs that can hold the K best groups, then (K = 8) the K best of their K x K entries
   if (wv == 0) {
-    unsigned long long c[1] = {lane < 4 * K ? hk[lane] : 0ull};
+    constexpr int P2 = (NW * K + 63) / 64;  // wave winners per lane
+    unsigned long long c[P2];
+#pragma unroll
+    for (int u = 0; u < P2; ++u) c[u] = lane + 64 * u < NW * K ? hk[lane + 64 * u] : 0ull;
     unsigned long long win[K];
-    wave_topk<1, K>(c, win);
+    wave_topk<P2, K>(c, win);
     if constexpr (K * K <= 64) {
       // K = 8: lane L takes entry L % K of the (L / K)-th selected run: K x K = 64 entries, one per lane
       unsigned long long rk = 0ull;
@@ -758,12 +768,14 @@ __global__ __launch_bounds__(256, K == 8 ? 6 : 1) void knn_select(const uint8_t*
   // K = 8: two passes in flight (the lean form, see the kernel's header)
   constexpr int PASSES = K == 8 ? 2 : 4;
   constexpr int ncand = K * 64;  // 4 chunks x 16 rows per group
-  for (int c0p = 0; c0p < ncand; c0p += 64 * PASSES) {
+  constexpr int RP = TH / 4;     // rows per pass
+  static_assert(ncand % (RP * PASSES) == 0, "whole rescoring rounds");
+  for (int c0p = 0; c0p < ncand; c0p += RP * PASSES) {
     int rows[PASSES];
     float accs[PASSES];
 #pragma unroll
     for (int ps = 0; ps < PASSES; ++ps) {
-      const int c = c0p + ps * 64 + slot;
+      const int c = c0p + ps * RP + slot;
       const int gid = topg[c >> 6];
       const int j = c & 63, cc = j >> 4, e = j & 15;
       int row = INT_MAX;
@@ -814,7 +826,7 @@ __global__ __launch_bounds__(256, K == 8 ? 6 : 1) void knn_select(const uint8_t*
       float a = accs[ps];
       a += __shfl_xor(a, 1, 64);
       a += __shfl_xor(a, 2, 64);
-      const int c = c0p + ps * 64 + slot;
+      const int c = c0p + ps * RP + slot;
       if (sub == 0) {
         cv[c] = rows[ps] != INT_MAX ? a : -INFINITY;
         ci[c] = rows[ps];
@@ -1017,11 +1029,24 @@ int launch_select(const KnnPlan& p, const void* query, const void* bank, int n, 
                   const float* ps, const int* pi, int index_base, int kout, float* out_sim, int* out_idx,
                   hipStream_t st) {
   if (p.nslices > 512) return WM_EUNSUPPORTED;  // two runs per lane of the selection block
-  // wave winners, selected runs / groups, rescored candidates, the query
-  const size_t lds = (4 * K * 8 + K * 4 + (size_t)K * 64 * 8 + (size_t)d * 4 + 15) & ~(size_t)15;
+  // wave winners (up to 16 waves), selected runs / groups, rescored candidates, the query
+  const size_t lds = (16 * K * 8 + K * 4 + (size_t)K * 64 * 8 + (size_t)d * 4 + 15) & ~(size_t)15;
+  const int kk = (knn_debug_bits() & 4) ? -kout : kout;
+  if constexpr (K == 8) {
+    // 1024 threads: the 512 candidate rows are rescored in ONE round of dependent loads instead of four
+    // (WM_KNN_SELECT_THREADS=256 keeps the lean form; read per call: A/B switch)
+    const char* e = getenv("WM_KNN_SELECT_THREADS");
+    if (e == nullptr || atoi(e) == 1024) {
+      knn_select<DT, K, 1024><<<nq, 1024, lds, st>>>(static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank),
+                                                     n, d, rowbytes, ps, pi, p.nslices, p.nslices, wm_cdiv(n, KNN_ROWS),
+                                                     index_base, kk, out_sim, out_idx);
+      WM_LAUNCH_CHECK();
+      return WM_OK;
+    }
+  }
   knn_select<DT, K><<<nq, 256, lds, st>>>(static_cast<const uint8_t*>(query), static_cast<const uint8_t*>(bank), n, d,
                                           rowbytes, ps, pi, p.nslices, p.nslices, wm_cdiv(n, KNN_ROWS), index_base,
-                                          (knn_debug_bits() & 4) ? -kout : kout, out_sim, out_idx);
+                                          kk, out_sim, out_idx);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
