@@ -50,9 +50,9 @@ HBM_PEAK_GBS = 8000.0           # HBM3E, same table
 # sgd_step).  A PMC pass cannot run inside the timed region: this is the committed measurement of the file named
 # below, not a live one.  Algorithmic bytes (every operand once): 230 MB per launch; round 2 measured 510 MB
 # (hardware block order: neighbouring tiles on different XCDs, every L2 fetching its own copy of shared operand rows).
-CONV_TRAFFIC_BYTES_PER_LAUNCH = 305.1e6
+CONV_TRAFFIC_BYTES_PER_LAUNCH = 294.4e6
 CONV_TRAFFIC_SOURCE = ("profiles/r03_hbm_traffic_simclr_r18.md (rocprofv3 --pmc, separate passes; 264 conv launches of 4 "
-                       "steps; 36.3 GB per step over all kernels)")
+                       "steps; 35.7 GB per step over all kernels)")
 # the same for the transformer workloads: {workload: (bytes per GEMM / attention launch, source)}
 VIT_TRAFFIC = {
     "dino_vit_tiny": (67.4e6, "profiles/r03_hbm_traffic_dino_vit_tiny.md (1044 GEMM / attention launches of 4 steps; "
@@ -190,12 +190,12 @@ def knn_object(dev):
             bytes_ = KNN_N * KNN_D * s + bq * KNN_D * s + bq * KNN_K * 8      # SURVEY 8d formula (ii), one batch
             # many batches, pipelined over HIP streams (functional.knn_topk_batched): the selection kernel of one batch
             # under the streaming kernel of the next -- the rate an embedding-retrieval job sees
-            nb = 48 if bq <= 256 else 12
+            nb = 256 if bq <= 256 else 32   # (enough batches that the first streaming kernel and the last selection are amortised)
             qq = bank[2000:2000 + nb * bq].contiguous()
             F.knn_topk_batched(qq, bank, KNN_K, batch=bq)
             torch.cuda.synchronize()
             us_p = float("inf")
-            for _ in range(3):  # best of three calls of nb batches each (one call is 0.5 - 4 ms: host jitter shows)
+            for _ in range(3):  # best of three calls of nb batches each (host jitter shows in a single call)
                 a.record()
                 F.knn_topk_batched(qq, bank, KNN_K, batch=bq)
                 b.record()
