@@ -46,7 +46,9 @@ def test_knn_topk_f32(nq, n, d, k):
     _check_topk(sim, idx, sim_ref, idx_ref, full, 2e-6)
 
 
-@pytest.mark.parametrize("nq,n,d,k", [(256, 50000, 128, 8), (64, 12449, 512, 5), (100, 3000, 256, 16)])
+# (64, 262235, 128, 8): 2 049 chunks on 410 slices (a last round that only some slices take part in)
+@pytest.mark.parametrize("nq,n,d,k", [(256, 50000, 128, 8), (64, 12449, 512, 5), (100, 3000, 256, 16), (64, 262235, 128, 8),
+                                      (40, 262235, 128, 16)])
 def test_knn_topk_bf16(nq, n, d, k):
     from ssl_wafermap_amd import functional as F
 
@@ -125,6 +127,12 @@ def test_knn_full_size_properties():
     full = (q[:4].float().cpu() @ bank.float().cpu().t())
     sref, iref = full.topk(8, dim=1)
     torch.testing.assert_close(sim[:4].cpu(), sref, atol=3e-6, rtol=0)
+    # every query against a float32 product on the device (the shares of the streaming blocks must cover every bank
+    # row exactly once: a dropped or doubled chunk shows here)
+    full_all = q.float() @ bank.float().t()
+    sref, iref = full_all.topk(8, dim=1)
+    _check_topk(sim, idx, sref.cpu(), iref.cpu(), full_all.cpu(), 3e-6)
+    del full_all
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
