@@ -55,13 +55,13 @@ CONV_TRAFFIC_SOURCE = ("profiles/r03_hbm_traffic_simclr_r18.md (rocprofv3 --pmc,
                        "steps; 35.7 GB per step over all kernels)")
 # the same for the transformer workloads: {workload: (bytes per GEMM / attention launch, source)}
 VIT_TRAFFIC = {
-    "dino_vit_tiny": (67.4e6, "profiles/r03_hbm_traffic_dino_vit_tiny.md (1044 GEMM / attention launches of 4 steps; "
-                              "22.6 GB per step over all kernels)"),
+    "dino_vit_tiny": (68.1e6, "profiles/r03_hbm_traffic_dino_vit_tiny.md (1044 GEMM / attention launches of 4 steps; "
+                              "22.8 GB per step over all kernels)"),
     "mae_vit_small_16": (28.8e6, "profiles/r03_hbm_traffic_mae_vit_small_16.md (760 GEMM / attention launches of 4 steps; "
                                  "9.2 GB per step over all kernels)"),
 }
 # one wm_knn_topk call, 64 bf16 queries: streaming kernel 210.1 MB + selection 9.5 MB (profiles/r03_hbm_traffic_knn_b64.md)
-KNN_B64_TRAFFIC_BYTES = 219.6e6
+KNN_B64_TRAFFIC_BYTES = 219.5e6
 R18_GFLOP_PER_SAMPLE = 21.76    # ResNet-18 fwd 3.627 GFLOP x 3 (fwd+bwd) x 2 views
 KNN_N, KNN_D, KNN_K = 811457, 128, 8
 
