@@ -111,6 +111,24 @@ def test_knn_predict_matches_oracle():
     torch.testing.assert_close(sc.cpu(), scores, rtol=2e-4, atol=1e-3)
 
 
+def test_knn_selection_kernel_forms_agree(monkeypatch):
+    """knn_select with 1 024 threads per query (default for k <= 8: one rescoring round) and with 256 (four rounds):
+    the same candidates, the same exact rescoring -> identical results, bf16 and float32."""
+    from ssl_wafermap_amd import functional as F
+
+    g = torch.Generator().manual_seed(11)
+    bank = torch.nn.functional.normalize(torch.randn(70001, 128, generator=g), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(96, 128, generator=g), dim=1)
+    for dt in (torch.bfloat16, torch.float32):
+        b, qq = bank.to(dt).to(_dev()), q.to(dt).to(_dev())
+        out = {}
+        for th in ("256", "1024"):
+            monkeypatch.setenv("WM_KNN_SELECT_THREADS", th)  # (read per call)
+            out[th] = F.knn_topk(qq, b, 8)
+            torch.cuda.synchronize()
+        assert torch.equal(out["256"][0], out["1024"][0]) and torch.equal(out["256"][1], out["1024"][1])
+
+
 def test_knn_full_size_properties():
     """BASELINE scale (811 457 x 128, bf16): self-retrieval, sortedness, spot check vs CPU."""
     from ssl_wafermap_amd import functional as F
