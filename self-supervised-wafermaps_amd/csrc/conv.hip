@@ -1284,6 +1284,158 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
   }
 }
 
+
+// ------------------------------------------------------------- weight gradient of the 64 -> 64 channel 3x3 layers
+// conv_wgrad<64, 8, 3> on layer1 is bound by its tile fetches (ablation builds: fetches alone 157 of 170 us, at the
+// chip's L2 -> LDS rate): three blocks per 64-pixel chunk each fetch the dY tile and gather three 8-KB X tiles, one per
+// tap -- 96 KB per chunk, the input re-read nine times through L2.  Here a chunk is an 8 x 8 output tile, its 10 x 10
+// input patch is fetched ONCE (12.8 KB) and the nine taps shift the transposed-read address inside the patch; one block
+// multiplies all nine taps (the dY fragments are read once per k-step for 36 MFMAs): 20.8 KB per chunk, 72 MFMAs per
+// barrier instead of 24.  Layout: dY tile [ty * 8 + tx][64 k] in 128-byte rows, 32-byte blocks XOR-swizzled as in
+// conv_wgrad; patch [py * 10 + px] in 160-BYTE pixel slots (128 B of channels + 32 B never read): a half-wave's
+// transposed read takes one 32-byte block of eight consecutive pixels, 160 k + 32 b bytes -> banks 40 k + 8 b mod 64,
+// eight disjoint groups of eight: conflict free WITHOUT a swizzle, so a tap is a constant byte offset (an immediate of
+// the ds_read) from one per-lane base address.  (First build: 128-byte slots with the XOR swizzle keyed on the patch
+// pixel -- 72 distinct read addresses per lane, recomputed every chunk for want of registers: 250 us against 175.)
+// MFMA k-slot <-> pixel map that of conv_wgrad.  Results: per-split partial sums in slabs as before (the pixel order
+// inside a split differs from conv_wgrad's, so the sums agree to rounding, not bit for bit).
+constexpr int WP_PITCH = 10;
+constexpr int WP_XSLOT = 160;   // bytes per patch pixel
+constexpr int WP_X_INSTR = 16;  // 100 pixels x 10 sixteen-byte slots = 1 000 lanes -> 16 x 64
+constexpr int WP_A_BYTES = 64 * 128;
+constexpr int WP_STAGE = WP_A_BYTES + WP_X_INSTR * 1024;
+constexpr int WP_LDS = 2 * WP_STAGE;
+
+__global__ __launch_bounds__(CV_THREADS, 2) void conv_wgrad_patch64(const WgradArgs a, const WmDiv d_tpi, const WmDiv d_tw) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t wg_smem[];
+  constexpr int RA = 128, RB = 128, MJ = 2, NJ = 2, NT = 9;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  int bz = blockIdx.x;
+  if (a.xcd) bz = (int)wm_xcd_swizzle(blockIdx.x, gridDim.x);  // neighbouring tiles (shared halo rows) on one XCD
+  const int cout_w = (wave >> 1) * 32, col_w = (wave & 1) * 32;  // 2 x 2 waves: 32 output channels x 32 columns of every tap
+
+  const int chunk_begin = bz * a.chunks_per_split;
+  int chunk_end = chunk_begin + a.chunks_per_split;
+  if (chunk_end > a.total_chunks) chunk_end = a.total_chunks;
+  const int iters = chunk_end - chunk_begin;
+
+  // ---- DMA lane geometry.  dY: instruction i covers tile row ty = i * 4 + wave (8 pixels x 128 B)
+  const int a_ro = lane >> 3, a_pc = lane & 7;
+  uint32_t a_off[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int ty = i * 4 + wave, row = ty * 8 + a_ro;
+    const int lc = (wg_swz<RA>(row, a_pc >> 1) << 1) | (a_pc & 1);
+    a_off[i] = (uint32_t)((ty * a.Q + a_ro) * a.K + lc * 8);  // relative to the tile's first pixel
+  }
+  // patch: instruction j = wave + 4 q fills the sixteen-byte slots 64 j .. 64 j + 63; slot = pixel * 10 + piece,
+  // pieces 8 and 9 of a pixel (and the slots past pixel 99) are padding
+  int x_off[4], x_py[4], x_px[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int slot = (wave + 4 * q) * 64 + lane;
+    const int pidx = slot / 10, piece = slot - pidx * 10;
+    const int py = pidx / WP_PITCH, px = pidx - py * WP_PITCH;
+    x_py[q] = (pidx < WP_PITCH * WP_PITCH && piece < 8) ? py : -100;  // (padding: never in range -> zeros)
+    x_px[q] = px;
+    x_off[q] = ((py - 1) * a.W + (px - 1)) * a.C + (piece & 7) * 8;
+  }
+
+  const uint32_t smem_base = lds_addr(wg_smem);
+  auto issue = [&](int it, uint32_t stage) {
+    const uint32_t c = (uint32_t)(chunk_begin + it);
+    uint32_t t, tw;
+    const int n = (int)wm_divmod(c, d_tpi, t);
+    const int th = (int)wm_divmod(t, d_tw, tw);
+    const int h0 = th * 8, w0 = (int)tw * 8;
+    const uint32_t org = (uint32_t)((n * a.H + h0) * a.W + w0);  // (P = H, Q = W; element offsets fit 32 bits: host-checked)
+#pragma unroll
+    for (int i = 0; i < 2; ++i) glds16_at(a.dy + (org * (uint32_t)a.K + a_off[i]), stage + ((i * 4 + wave) * 8) * RA);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = wave + 4 * q;
+      const int sh = h0 - 1 + x_py[q], sw = w0 - 1 + x_px[q];
+      const bool ok = (unsigned)sh < (unsigned)a.H && (unsigned)sw < (unsigned)a.W;
+      const uint16_t* src = ok ? a.x + (long long)org * a.C + x_off[q] : conv_zero_page;
+      glds16_at(src, stage + WP_A_BYTES + j * 1024);
+    }
+  };
+
+  f32x4_t acc[MJ][NT * NJ];
+#pragma unroll
+  for (int i = 0; i < MJ; ++i)
+#pragma unroll
+    for (int j = 0; j < NT * NJ; ++j) acc[i][j] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+
+  const int tg = lane >> 4, tq = (lane & 15) >> 2, tp = lane & 3;
+  auto tr_read = [&](const uint8_t* p) -> s16x4_t {
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(p));
+  };
+  // pixel 4 tg + tq of the tile = (tg >> 1, 4 (tg & 1) + tq); column block col_w / 16; 8 bytes per tp
+  const int x_lane = ((tg >> 1) * WP_PITCH + 4 * (tg & 1) + tq) * WP_XSLOT + (col_w >> 4) * 32 + 8 * tp;
+  auto compute = [&](const uint8_t* buf) {
+    const uint8_t* xb = buf + WP_A_BYTES;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      const int r0 = ks * 32 + 4 * tg + tq, r1 = r0 + 16;  // pixels of the tile: (r >> 3, r & 7)
+      bf16x8_t af[MJ];
+#pragma unroll
+      for (int i = 0; i < MJ; ++i) {
+        const int blk = (cout_w + i * 16) >> 4;
+        const s16x4_t lo = tr_read(buf + r0 * RA + wg_swz<RA>(r0, blk) * 32 + 8 * tp);
+        const s16x4_t hi = tr_read(buf + r1 * RA + wg_swz<RA>(r1, blk) * 32 + 8 * tp);
+        const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        af[i] = __builtin_bit_cast(bf16x8_t, v);
+      }
+      // this lane's patch address for tap (0, 0), k-step 0, column block 0; everything else is a constant offset
+      const uint8_t* xl = xb + x_lane + ks * (4 * WP_PITCH * WP_XSLOT);
+#pragma unroll
+      for (int t = 0; t < NT; ++t) {
+        const int toff = ((t / 3) * WP_PITCH + (t % 3)) * WP_XSLOT;
+        bf16x8_t bfr[NJ];
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) {
+          const s16x4_t lo = tr_read(xl + toff + j * 32);
+          const s16x4_t hi = tr_read(xl + toff + j * 32 + 2 * WP_PITCH * WP_XSLOT);
+          const s16x8_t v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          bfr[j] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int i = 0; i < MJ; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            acc[i][t * NJ + j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][t * NJ + j], 0, 0, 0);
+      }
+    }
+  };
+
+  issue(0, smem_base);
+  for (int it = 0; it < iters; ++it) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    wm_barrier();
+    if (it + 1 < iters) issue(it + 1, smem_base + ((it + 1) & 1) * WP_STAGE);
+    else wm_barrier();  // (as in conv_igemm: a phase between the retiring wait and the reads when nothing is issued)
+    compute(wg_smem + (it & 1) * WP_STAGE);
+  }
+
+  const size_t rsc = (size_t)9 * a.C;
+  const int fr = lane & 15, fg = lane >> 4;
+  float* slab = a.dw + (size_t)bz * (size_t)a.K * rsc;
+#pragma unroll
+  for (int i = 0; i < MJ; ++i)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int kk = cout_w + i * 16 + fg * 4 + e;
+          const int col = t * 64 + col_w + j * 16 + fr;
+          slab[(size_t)kk * rsc + col] = acc[i][t * NJ + j][e];
+        }
+}
+
 template <typename K>
 int set_lds(K kernel, int bytes) {
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel),
@@ -1392,6 +1544,13 @@ inline void wgrad_plan(const WgradArgs& a, int BMO, int NT, int& nsplit, int& ch
   }
   int tgt = target;
   if (a.R * a.S == 1 && a.H * a.W == 1 && target == 512) tgt = target_lin > 0 ? target_lin : (total_chunks >= 256 ? 512 : 256);
+  if (NT == 9) {  // conv_wgrad_patch64: one block owns the whole K x R x S x C gradient, every split costs a full slab
+    // (kernel alone 112 us with 512 blocks, 130 with 256 -- but the fold then reads 150 instead of 300 MB of slabs
+    // for the four layer1 convolutions: SimCLR step 11.32 ms with 256 or 384 blocks, 11.38 with 512, 11.51 without this
+    // kernel, one box)
+    const char* e = getenv("WM_WGRAD_PATCH_BLOCKS");  // (read per call)
+    tgt = e ? atoi(e) : 256;
+  }
   nsplit = tgt / (colgroups * ktiles);
   if (nsplit < 1) nsplit = 1;
   if (nsplit > total_chunks) nsplit = total_chunks;
@@ -1421,6 +1580,28 @@ int launch_wgrad(const WgradArgs& a, hipStream_t st) {
   if (a.dbias == nullptr) return launch_wgrad_impl<BMO, CPT, NT, false>(a, st);
   if constexpr (CPT == 8) return launch_wgrad_impl<BMO, CPT, NT, true>(a, st);
   return WM_EUNSUPPORTED;  // no bias gradient on the space-to-depth stem form
+}
+
+// the patch-resident form (conv_wgrad_patch64): WM_WGRAD_PATCH=0 keeps conv_wgrad<64, 8, 3>
+inline bool wgrad_patch_ok(const WgradArgs& a) {
+  const char* e = getenv("WM_WGRAD_PATCH");  // (read per call: A/B switch)
+  if (e != nullptr && atoi(e) == 0) return false;
+  return a.C == 64 && a.K == 64 && a.R == 3 && a.S == 3 && a.stride == 1 && a.pad == 1 && a.P == a.H && a.Q == a.W &&
+         (a.H & 7) == 0 && (a.W & 7) == 0 && a.dbias == nullptr;
+}
+inline int launch_wgrad_patch(WgradArgs a, hipStream_t st) {
+  static bool attr = false;
+  if (!attr) {
+    const int rc = set_lds(&conv_wgrad_patch64, WP_LDS);
+    if (rc != WM_OK) return rc;
+    attr = true;
+  }
+  int nsplit;
+  wgrad_plan(a, 64, 9, nsplit, a.chunks_per_split, a.total_chunks);  // one block per split: all nine taps, all 64 channels
+  const int tiles_w = a.W >> 3, tpi = (a.H >> 3) * tiles_w;
+  conv_wgrad_patch64<<<nsplit, CV_THREADS, WP_LDS, st>>>(a, wm_div_make((uint32_t)tpi), wm_div_make((uint32_t)tiles_w));
+  WM_LAUNCH_CHECK();
+  return WM_OK;
 }
 
 // tile configuration of a weight-gradient shape (one place: the launch and wm_conv2d_wgrad_splits must agree)
@@ -1783,6 +1964,7 @@ extern "C" int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_krs
   a.stride = stride; a.pad = pad; a.M = N * P * Q;
   a.chunks_per_split = 0; a.total_chunks = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (wgrad_patch_ok(a)) return launch_wgrad_patch(a, st);
   int bmo, cpt, nt;
   wgrad_config(C, K, R, S, bmo, cpt, nt);
   if (cpt == 2) {
@@ -1802,8 +1984,10 @@ extern "C" int wm_conv2d_wgrad_splits(int N, int H, int W, int C, int K, int R, 
   if (rc != WM_OK) return rc;
   WgradArgs a{};
   a.N = N; a.H = H; a.W = W; a.C = C; a.K = K; a.R = R; a.S = S; a.P = P; a.Q = Q;
+  a.stride = stride; a.pad = pad; a.dbias = nullptr;
   int bmo, cpt, nt, nsplit, cps, tc;
   wgrad_config(C, K, R, S, bmo, cpt, nt);
+  if (wgrad_patch_ok(a)) { bmo = 64; nt = 9; }  // (a bias gradient is only asked of Linear layers: never this shape)
   wgrad_plan(a, bmo, nt, nsplit, cps, tc);
   return nsplit;
 }
