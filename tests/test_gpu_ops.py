@@ -43,6 +43,9 @@ CONVS = [
     (5, 512, 7, 7, 512, 3, 1, 1), (1, 64, 9, 11, 64, 3, 1, 1), (1, 128, 5, 7, 64, 3, 2, 1),
     # stride-2 dgrad by parity class (needs N*(H/2)*(W/2) % 128 == 0)
     (8, 64, 56, 56, 128, 3, 2, 1), (8, 64, 56, 56, 128, 1, 2, 0), (32, 128, 28, 28, 256, 3, 2, 1),
+    # 64 -> 64 with sides that are whole 8 x 8 tiles: the patch-resident weight gradient (one tile per image; every tile
+    # on a border; more splits than tiles)
+    (3, 64, 8, 8, 64, 3, 1, 1), (1, 64, 8, 24, 64, 3, 1, 1), (5, 64, 24, 16, 64, 3, 1, 1),
 ]
 
 
