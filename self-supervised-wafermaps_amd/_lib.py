@@ -12,7 +12,9 @@ from ctypes import c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_ui
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
-LIB_PATH = _HERE / "libwafer_hip.so"
+# WM_HIP_LIB: another build of the library (A/B runs of a kernel change inside one gpurun call: build the old
+# revision to a second file and alternate); it must exist -- there is no fallback either way
+LIB_PATH = Path(os.environ["WM_HIP_LIB"]) if os.environ.get("WM_HIP_LIB") else _HERE / "libwafer_hip.so"
 
 WM_F32, WM_BF16 = 0, 1
 WM_AUG_NONE, WM_AUG_DIENOISE, WM_AUG_DPW, WM_AUG_MEDIAN3 = 0, 1, 2, 3

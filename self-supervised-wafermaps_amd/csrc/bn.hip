@@ -461,8 +461,12 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize(
   }
 }
 
-template <bool POW2>
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __restrict__ y,
+// FORM 0: gradient tensor in, nothing else (no ReLU mask, no dz copy: the form behind the dgrad epilogues, 21 launches of
+// a SimCLR step); 1: + the optional ReLU mask (from `out` or recomputed) and dz output; 2: the gradient is gathered from a
+// pooled gradient (PoolSrc).  Separate instantiations because the pass is bound by the bytes it keeps in flight: with
+// everything compiled into one kernel it needed 142 registers (three waves per SIMD); form 0 runs five.
+template <bool POW2, int FORM>
+__global__ __launch_bounds__(BN_THREADS, FORM == 0 ? 4 : 1) void bn_bwd_apply(const uint16_t* __restrict__ y,
                                                            const uint16_t* __restrict__ dout,
                                                            const uint16_t* __restrict__ out,
                                                            const float* __restrict__ coef,
@@ -472,7 +476,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __res
   const int cpr = C >> 3;
   const long long total = rows * cpr;
   int cur_g = -1;
-  float k[7][8];  // mean, invstd, gamma*invstd, s1/M, s2/M, forward scale, forward shift
+  constexpr int NK = FORM == 0 ? 5 : 7;
+  float k[NK][8];  // mean, invstd, gamma*invstd, s1/M, s2/M, (forward scale, forward shift: the recomputed mask)
   for (long long p = (long long)blockIdx.x * BN_THREADS + threadIdx.x; p < total;
        p += (long long)gridDim.x * BN_THREADS) {
     long long row;
@@ -490,7 +495,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __res
     if (!POW2 || g != cur_g) {
       const float* cf = coef + (size_t)g * 7 * C + c0;
 #pragma unroll
-      for (int t = 0; t < 7; ++t) {
+      for (int t = 0; t < NK; ++t) {
         const float4 a = *reinterpret_cast<const float4*>(cf + (size_t)t * C);
         const float4 b = *reinterpret_cast<const float4*>(cf + (size_t)t * C + 4);
         k[t][0] = a.x; k[t][1] = a.y; k[t][2] = a.z; k[t][3] = a.w;
@@ -501,19 +506,21 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply(const uint16_t* __res
     const size_t off = row * C + c0;
     float fy[8], fd[8];
     unpack8(*reinterpret_cast<const uint4*>(y + off), fy);
-    if (ps.dy != nullptr) pool_grad8(ps, (uint32_t)row, C, c0, fd);
+    if constexpr (FORM == 2) pool_grad8(ps, (uint32_t)row, C, c0, fd);
     else unpack8(*reinterpret_cast<const uint4*>(dout + off), fd);
-    if (out) {
-      float fo[8];
-      unpack8(*reinterpret_cast<const uint4*>(out + off), fo);
+    if constexpr (FORM != 0) {
+      if (out) {
+        float fo[8];
+        unpack8(*reinterpret_cast<const uint4*>(out + off), fo);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) fd[e] = fo[e] > 0.f ? fd[e] : 0.f;
-    }
-    if (!out && remask) {
+        for (int e = 0; e < 8; ++e) fd[e] = fo[e] > 0.f ? fd[e] : 0.f;
+      }
+      if (!out && remask) {
 #pragma unroll
-      for (int e = 0; e < 8; ++e) fd[e] = bf2f(f2bf(fmaf(fy[e], k[5][e], k[6][e]))) > 0.f ? fd[e] : 0.f;
+        for (int e = 0; e < 8; ++e) fd[e] = bf2f(f2bf(fmaf(fy[e], k[NK - 2][e], k[NK - 1][e]))) > 0.f ? fd[e] : 0.f;
+      }
+      if (dz) *reinterpret_cast<uint4*>(dz + off) = pack8(fd);
     }
-    if (dz) *reinterpret_cast<uint4*>(dz + off) = pack8(fd);
     float r[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -1002,11 +1009,11 @@ extern "C" int wm_bn_train_bwd_from_stats(const void* y, const void* g, const fl
   const int tpr = C >> 3;
   int csh = 0;
   if (chunk_pow2(C, &csh))
-    bn_bwd_apply<true><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+    bn_bwd_apply<true, 0><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(g), nullptr, coef, rows, C, rpg, 0, csh,
         static_cast<uint16_t*>(dy), nullptr, PoolSrc{});
   else
-    bn_bwd_apply<false><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+    bn_bwd_apply<false, 0><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(g), nullptr, coef, rows, C, rpg, 0, csh,
         static_cast<uint16_t*>(dy), nullptr, PoolSrc{});
   WM_LAUNCH_CHECK();
@@ -1089,14 +1096,22 @@ static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, in
     WM_LAUNCH_CHECK();
     return WM_OK;
   }
-  if (chunk_pow2(C, &csh))
-    bn_bwd_apply<true><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+  const bool pow2 = chunk_pow2(C, &csh);
+  auto launch = [&](auto kernel) {
+    kernel<<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
         coef, rows, C, rpg, remask ? 1 : 0, csh, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz), ps);
-  else
-    bn_bwd_apply<false><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
-        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
-        coef, rows, C, rpg, remask ? 1 : 0, csh, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz), ps);
+  };
+  if (ps.dy != nullptr) {
+    if (pow2) launch(bn_bwd_apply<true, 2>);
+    else launch(bn_bwd_apply<false, 2>);
+  } else if (out_relu == nullptr && !remask && dz == nullptr) {
+    if (pow2) launch(bn_bwd_apply<true, 0>);
+    else launch(bn_bwd_apply<false, 0>);
+  } else {
+    if (pow2) launch(bn_bwd_apply<true, 1>);
+    else launch(bn_bwd_apply<false, 1>);
+  }
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -1214,11 +1229,11 @@ extern "C" int wm_bn_sync_bwd_apply(const void* y, const void* dout, const void*
   const int tpr = C >> 3;
   int csh = 0;
   if (chunk_pow2(C, &csh))
-    bn_bwd_apply<true><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+    bn_bwd_apply<true, 1><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
         coef, rows, C, rpg, remask ? 1 : 0, csh, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz), PoolSrc{});
   else
-    bn_bwd_apply<false><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
+    bn_bwd_apply<false, 1><<<stream_grid(rows * tpr), BN_THREADS, 0, st>>>(
         static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
         coef, rows, C, rpg, remask ? 1 : 0, csh, static_cast<uint16_t*>(dy), static_cast<uint16_t*>(dz), PoolSrc{});
   WM_LAUNCH_CHECK();
