@@ -536,7 +536,7 @@ __global__ __launch_bounds__(BN_THREADS, FORM == 0 ? 4 : 1) void bn_bwd_apply(co
 // (a+1, b), (a+1, b+1) only, so the pooled gradient and the window positions are read 4 times per
 // quad instead of 9 (1 + 2 + 2 + 4 per pixel), with fixed position codes per (pixel, window).
 __global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply(const uint16_t* __restrict__ y,
-                                                                const float* __restrict__ coef, int N, int C,
+                                                                const float* __restrict__ coef, int n_coef, int N, int C,
                                                                 int imgs_per_group, int remask,
                                                                 uint16_t* __restrict__ dy, const PoolSrc ps,
                                                                 const WmDiv d_cpr, const WmDiv d_wb, const WmDiv d_ha,
@@ -545,8 +545,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply(const uint16_t* 
   const uint32_t cpr = (uint32_t)C >> 3;
   const uint32_t HA = (uint32_t)ps.H >> 1, WB = (uint32_t)ps.W >> 1;
   const uint32_t total = (uint32_t)N * HA * WB * cpr;
-  int cur_g = -1;
-  float k[7][8];
+  // The coefficient rows of every group sit in LDS ([G][7][C] floats, a few KB) and are read where they are used: held in
+  // registers across the loop (first build: 56 of them) the kernel needed 196 registers -- two waves per SIMD for a pass
+  // that moves 2.3 GB.
+  extern __shared__ __attribute__((aligned(16))) float pool_coef[];
+  for (int i = threadIdx.x; i < n_coef; i += BN_THREADS) pool_coef[i] = coef[i];
+  __syncthreads();
   for (uint32_t t = blockIdx.x * BN_THREADS + threadIdx.x; t < total; t += gridDim.x * BN_THREADS) {
     uint32_t rc, rb, ra;
     uint32_t u = wm_divmod(t, d_cpr, rc);
@@ -555,17 +559,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply(const uint16_t* 
     const int n = (int)wm_divmod(u, d_ha, ra);
     const int b = (int)rb, a = (int)ra;
     const int g = (int)wm_div((uint32_t)n, d_ipg);
-    if (g != cur_g) {
-      const float* cf = coef + (size_t)g * 7 * C + c0;
-#pragma unroll
-      for (int q = 0; q < 7; ++q) {
-        const float4 lo = *reinterpret_cast<const float4*>(cf + (size_t)q * C);
-        const float4 hi = *reinterpret_cast<const float4*>(cf + (size_t)q * C + 4);
-        k[q][0] = lo.x; k[q][1] = lo.y; k[q][2] = lo.z; k[q][3] = lo.w;
-        k[q][4] = hi.x; k[q][5] = hi.y; k[q][6] = hi.z; k[q][7] = hi.w;
-      }
-      cur_g = g;
-    }
+    const float* kk = pool_coef + (size_t)g * 7 * C + c0;
+    auto krow = [&](int q, float (&v)[8]) {
+      const float4 lo = *reinterpret_cast<const float4*>(kk + q * C);
+      const float4 hi = *reinterpret_cast<const float4*>(kk + q * C + 4);
+      v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w; v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+    };
     // the four windows (clamped addresses; an out-of-range window contributes nothing)
     uint2 pk[4];
     uint4 dv[4];
@@ -609,15 +608,24 @@ __global__ __launch_bounds__(BN_THREADS) void bn_pool_bwd_apply(const uint16_t* 
       float fy[8];
       unpack8(*reinterpret_cast<const uint4*>(y + off), fy);
       if (remask) {
+        float k5[8], k6[8];
+        krow(5, k5);
+        krow(6, k6);
 #pragma unroll
-        for (int e = 0; e < 8; ++e) fd[e] = bf2f(f2bf(fmaf(fy[e], k[5][e], k[6][e]))) > 0.f ? fd[e] : 0.f;
+        for (int e = 0; e < 8; ++e) fd[e] = bf2f(f2bf(fmaf(fy[e], k5[e], k6[e]))) > 0.f ? fd[e] : 0.f;
       }
-      float r[8];
+      float r[8], k0[8], k1[8];
+      krow(0, k0);
+      krow(1, k1);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float xh = (fy[e] - k[0][e]) * k[1][e];
-        r[e] = k[2][e] * (fd[e] - k[3][e] - xh * k[4][e]);
-      }
+      for (int e = 0; e < 8; ++e) r[e] = (fy[e] - k0[e]) * k1[e];  // xhat
+      krow(4, k0);
+      krow(3, k1);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = fd[e] - k1[e] - r[e] * k0[e];
+      krow(2, k0);
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r[e] = k0[e] * r[e];
       *reinterpret_cast<uint4*>(dy + off) = pack8(r);
     }
   }
@@ -1087,10 +1095,10 @@ static int bn_bwd_impl(const void* y, const void* dout, const void* out_relu, in
   WM_LAUNCH_CHECK();
   int csh = 0;
   if (ps.dy != nullptr && !dz && !out_relu && (ps.H & 1) == 0 && (ps.W & 1) == 0 && BN_THREADS % tpr == 0 &&
-      rows * tpr < (1ll << 31)) {  // (32-bit item indices in the quad kernel)
+      rows * tpr < (1ll << 31) && (size_t)G * 7 * C * sizeof(float) <= 32768) {  // (32-bit item indices; coefficient rows in LDS)
     const int n_img = (int)(rows / ((long long)ps.H * ps.W));
-    bn_pool_bwd_apply<<<stream_grid(rows / 4 * tpr), BN_THREADS, 0, st>>>(
-        static_cast<const uint16_t*>(y), coef, n_img, C, n_img / G, remask ? 1 : 0, static_cast<uint16_t*>(dy), ps,
+    bn_pool_bwd_apply<<<stream_grid(rows / 4 * tpr), BN_THREADS, (size_t)G * 7 * C * sizeof(float), st>>>(
+        static_cast<const uint16_t*>(y), coef, G * 7 * C, n_img, C, n_img / G, remask ? 1 : 0, static_cast<uint16_t*>(dy), ps,
         wm_div_make((uint32_t)(C >> 3)), wm_div_make((uint32_t)(ps.W >> 1)), wm_div_make((uint32_t)(ps.H >> 1)),
         wm_div_make((uint32_t)(n_img / G)));
     WM_LAUNCH_CHECK();
