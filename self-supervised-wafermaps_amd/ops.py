@@ -263,7 +263,9 @@ _SPLITS = {}
 
 def wgrad_splits(n, h, w, c, k, r, s, p, q, stride, pad) -> int:
     """Number of pixel-range splits (= slabs) wm_conv2d_wgrad uses for this geometry."""
-    key = (n, h, w, c, k, r, s, p, q, stride, pad)
+    # (the library reads its split-count switches per call: a changed switch must not meet a cached count, the slab buffer
+    # is sized by it)
+    key = (n, h, w, c, k, r, s, p, q, stride, pad, os.environ.get("WM_WGRAD_PATCH"), os.environ.get("WM_WGRAD_PATCH_BLOCKS"))
     v = _SPLITS.get(key)
     if v is None:
         v = int(_lib.load().wm_conv2d_wgrad_splits(n, h, w, c, k, r, s, p, q, stride, pad))
