@@ -177,7 +177,9 @@ struct BnbRegs {
 // safe here: under register pressure hipcc splits the live range -- copies the destination registers before the data
 // has landed -- and the late-landing load then overwrites whatever lives in the old registers.)
 __device__ __forceinline__ void bnb_load16(u32x4_t& dst, const void* p) {
-  dst = *reinterpret_cast<const u32x4_t*>(p);
+  // read-once operand tiles: non-temporal, so that they do not displace the dY rows and weights the DMA loop re-reads
+  // through L2
+  dst = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
 }
 template <int BNC, typename PixOf>
 __device__ __forceinline__ void bnb_prefetch(const ConvArgs& a, BnbRegs<BNC>& R, int n0, int tid, PixOf pix_of) {
