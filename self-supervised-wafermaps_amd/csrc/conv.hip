@@ -1276,7 +1276,7 @@ __global__ __launch_bounds__(CV_THREADS) void conv_wgrad(const WgradArgs a) {
         for (int e = 0; e < 4; ++e) {
           const int kk = k0 + cout_w + i * 16 + fg * 4 + e;
           const int col = (ct0 + tile_w + t) * 64 + col_w + j * 16 + fr;
-          slab[(size_t)kk * rsc + col] = acc[i][t * NJ + j][e];
+          __builtin_nontemporal_store(acc[i][t * NJ + j][e], &slab[(size_t)kk * rsc + col]);  // (read again only by the fold at the end of the pass)
         }
   if (BIAS && bias_wave && fr == 0) {  // every column of bacc holds the same sums: lane column 0 reports
 #pragma unroll
@@ -1434,7 +1434,7 @@ __global__ __launch_bounds__(CV_THREADS, 2) void conv_wgrad_patch64(const WgradA
         for (int e = 0; e < 4; ++e) {
           const int kk = cout_w + i * 16 + fg * 4 + e;
           const int col = t * 64 + col_w + j * 16 + fr;
-          slab[(size_t)kk * rsc + col] = acc[i][t * NJ + j][e];
+          __builtin_nontemporal_store(acc[i][t * NJ + j][e], &slab[(size_t)kk * rsc + col]);  // (read again only by the fold at the end of the pass)
         }
 }
 
