@@ -45,23 +45,10 @@ sys.path.insert(0, str(ROOT))
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16, MI355X_MICROARCH.md chip table
 HBM_PEAK_GBS = 8000.0           # HBM3E, same table
-# HBM-side bytes per conv launch (mean over the implicit-GEMM launches of a step), rocprofv3 --pmc FETCH_SIZE and
-# WRITE_SIZE in separate passes of this script, FETCH_SIZE doubled per the gfx950 correction (calibrated on
-# sgd_step).  A PMC pass cannot run inside the timed region: this is the committed measurement of the file named
-# below, not a live one.  Algorithmic bytes (every operand once): 230 MB per launch; round 2 measured 510 MB
-# (hardware block order: neighbouring tiles on different XCDs, every L2 fetching its own copy of shared operand rows).
-CONV_TRAFFIC_BYTES_PER_LAUNCH = 294.4e6
-CONV_TRAFFIC_SOURCE = ("profiles/r03_hbm_traffic_simclr_r18.md (rocprofv3 --pmc, separate passes; 264 conv launches of 4 "
-                       "steps; 35.7 GB per step over all kernels)")
-# the same for the transformer workloads: {workload: (bytes per GEMM / attention launch, source)}
-VIT_TRAFFIC = {
-    "dino_vit_tiny": (68.1e6, "profiles/r03_hbm_traffic_dino_vit_tiny.md (1044 GEMM / attention launches of 4 steps; "
-                              "22.8 GB per step over all kernels)"),
-    "mae_vit_small_16": (28.8e6, "profiles/r03_hbm_traffic_mae_vit_small_16.md (760 GEMM / attention launches of 4 steps; "
-                                 "9.2 GB per step over all kernels)"),
-}
-# one wm_knn_topk call, 64 bf16 queries: streaming kernel 210.1 MB + selection 9.5 MB (profiles/r03_hbm_traffic_knn_b64.md)
-KNN_B64_TRAFFIC_BYTES = 219.5e6
+# HBM-side bytes per launch of the dominant kernels (rocprofv3 --pmc FETCH_SIZE and WRITE_SIZE in separate passes of this
+# script, FETCH_SIZE doubled per the gfx950 correction, calibrated on sgd_step) live in profiles/traffic.json together
+# with the commit and the kernel-source digest they were measured at: see traffic_entry().  Algorithmic bytes of a conv
+# launch (every operand once): 230 MB.
 R18_GFLOP_PER_SAMPLE = 21.76    # ResNet-18 fwd 3.627 GFLOP x 3 (fwd+bwd) x 2 views
 KNN_N, KNN_D, KNN_K = 811457, 128, 8
 
@@ -207,7 +194,7 @@ def knn_object(dev):
                                 "hbm_GBs": round(bytes_ / us / 1e3, 1), "hbm_frac": round(bytes_ / us / 1e3 / HBM_PEAK_GBS, 3),
                                 "dense_TFLOPs": round(2.0 * bq * KNN_N * KNN_D / us / 1e6, 1),
                                 "allpairs_s": round(us * 1e-6 * (KNN_N / bq), 3),
-                                "traffic": KNN_B64_TRAFFIC_BYTES if (dtype == "bf16" and bq == 64) else None})
+                                "traffic": traffic_entry("knn_b64")[0] if (dtype == "bf16" and bq == 64) else None})
     del bank32, bank16
     torch.cuda.empty_cache()
     return out
@@ -252,6 +239,85 @@ def augment_object(dev, ds, B):
     return {"views": views, "us_per_launch": round(us, 1), "views_per_sec": round(views / us * 1e6, 0),
             "algorithmic_GBs": round(bytes_ / us / 1e3, 1), "hbm_frac": round(bytes_ / us / 1e3 / HBM_PEAK_GBS, 3),
             "written_GBs": round(written / us / 1e3, 1), "fill_same_tensor_us": round(fill_us, 1), "includes": "kernel launches back to back, decisions resident on the device"}
+
+
+# --------------------------------------------------------------------------------------------- self-launch (N > 1)
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` without a launcher (reference switch: scripts/WM811k_benchmark.py:78-85, `devices` +
+    strategy="ddp"): this process -- which has touched neither torch nor the GPU -- starts the N ranks as CHILDREN
+    through torch.distributed.run (one process per GPU, RCCL over xGMI), lets rank 0's JSON line through on stdout and
+    returns the launcher's exit status.  Never an exec: a process is only ever replaced before anything GPU-side exists,
+    and a child is simpler to reason about."""
+    import socket
+    import subprocess
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC: RCCL's cross-process buffers need it on this driver
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), str(Path(__file__).resolve()), *sys.argv[1:]]
+    print(f"[bench] launching {args.gpus} ranks: {' '.join(cmd)}", file=sys.stderr, flush=True)
+    return subprocess.run(cmd, env=env).returncode
+
+
+def dry_run(args) -> None:
+    """The launch / rendezvous / collective plumbing of an N-rank run without any kernel: every rank joins the
+    process group (RCCL on GPUs, gloo on a CPU-only box or under WM_DIST_BACKEND=gloo), all-reduces a one, rank 0
+    prints a line in the bench schema with "dry_run": true."""
+    import torch
+    import torch.distributed as dist
+
+    from ssl_wafermap_amd import distributed as wdist
+
+    rank, world, local = wdist.init_from_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    ranks, backend = 1, "none"
+    if world > 1:
+        backend = dist.get_backend()
+        dev = torch.device("cuda", 0 if os.environ.get("WM_SINGLE_DEVICE") == "1" else local) if backend == "nccl" else torch.device("cpu")
+        one = torch.ones(1, device=dev)
+        dist.all_reduce(one)
+        ranks = int(one.item())
+        dist.barrier()
+    if rank == 0:
+        print(json.dumps({"metric": "imgs/sec (SimCLR ResNet18, bs=256, 224^2)", "value": None, "unit": "imgs/sec",
+                          "n_gpus": world, "steps": 0, "warmup": 0, "dry_run": True, "rccl_ranks": ranks,
+                          "backend": backend, "config": {"workload": args.workload}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def source_digest() -> str:
+    """sha256 over the kernel sources: committed PMC traffic figures name the digest they were measured at."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in sorted((ROOT / "self-supervised-wafermaps_amd" / "csrc").glob("*.h*")):
+        h.update(f.name.encode())
+        h.update(f.read_bytes())
+    return h.hexdigest()[:12]
+
+
+def traffic_entry(key):
+    """(bytes per launch, source, commit, stale) of a committed rocprofv3 --pmc measurement (profiles/traffic.json,
+    written by tools/pmc_traffic.py --json): a PMC pass cannot run inside the timed region, so the line carries the
+    committed figure, the commit and kernel-source digest it was measured at, and says so when the kernels have
+    changed since (`traffic_stale`)."""
+    try:
+        ent = json.loads((ROOT / "profiles" / "traffic.json").read_text()).get(key)
+    except (OSError, ValueError):
+        ent = None
+    if not ent:
+        return None, None, None, None
+    stale = ent.get("kernel_digest") != source_digest()
+    if stale:
+        print(f"[bench] warning: roofline.traffic for {key!r} was measured at commit {ent.get('commit')} (kernel digest "
+              f"{ent.get('kernel_digest')}); the kernel sources have changed since -- re-run tools/pmc_bench.sh", file=sys.stderr)
+    return ent["bytes_per_launch"], ent.get("source"), ent.get("commit"), stale
 
 
 # --------------------------------------------------------------------------------------------- workloads
@@ -309,7 +375,14 @@ def main():
     ap.add_argument("--sharded", action="store_true",
                     help="knn_allpairs: the bank stays row-sharded (no all-gather of the embeddings); every step all-gathers "
                          "the ranks' query batches, searches the local shard and merges the per-rank top-k lists")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch, rendezvous and one all-reduce only (no kernel): checks the N-rank plumbing, also without a GPU")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # no launcher set the rank environment: this (GPU-free) process starts the ranks itself and relays their result
+        raise SystemExit(launch_ranks(args))
+    if args.dry_run:
+        return dry_run(args)
 
     import numpy as np
     import torch
@@ -370,7 +443,8 @@ def main():
             raise SystemExit(3)
         return v
 
-    def roofline_from(timer, sampled_steps, kernel_label, traffic=None, traffic_source=None):
+    def roofline_from(timer, sampled_steps, kernel_label, traffic_key=None):
+        traffic, traffic_source, traffic_commit, traffic_stale = traffic_entry(traffic_key) if traffic_key else (None,) * 4
         summ = timer.summary()
         work = sum(v["work"] for v in summ.values())
         ms = sum(v["ms"] for v in summ.values())
@@ -382,7 +456,7 @@ def main():
              "by_kernel": {k: {"TFLOP/s": round(v["work"] / (v["ms"] * 1e-3) / 1e12, 2),
                                "ms_per_step": round(v["ms"] / max(sampled_steps, 1), 3)} for k, v in summ.items()}}
         if traffic_source:
-            r["traffic_source"] = traffic_source
+            r["traffic_source"], r["traffic_commit"], r["traffic_stale"] = traffic_source, traffic_commit, traffic_stale
         return r
 
     # ------------------------------------------------------------------------------------------ kNN all-pairs
@@ -490,7 +564,7 @@ def main():
                              "achieved": round(bytes_ / us / 1e3, 1) if bq <= 256 else round(2.0 * bq * KNN_N * KNN_D / us / 1e6, 1),
                              "peak": HBM_PEAK_GBS if bq <= 256 else MFMA_BF16_PEAK_TFLOPS, "unit": "GB/s" if bq <= 256 else "TFLOP/s",
                              "frac": round((bytes_ / us / 1e3 / HBM_PEAK_GBS) if bq <= 256 else (2.0 * bq * KNN_N * KNN_D / us / 1e6 / MFMA_BF16_PEAK_TFLOPS), 4),
-                             "traffic": KNN_B64_TRAFFIC_BYTES if bq == 64 else None}})
+                             "traffic": traffic_entry("knn_b64")[0] if bq == 64 else None}})
         return
 
     # ------------------------------------------------------------------------------------------ training workloads
@@ -560,6 +634,28 @@ def main():
 
         dt, gpu_ms, loss = timed(step, warmup, steps)
         final_loss = check_finite(loss)
+        rccl_ranks, ar_exposed = 1, 0.0
+        if world > 1:
+            one = torch.ones(1, device=dev)
+            dist.all_reduce(one)                       # every rank of the job took part in a collective
+            rccl_ranks = int(one.item())
+            # exposed cost of the gradient exchange = the same steps with and without it, measured AFTER the timed region
+            # (without the exchange the replicas drift apart: nothing from here on is a training result)
+            m = max(5, min(20, steps))
+
+            def step_local(i):
+                if graphed is None:
+                    idx = (np.arange(B) + i * B) % len(ds)
+                    opt.zero_grad()
+                    loss_ = model.training_step(ds.get_batch(idx, rng, fmt=FMT), i)
+                    loss_.backward()
+                    opt.step()
+                    return loss_
+                return graphed.step((np.arange(B) + i * B) % len(ds), rng, None)
+
+            dt_with, _, _ = timed(step, 0, m)
+            dt_without, _, _ = timed(step_local, 0, m)
+            ar_exposed = max(0.0, (dt_with - dt_without) / m * 1e3)
 
         # ---- after the timed region: host-side preparation cost of a step, and eager steps with event brackets
         t0 = time.perf_counter()
@@ -575,11 +671,10 @@ def main():
             ops.TIMER = None
             torch.cuda.synchronize()
             if simclr:
-                roof = roofline_from(timer, roof_steps, "conv_igemm + conv3x3_patch + conv_wgrad (implicit-GEMM, bf16 MFMA)",
-                                     CONV_TRAFFIC_BYTES_PER_LAUNCH, CONV_TRAFFIC_SOURCE)
+                roof = roofline_from(timer, roof_steps, "conv_igemm + conv3x3_patch + conv_wgrad (implicit-GEMM, bf16 MFMA)", "simclr_r18")
             else:
                 roof = roofline_from(timer, roof_steps, "Linear GEMMs (conv_igemm 1x1 fwd / dgrad, conv_wgrad) + attn_fwd / attn_bwd, bf16 MFMA",
-                                     VIT_TRAFFIC.get(workload, (None, None))[0], VIT_TRAFFIC.get(workload, (None, None))[1])
+                                     workload)
         imgs = B * world * steps
         value = imgs / dt
         res = {
@@ -592,6 +687,8 @@ def main():
                        "model_tflop_per_step_per_gpu": round(gflop * B / 1e3, 3),
                        "model_mfma_frac": round(value / world * gflop / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)},
             "final_loss": round(final_loss, 4),
+            "rccl_ranks": rccl_ranks,                    # result of an all-reduce of ones over the job's process group
+            "all_reduce_ms_exposed": round(ar_exposed, 3),  # step time with minus without the gradient exchange (after the timed region)
             "gpu_ms_per_step": round(gpu_ms, 3),          # HIP events around the K steps on the launch stream
             "host_prepare_ms_per_step": round(host_prepare_ms, 3),  # drawing + checking the step's augmentation decisions
             "roofline": roof,

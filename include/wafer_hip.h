@@ -236,9 +236,9 @@ int wm_conv2d_dgrad_add(const void* dy, const void* w_crsk, const void* residual
  * scripts/WM811k_benchmark.py:231): the epilogue takes the gradient through the ReLU and accumulates the
  * BatchNorm-backward sums, so that BatchNorm's backward needs no reduction pass and no mask:
  *   g  = (conv_transpose(dy, w) (+ residual)) * mask          -> dx (the MASKED gradient, bf16)
- *   stat_part f32 [G][stat_tiles][2][C] = per-tile (sum g, sum g * bn_y) per channel, stat_tiles = rows of dx per
- *        group / 128 (plain stores into the tile's slot; wm_bn_train_bwd_from_stats adds the slots in order and forms
- *        sum g * xhat = invstd * (sum g y - mean * sum g) in double)
+ *   stat_part f32 [G][stat_tiles][2][C] = per-tile (sum g, sum g * (bn_y - mean)) per channel, stat_tiles = rows of dx
+ *        per group / 128 (plain stores into the tile's slot; wm_bn_train_bwd_from_stats adds the slots in order and
+ *        scales the second sum by invstd to sum g * xhat; centred per element, so no cancellation when |mean| >> std)
  * mask = relu_x > 0 when relu_x (the convolution's own forward input, shape of dx) is given; or the bits of relu_mask
  * ([pixels][C / 8] bytes written by wm_bn_train_fwd* for that tensor: 1/16 of its bytes; give one of the two); else
  * recomputed from bn_y as bf16(bn_y * gamma * invstd + beta - mean * gamma * invstd) > 0 (a BatchNorm without shortcut).

@@ -423,7 +423,7 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize(
     float* __restrict__ part, int nblk, int G, int C, int rows_per_group,
     const float* __restrict__ gamma, const float* __restrict__ beta, const float* __restrict__ mean,
     const float* __restrict__ invstd, float* __restrict__ dgamma, float* __restrict__ dbeta, int accumulate,
-    float* __restrict__ coef, int fx) {  // fx: the second sum is sum g * y (dgrad epilogue), not sum g * xhat
+    float* __restrict__ coef, int fx) {  // fx: the second sum is sum g * (y - mean) (dgrad epilogue), not sum g * xhat
   __shared__ double red[2][2][32][33];
   const int bl = threadIdx.x >> 5, cl = threadIdx.x & 31;
   const int c = blockIdx.x * 32 + cl;
@@ -437,8 +437,8 @@ __global__ __launch_bounds__(1024) void bn_bwd_finalize(
       for (int u = 0; u < ng; ++u) {
         const int g = g0 + u;
         double s1 = s1v[u], s2 = s2v[u];
-        if (fx) {  // the dgrad epilogue accumulated sum g * y: sum g * xhat = invstd * (sum g y - mean * sum g)
-          s2 = (double)invstd[(size_t)g * C + c] * (s2 - (double)mean[(size_t)g * C + c] * s1);
+        if (fx) {  // the dgrad epilogue accumulated sum g * (y - mean): sum g * xhat = invstd * that
+          s2 = (double)invstd[(size_t)g * C + c] * s2;
         }
         tb += s1;
         tg += s2;
@@ -818,6 +818,44 @@ __global__ __launch_bounds__(BN_THREADS) void bn_col_bwd(const uint16_t* __restr
   if (dbeta) dbeta[c] = accumulate ? dbeta[c] + db : db;
 }
 
+// Synchronised form of the wide case: this rank's per-(group, channel) totals [G][2][C] for the caller's all-reduce.
+// BWD 0: (sum y, sum y^2); BWD 1: (sum d, sum d * xhat) with the ReLU mask applied to d as in bn_col_bwd.  One thread per
+// channel (coalesced across channels), double accumulators: a few hundred rows, not a hot path.
+template <int BWD>
+__global__ __launch_bounds__(BN_THREADS) void bn_col_sums(const uint16_t* __restrict__ y, const uint16_t* __restrict__ dout,
+                                                          const uint16_t* __restrict__ out_relu, int remask,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          int rpg, int C, int G, float* __restrict__ sums) {
+  const int c = blockIdx.x * BN_THREADS + threadIdx.x;
+  if (c >= C) return;
+  for (int g = 0; g < G; ++g) {
+    const size_t base = (size_t)g * rpg;
+    double a = 0.0, b = 0.0;
+    if constexpr (BWD == 0) {
+      for (int r = 0; r < rpg; ++r) {
+        const double v = (double)bf2f(y[(base + r) * C + c]);
+        a += v;
+        b += v * v;
+      }
+    } else {
+      const float mu = mean[(size_t)g * C + c], is = invstd[(size_t)g * C + c];
+      const float sc = (gamma ? gamma[c] : 1.f) * is, sh = (beta ? beta[c] : 0.f) - mu * sc;
+      for (int r = 0; r < rpg; ++r) {
+        const size_t o = (base + r) * C + c;
+        const float yv = bf2f(y[o]);
+        float d = bf2f(dout[o]);
+        if (out_relu) d = bf2f(out_relu[o]) > 0.f ? d : 0.f;
+        else if (remask) d = bf2f(f2bf(fmaf(yv, sc, sh))) > 0.f ? d : 0.f;
+        a += (double)d;
+        b += (double)d * (double)((yv - mu) * is);
+      }
+    }
+    sums[((size_t)g * 2 + 0) * C + c] = (float)a;
+    sums[((size_t)g * 2 + 1) * C + c] = (float)b;
+  }
+}
+
 inline bool bn_wide(long long rows, int C, int G) {
   return C > 2048 && C <= BN_WIDE_MAX_C && rows / G <= 65536;
 }
@@ -1132,9 +1170,14 @@ extern "C" int wm_bn_sync_fwd_sums(const void* y, long long rows, int C, int G, 
   WM_REQUIRE(y && sums && workspace, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
   if (rc != WM_OK) return rc;
-  WM_REQUIRE(!bn_wide(rows, C, G), WM_EUNSUPPORTED);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rpg = (int)(rows / G);
+  if (bn_wide(rows, C, G)) {   // projection-head widths (BYOL: BatchNorm1d(4096)): one thread per channel
+    bn_col_sums<0><<<wm_cdiv(C, BN_THREADS), BN_THREADS, 0, st>>>(static_cast<const uint16_t*>(y), nullptr, nullptr, 0, nullptr,
+                                                                 nullptr, nullptr, nullptr, rpg, C, G, sums);
+    WM_LAUNCH_CHECK();
+    return WM_OK;
+  }
   int nblk = 0;
   const float* part;
   if (stat_part) {
@@ -1165,8 +1208,7 @@ extern "C" int wm_bn_sync_fwd_apply(const void* y, const void* residual, const f
   WM_REQUIRE(y && out && save_mean && save_invstd && sums && workspace, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
   if (rc != WM_OK) return rc;
-  WM_REQUIRE(!bn_wide(rows, C, G), WM_EUNSUPPORTED);
-  WM_REQUIRE(group_count >= rows / G && group_count < (1ll << 31), WM_EINVAL);
+  WM_REQUIRE(group_count >= rows / G && group_count < (1ll << 31), WM_EINVAL);   // (finalize + apply serve any width)
   WM_REQUIRE(workspace_bytes >= (size_t)2 * G * C * sizeof(float), WM_EWORKSPACE);
   hipStream_t st = static_cast<hipStream_t>(stream);
   float* scale = static_cast<float*>(workspace);
@@ -1189,23 +1231,29 @@ extern "C" int wm_bn_sync_bwd_sums(const void* y, const void* dout, const void* 
   WM_REQUIRE(y && dout && save_mean && save_invstd && sums && workspace, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
   if (rc != WM_OK) return rc;
-  WM_REQUIRE(!bn_wide(rows, C, G), WM_EUNSUPPORTED);
   WM_REQUIRE(workspace_bytes >= wm_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rpg = (int)(rows / G);
   const int nblk = reduce_blocks(rpg, C);
   float* part = static_cast<float*>(workspace);
   float* coef = part + (size_t)G * nblk * 2 * C;
-  const int tpr = C >> 3, rpp = BN_THREADS / tpr;
-  const size_t lds = (size_t)2 * rpp * C * sizeof(float);
   const bool remask = relu_from_y && !out_relu;
   WM_REQUIRE(!remask || (gamma && beta), WM_EINVAL);
-  bn_reduce<1><<<dim3(nblk, G), BN_THREADS, lds, st>>>(
-      static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
-      save_mean, save_invstd, remask ? gamma : nullptr, remask ? beta : nullptr, rpg, C, wm_cdiv(rpg, nblk), part, PoolSrc{});
-  WM_LAUNCH_CHECK();
-  bn_sums_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, sums);
-  WM_LAUNCH_CHECK();
+  if (bn_wide(rows, C, G)) {
+    bn_col_sums<1><<<wm_cdiv(C, BN_THREADS), BN_THREADS, 0, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
+        remask ? 1 : 0, gamma, beta, save_mean, save_invstd, rpg, C, G, sums);
+    WM_LAUNCH_CHECK();
+  } else {
+    const int tpr = C >> 3, rpp = BN_THREADS / tpr;
+    const size_t lds = (size_t)2 * rpp * C * sizeof(float);
+    bn_reduce<1><<<dim3(nblk, G), BN_THREADS, lds, st>>>(
+        static_cast<const uint16_t*>(y), static_cast<const uint16_t*>(dout), static_cast<const uint16_t*>(out_relu),
+        save_mean, save_invstd, remask ? gamma : nullptr, remask ? beta : nullptr, rpg, C, wm_cdiv(rpg, nblk), part, PoolSrc{});
+    WM_LAUNCH_CHECK();
+    bn_sums_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(part, nblk, G, C, sums);
+    WM_LAUNCH_CHECK();
+  }
   if (dgamma || dbeta) {  // the local parameter gradients from the local totals (coef is scratch here)
     bn_bwd_finalize<<<wm_cdiv(C, 32), 1024, 0, st>>>(sums, 1, G, C, rpg, gamma, beta, save_mean, save_invstd, dgamma,
                                                      dbeta, accumulate, coef, 0);
@@ -1223,8 +1271,7 @@ extern "C" int wm_bn_sync_bwd_apply(const void* y, const void* dout, const void*
   WM_REQUIRE(y && dout && save_mean && save_invstd && sums && dy && workspace, WM_EINVAL);
   const int rc = bn_shape_check(rows, C, G);
   if (rc != WM_OK) return rc;
-  WM_REQUIRE(!bn_wide(rows, C, G), WM_EUNSUPPORTED);
-  WM_REQUIRE(group_count >= rows / G && group_count < (1ll << 31), WM_EINVAL);
+  WM_REQUIRE(group_count >= rows / G && group_count < (1ll << 31), WM_EINVAL);   // (finalize + apply serve any width)
   WM_REQUIRE(workspace_bytes >= (size_t)7 * G * C * sizeof(float), WM_EWORKSPACE);
   hipStream_t st = static_cast<hipStream_t>(stream);
   const int rpg = (int)(rows / G);

@@ -198,7 +198,7 @@ __device__ __forceinline__ void bnb_prefetch(const ConvArgs& a, BnbRegs<BNC>& R,
 }
 
 // bnb_epilogue: staged bf16 tile [128 rows][CS bytes] of BNC channels -> (+ residual) -> ReLU mask -> store, and the
-// tile's (sum g, sum g * bn_y) into its statistics slot.  `red`: 2 x 4 x BNC floats of LDS outside the tile.
+// tile's (sum g, sum g * (bn_y - mean)) into its statistics slot.  `red`: 2 x 4 x BNC floats of LDS outside the tile.
 template <int BNC>
 __device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, const BnbRegs<BNC>& R, const uint8_t* smem, int CS, float* red,
                                              int g, int n0, int tile, int tid) {
@@ -210,20 +210,24 @@ __device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, const BnbRegs<BN
   // shift.  (The forward rounds to bf16 before its ReLU; that rounding changes the sign test only for |value| < 2^-133.)
   const bool remask = a.bn_x == nullptr && a.bn_mask == nullptr;
   const bool bitmask = a.bn_mask != nullptr;
-  float sc[8], sh[8];
+  float sc[8], sh[8], mu[8];
+  const float* pm = a.bn_mean + (size_t)g * a.DC + c0;
 #pragma unroll
-  for (int e = 0; e < 8; ++e) sc[e] = sh[e] = 0.f;
+  for (int e = 0; e < 8; ++e) {
+    sc[e] = sh[e] = 0.f;
+    mu[e] = pm[e];
+  }
   if (remask) {
-    const float* pm = a.bn_mean + (size_t)g * a.DC + c0;
     const float* pi = a.bn_invstd + (size_t)g * a.DC + c0;
 #pragma unroll
     for (int e = 0; e < 8; ++e) {  // bn_fwd_finalize: scale = gamma * invstd, shift = beta - mean * scale
       sc[e] = a.bn_gamma[c0 + e] * pi[e];
-      sh[e] = a.bn_beta[c0 + e] - pm[e] * sc[e];
+      sh[e] = a.bn_beta[c0 + e] - mu[e] * sc[e];
     }
   }
-  // per element: unpack, (+ residual), mask, two running sums (sum g and sum g * y: the finalize kernel turns them
-  // into sum g * xhat = invstd * (sum g y - mean * sum g) in double), pack: ~10 VALU instructions.  The first build
+  // per element: unpack, (+ residual), mask, two running sums (sum g and sum g * (y - mean): the finalize kernel scales
+  // the second by invstd to sum g * xhat; centring per element instead of correcting sum g * y by mean * sum g keeps
+  // the f32 partials free of cancellation when |mean| >> std), pack: ~11 VALU instructions.  The first build
   // (xhat per element, bf16 round trips for the residual sum and the mask) spent as long here as in the MFMA loop.
   float s1[8], s2[8];
 #pragma unroll
@@ -252,7 +256,7 @@ __device__ __forceinline__ void bnb_epilogue(const ConvArgs& a, const BnbRegs<BN
                                     : __builtin_bit_cast(float, h ? (xx[q] & 0xffff0000u) : (xx[q] << 16)) > 0.f;
         v = keep ? v : 0.f;
         s1[e] += v;
-        s2[e] = fmaf(v, y, s2[e]);
+        s2[e] = fmaf(v, y - mu[e], s2[e]);
         gv[h] = v;
       }
       o[q] = pack_bf2(gv[0], gv[1]);
@@ -1966,6 +1970,14 @@ extern "C" int wm_conv2d_wgrad_bias(const void* dy, const void* x, float* dw_krs
   a.stride = stride; a.pad = pad; a.M = N * P * Q;
   a.chunks_per_split = 0; a.total_chunks = 0;
   hipStream_t st = static_cast<hipStream_t>(stream);
+  if (dbias != nullptr) {
+    // wm_conv2d_wgrad_splits answers for the launch WITHOUT a bias gradient; a shape whose plan would differ with one
+    // (the patch-resident 64 -> 64 3x3 form has no bias path) is refused instead of leaving slabs of the caller's
+    // buffer unwritten.  Only Linear layers (1x1) ask for a bias gradient.
+    WgradArgs q = a;
+    q.dbias = nullptr;
+    WM_REQUIRE(!wgrad_patch_ok(q), WM_EUNSUPPORTED);
+  }
   if (wgrad_patch_ok(a)) return launch_wgrad_patch(a, st);
   int bmo, cpt, nt;
   wgrad_config(C, K, R, S, bmo, cpt, nt);

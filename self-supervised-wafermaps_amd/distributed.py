@@ -131,18 +131,36 @@ def sharded_knn_topk(query: torch.Tensor, bank_shard: torch.Tensor, k: int, shar
     return F_hip.knn_merge(torch.stack(sims), torch.stack(idxs))
 
 
+_GATHER_DTYPES = [torch.float32, torch.bfloat16, torch.float16, torch.int64, torch.int32, torch.uint8, torch.float64, torch.bool]
+
+
 def all_gather_rows(t: torch.Tensor) -> torch.Tensor:
     """Concatenation over the ranks (in rank order) of tensors [n_rank, ...] whose first dimension may differ per rank:
-    one all-gather of the row counts, one of the rows padded to the longest shard.  world 1: `t` itself."""
+    one all-gather of a small descriptor (row count, trailing shape, dtype), one of the rows padded to the longest shard.
+    A rank with NO rows (an evaluation loader with fewer batches than ranks) need not know the trailing shape or the
+    dtype: it adopts them from the first rank that has rows, so every rank issues the same collective.  world 1: `t`."""
     w = world_size()
     if w == 1:
         return t
-    n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    counts = [torch.empty_like(n) for _ in range(w)]
-    dist.all_gather(counts, n)
-    counts = [int(c.item()) for c in counts]
+    if t.dim() > 5 or t.dtype not in _GATHER_DTYPES:
+        raise ValueError(f"all_gather_rows: unsupported tensor {tuple(t.shape)} {t.dtype}")
+    desc = torch.zeros(8, dtype=torch.int64, device=t.device)
+    meta = [t.shape[0] if t.dim() else 0, t.dim(), _GATHER_DTYPES.index(t.dtype)] + list(t.shape[1:])
+    desc[: len(meta)] = torch.tensor(meta, dtype=torch.int64)
+    descs = [torch.empty_like(desc) for _ in range(w)]
+    dist.all_gather(descs, desc)
+    descs = [d.tolist() for d in descs]
+    counts = [d[0] for d in descs]
+    lead = next((d for d in descs if d[0] > 0), descs[0])
+    tail, dtype = tuple(lead[3:3 + max(lead[1] - 1, 0)]), _GATHER_DTYPES[lead[2]]
+    if t.shape[0] == 0:
+        t = torch.empty((0,) + tail, dtype=dtype, device=t.device)
+    elif tuple(t.shape[1:]) != tail or t.dtype != dtype:
+        raise ValueError(f"all_gather_rows: rank {rank()} holds {tuple(t.shape)} {t.dtype}, rank with rows holds (n,) + {tail} {dtype}")
     m = max(counts)
-    pad = t.new_zeros((m,) + tuple(t.shape[1:]))
+    if m == 0:
+        return t
+    pad = t.new_zeros((m,) + tail)
     pad[: t.shape[0]] = t
     parts = [torch.empty_like(pad) for _ in range(w)]
     dist.all_gather(parts, pad.contiguous())

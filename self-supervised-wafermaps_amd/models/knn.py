@@ -96,8 +96,10 @@ class KNNBenchmarkModule(nn.Module):
         for img, target in rank_batches(self.dataloader_kNN):
             feats.append(self._features(img.to(self.device)))
             targets.append(target.to(self.device))
-        d = feats[0].shape[1] if feats else 0
-        bank = torch.cat(feats, dim=0).contiguous() if feats else torch.empty((0, d), device=self.device)
+        # (a rank that owns no batch -- fewer batches than ranks -- contributes zero rows; all_gather_rows gives it the
+        # feature width and dtype of the ranks that have some)
+        bank = (torch.cat(feats, dim=0).contiguous() if feats
+                else torch.empty((0, 0), dtype=self.knn_dtype, device=self.device))
         tbank = (torch.cat(targets, dim=0).long().contiguous() if targets
                  else torch.empty((0,), dtype=torch.long, device=self.device))
         if wdist.world_size() > 1 and getattr(self.dataloader_kNN, "world_size", 1) == 1:
@@ -120,7 +122,9 @@ class KNNBenchmarkModule(nn.Module):
         self.all_targets.append(targets.to(self.device))
 
     def on_validation_epoch_end(self):
-        preds, targets = torch.cat(self.all_preds), torch.cat(self.all_targets)
+        empty = torch.empty((0,), dtype=torch.long, device=self.device)
+        preds = torch.cat(self.all_preds) if self.all_preds else empty
+        targets = torch.cat(self.all_targets).long() if self.all_targets else empty
         if wdist.world_size() > 1:   # the ranks validated disjoint shares: the metrics are over all of them
             preds, targets = wdist.all_gather_rows(preds.contiguous()), wdist.all_gather_rows(targets.contiguous())
         acc, f1, cm = macro_metrics(preds, targets, self.num_classes)

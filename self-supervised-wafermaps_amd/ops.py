@@ -834,8 +834,6 @@ class _SyncBatchNorm(torch.autograd.Function):
         rows, c = _rows_c(y)
         if rows % groups:
             raise ValueError("sync_batch_norm: rows not divisible by groups")
-        if c > 2048:
-            raise NotImplementedError("sync_batch_norm: more than 2048 channels")
         lib = _lib.load()
         world = dist.get_world_size(group)
         out = torch.empty_like(y)

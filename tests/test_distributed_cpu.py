@@ -296,7 +296,7 @@ class _ListLoader:
         return iter(self.batches)
 
 
-def _knn_problem():
+def _knn_problem(short=False):
     g = torch.Generator().manual_seed(5)
     proj = torch.randn(20, 12, generator=g)
     centers = torch.randn(4, 20, generator=g) * 2
@@ -305,16 +305,18 @@ def _knn_problem():
         return centers[y] + torch.randn(n, 20, generator=g), y
     xb, yb = make(103)
     xv, yv = make(41)
+    if short:   # ONE batch each: with two ranks, rank 0 owns no batch at all
+        return proj, _ListLoader([(xb, yb)]), _ListLoader([(xv, yv)])
     bank = _ListLoader([(xb[i:i + 16], yb[i:i + 16]) for i in range(0, 103, 16)])   # 7 batches, ragged tail
     val = _ListLoader([(xv[i:i + 8], yv[i:i + 8]) for i in range(0, 41, 8)])        # 6 batches
     return proj, bank, val
 
 
-def _knn_module_run(world_tag):
+def _knn_module_run(world_tag, short=False):
     from ssl_wafermap_amd.models.knn import KNNBenchmarkModule
     from ssl_wafermap_amd.trainer import Trainer
 
-    proj, bank, val = _knn_problem()
+    proj, bank, val = _knn_problem(short)
 
     class M(KNNBenchmarkModule):
         def __init__(self):
@@ -330,11 +332,11 @@ def _knn_module_run(world_tag):
     return m
 
 
-def _sharded_knn_module(rank, world):
+def _sharded_knn_module(rank, world, short=False):
     _knn_stand_ins()
-    m = _knn_module_run("dp")
+    m = _knn_module_run("dp", short)
     # every rank holds the whole bank in single-process order and reports the metrics of ALL validation samples
-    _, bank, val = _knn_problem()
+    _, bank, val = _knn_problem(short)
     assert m.feature_bank_nd.shape[0] == 103 and torch.equal(m.targets_bank, torch.cat([y for _, y in bank.batches]))
     assert m.last_preds.shape[0] == 41 and torch.equal(m.last_targets, torch.cat([y for _, y in val.batches]))
     out = torch.cat([m.last_preds.float(), torch.tensor([m.logged["knn_accuracy"], m.logged["knn_f1"]])])
@@ -355,6 +357,34 @@ def test_knn_module_sharded_evaluation_equals_single_process_world2(tmp_path):
     for r in range(2):
         got = torch.load(str(tmp_path / "knn_out") + f".{r}")
         assert torch.equal(got, want)
+
+
+def test_knn_module_sharded_evaluation_with_fewer_batches_than_ranks_world2(tmp_path):
+    """A one-batch bank loader and a one-batch validation loader under world_size 2: rank 0 owns NO batch.  It must
+    still take part in every collective with the right feature width / dtype (learned from rank 1) and report the
+    single-process metrics (used to raise on rank 0 while rank 1 hung in all_gather)."""
+    _knn_stand_ins()
+    single = _knn_module_run("single", True)
+    want = torch.cat([single.last_preds.float(), torch.tensor([single.logged["knn_accuracy"], single.logged["knn_f1"]])])
+    os.environ["WM_TEST_OUT"] = str(tmp_path / "knn_short")
+    _spawn(_sharded_knn_module, 2, True)
+    for r in range(2):
+        got = torch.load(str(tmp_path / "knn_short") + f".{r}")
+        assert torch.equal(got, want)
+
+
+def test_all_gather_rows_adopts_shape_and_dtype_on_empty_ranks_world2():
+    _spawn(_gather_rows_empty, 2)
+
+
+def _gather_rows_empty(rank, world):
+    from ssl_wafermap_amd import distributed as wdist
+
+    mine = torch.arange(12, dtype=torch.bfloat16).reshape(3, 4) if rank == 1 else torch.empty((0, 0))
+    got = wdist.all_gather_rows(mine)
+    assert got.dtype == torch.bfloat16 and tuple(got.shape) == (3, 4) and torch.equal(got, torch.arange(12, dtype=torch.bfloat16).reshape(3, 4))
+    both_empty = wdist.all_gather_rows(torch.empty((0,), dtype=torch.long))
+    assert both_empty.numel() == 0
 
 
 def test_knn_classifier_fit_and_predict_cpu_contract():
@@ -444,3 +474,38 @@ def _gathered_sinkhorn(rank, world):
 
 def test_sinkhorn_gather_distributed_equals_lightly_allreduce_form_world2():
     _spawn(_gathered_sinkhorn, 2)
+
+
+# ---- bench.py starts its own ranks (reference switch scripts/WM811k_benchmark.py:78-85)
+def test_bench_launches_its_own_ranks_dry_run():
+    """`python bench.py --gpus 2` with no launcher environment: the parent (which never touches torch / the GPU) starts
+    two children through torch.distributed.run, they rendezvous (gloo here, RCCL on GPUs), all-reduce a one, and rank
+    0's JSON line comes back on the parent's stdout with the parent's exit status 0."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["WM_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["dry_run"] is True and out["backend"] == "gloo"
+
+
+def test_bench_launcher_propagates_a_failing_rank():
+    """A rank that exits non-zero (here: --gpus disagrees with the world the launcher made) fails the parent too."""
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, str(root / "bench.py"), "--gpus", "2", "--dry-run"], env=env, capture_output=True,
+                       text=True, timeout=120)
+    assert r.returncode != 0 and "WORLD_SIZE=1" in (r.stderr + r.stdout)

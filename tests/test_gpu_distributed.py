@@ -228,6 +228,67 @@ def test_sync_batchnorm_world2_equals_whole_batch_statistics(tmp_path):
     parity("SyncBN world 2 vs whole-batch BN, running statistics (relative max)", worst_b, 2.2e-7)  # measured 1.1e-7
 
 
+def _sync_bn_wide_case(rank, world, out_path):
+    """BYOL's head width (lightly BYOLProjectionHead: Linear - BatchNorm1d(4096) - ReLU, reference
+    scripts/WM811k_benchmark.py:437-438) under convert_sync_batchnorm, two view groups per rank: the wide
+    (C > 2048) form of the wm_bn_sync_* entry points."""
+    from ssl_wafermap_amd import nn as wnn
+    from ssl_wafermap_amd import ops
+
+    C, b = 4096, 12   # rows per rank and view
+
+    def build():
+        torch.manual_seed(5)
+        bn = wnn.BatchNorm1d(C).to("cuda:0").train()
+        with torch.no_grad():
+            bn.weight.uniform_(0.5, 1.5)
+            bn.bias.uniform_(-0.3, 0.3)
+        return bn
+
+    def run(bn, v, dv):
+        v = v.clone().requires_grad_(True)
+        with ops.bn_groups(2):
+            z = bn(v, relu=True)
+        z.backward(dv)
+        return z.detach(), v.grad, [p.grad.clone() for p in bn.parameters()], [t.clone() for t in bn.buffers()]
+
+    g = torch.Generator().manual_seed(22)
+    # [view][rank][row][C]: a rank sees its rows of both views, view-major; the whole batch is view-major over all ranks
+    full = (torch.randn(2, world, b, C, generator=g) * 1.5 + 0.3).to("cuda:0").bfloat16()
+    dfull = torch.randn(2, world, b, C, generator=g).to("cuda:0").bfloat16()
+    mine, dmine = full[:, rank].reshape(2 * b, C), dfull[:, rank].reshape(2 * b, C)
+    bn = wnn.convert_sync_batchnorm(build())
+    z, dv, grads, bufs = run(bn, mine, dmine)
+    for t in grads:
+        dist.all_reduce(t)
+    outs = []
+    for t in (z, dv):
+        both = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(both, t.contiguous())
+        outs.append(torch.stack([x.reshape(2, b, C) for x in both], dim=1).reshape(2 * world * b, C))
+    if rank == 0:
+        rz, rdv, rgrads, rbufs = run(build(), full.reshape(2 * world * b, C), dfull.reshape(2 * world * b, C))
+        torch.save({"got": [t.float().cpu() for t in outs], "ref": [rz.float().cpu(), rdv.float().cpu()],
+                    "got_g": [t.float().cpu() for t in grads], "ref_g": [t.float().cpu() for t in rgrads],
+                    "got_b": [t.float().cpu() for t in bufs], "ref_b": [t.float().cpu() for t in rbufs]}, out_path)
+
+
+def test_sync_batchnorm_wide_world2_equals_whole_batch_statistics(tmp_path):
+    from parity_log import parity
+
+    out = str(tmp_path / "syncbn_wide.pt")
+    mp.spawn(_entry, args=(2, _free_port(), _sync_bn_wide_case, (out,)), nprocs=2, join=True)
+    d = torch.load(out)
+    for n, a, b in zip(["output", "input gradient"], d["got"], d["ref"]):
+        # the unsynchronised wide kernel takes a two-pass variance, the synchronised one sum / sum of squares (it has to:
+        # the totals cross ranks): outputs on a bf16 rounding boundary may land on the other side
+        parity(f"wide SyncBN (4096 channels) world 2 vs whole-batch BN, {n} (relative L2)", float((a - b).norm() / b.norm()), 2e-3)
+    worst = max(float((a - b).norm() / b.norm().clamp_min(1e-12)) for a, b in zip(d["got_g"], d["ref_g"]))
+    parity("wide SyncBN world 2 vs whole-batch BN, parameter gradients summed over ranks (relative L2, worst)", worst, 1e-4)
+    worst_b = max(float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-12)) for a, b in zip(d["got_b"], d["ref_b"]))
+    parity("wide SyncBN world 2 vs whole-batch BN, running statistics (relative max)", worst_b, 1e-5)
+
+
 def _barlow_gather_case(rank, world, out_path):
     """lightly's BarlowTwinsLoss(gather_distributed=True) (reference scripts/WM811k_benchmark.py:364-366): every rank
     standardises ITS half of the batch, c = z_a^T z_b / N_local / world, all_reduce(c); the gradient reaches the local

@@ -587,6 +587,44 @@ def test_bn_backward_fused_into_dgrad_epilogue_matches_separate_pass():
         assert float(cos) > 0.9995, (a.shape, float(cos))
 
 
+def test_bn_backward_fused_epilogue_with_a_large_channel_mean():
+    """the dgrad epilogue's second sum is centred per element (sum g * (y - mean)); with sum g * y corrected by
+    mean * sum g afterwards, f32 per-tile partials cancel badly when |mean| >> std.  A BasicBlock whose conv1 output has
+    a channel mean of ~100 standard deviations: the fused backward against the separate reduction pass."""
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models.resnet import BasicBlock
+
+    def run(fuse):
+        old = ops._BN_FUSE_BWD
+        ops._BN_FUSE_BWD = fuse
+        try:
+            torch.manual_seed(0)
+            blk = BasicBlock(64, 64).to(DEV).train()
+            with torch.no_grad():
+                blk.conv1.weight.mul_(0.02).add_(0.05)       # every output = a large common term + a small varying one
+                torch.nn.init.normal_(blk.bn2.weight, 1.0, 0.1)
+            g = torch.Generator().manual_seed(1)
+            x = ops.to_nhwc_bf16((4.0 + 0.05 * torch.randn(8, 64, 16, 16, generator=g)).to(DEV)).requires_grad_(True)
+            t = torch.randn(8, 64, 16, 16, generator=g).to(DEV)
+            st = blk.bn1.stats_buffer(1)
+            y = blk.conv1(x, stats=st, groups=1)
+            ratio = float((y.float().mean((0, 2, 3)).abs() / y.float().std((0, 2, 3))).median())
+            out = blk(x)
+            (out.float() * t).sum().backward()
+            torch.cuda.synchronize()
+            # (conv1's weight gradient is left out: with a constant input its value is the rounding residue of sum dy = 0)
+            return ratio, {"dx": x.grad.float(), "bn1.dgamma": blk.bn1.weight.grad.float(), "bn1.dbeta": blk.bn1.bias.grad.float()}
+        finally:
+            ops._BN_FUSE_BWD = old
+
+    ratio, fused = run(True)
+    _, plain = run(False)
+    assert ratio > 30, ratio   # the case the finding describes
+    for k in fused:
+        rel = float((fused[k] - plain[k]).norm() / plain[k].norm().clamp_min(1e-20))
+        parity(f"BatchNorm backward in the dgrad epilogue vs separate pass, |mean|/std = {ratio:.0f}: {k} (relative L2)", rel, 5e-2 if k == "dx" else 2e-2)
+
+
 def test_conv_bn_backward_is_bit_reproducible():
     """No floating-point atomics on the conv / BatchNorm path (fixed-point statistics buckets, split-K slabs folded in
     order): two runs of the same forward + backward give bit-identical gradients."""
