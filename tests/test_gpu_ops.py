@@ -601,7 +601,9 @@ def test_bn_backward_fused_epilogue_with_a_large_channel_mean():
             torch.manual_seed(0)
             blk = BasicBlock(64, 64).to(DEV).train()
             with torch.no_grad():
-                blk.conv1.weight.mul_(0.02).add_(0.05)       # every output = a large common term + a small varying one
+                # every output = a large common term (centre tap only: also at the zero-padded border) + a small varying one
+                blk.conv1.weight.mul_(0.02)
+                blk.conv1.weight[:, :, 1, 1] += 0.05
                 torch.nn.init.normal_(blk.bn2.weight, 1.0, 0.1)
             g = torch.Generator().manual_seed(1)
             x = ops.to_nhwc_bf16((4.0 + 0.05 * torch.randn(8, 64, 16, 16, generator=g)).to(DEV)).requires_grad_(True)
@@ -626,7 +628,7 @@ def test_bn_backward_fused_epilogue_with_a_large_channel_mean():
 
 
 def test_conv_bn_backward_is_bit_reproducible():
-    """No floating-point atomics on the conv / BatchNorm path (fixed-point statistics buckets, split-K slabs folded in
+    """No floating-point atomics on the conv / BatchNorm path (per-tile statistics slots stored and added in order, split-K slabs folded in
     order): two runs of the same forward + backward give bit-identical gradients."""
     a, oa = _block_stack_grads(True)
     b, ob = _block_stack_grads(True)
