@@ -25,7 +25,7 @@
 extern "C" {
 #endif
 
-#define WM_ABI_VERSION 3
+#define WM_ABI_VERSION 4
 
 /* error codes */
 #define WM_OK 0
@@ -621,6 +621,43 @@ int wm_lars_step(float* params, const float* grads, float* momentum_buf, const l
  * sites scripts/WM811k_benchmark.py:548-550, utilities via lightly MAEBackbone) as a fixed matrix product, and its
  * gradient. */
 int wm_matmul_f32(const float* a, const float* b, float* c, int M, int N, int K, int trans_a, void* stream);
+
+/* ---- Float32 "parity" preset (csrc/f32path.hip): the FORWARD pass of the SimCLR / DINO / MAE steps with every activation,
+ * weight and accumulator in float32 (reference call sites scripts/WM811k_benchmark.py:236-248, :578-588, :902-947).  The
+ * production kernels keep activations in bf16; profiles/r04_error_budget_bf16.md shows that storage puts the step losses
+ * 0.4e-4 .. 3.4e-4 from the float32 reference (north_star: 1e-4).  These entry points keep them in float32: a validation
+ * preset (forward only), selected by ssl_wafermap_amd.precision("float32").  Activations NHWC float32 / [rows][C]. */
+size_t wm_f32_conv2d_workspace_bytes(int C, int K, int R, int S);
+/* y = act(conv(x, w) + bias) + residual: x [N][H][W][C], w_oihw [K][C][R][S] (the float32 master layout), bias [K] or NULL,
+ * residual [N][P][Q][K] or NULL, act 0 none / 1 GELU (erf) / 2 ReLU.  A Linear layer is the 1x1 case on a 1x1 image. */
+int wm_f32_conv2d_fwd(const float* x, const float* w_oihw, const float* bias, const float* residual, float* y, int N, int H,
+                      int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, int act, void* workspace,
+                      size_t workspace_bytes, void* stream);
+size_t wm_f32_bn_workspace_bytes(long long rows, int C, int G);
+/* out = relu?(BN(y) (+ residual)) over G equal row groups with their own batch statistics (training != 0: running
+ * statistics and the batch counter are updated as by G consecutive nn.BatchNorm calls) or with the running statistics. */
+int wm_f32_bn_fwd(const float* y, const float* residual, const float* gamma, const float* beta, float* running_mean,
+                  float* running_var, long long* num_batches_tracked, long long rows, int C, int G, int training, float eps,
+                  float momentum, int relu, float* save_mean, float* save_invstd, float* out, void* workspace,
+                  size_t workspace_bytes, void* stream);
+int wm_f32_maxpool3x3s2(const float* x, int N, int H, int W, int C, float* y, void* stream);
+int wm_f32_gap(const float* x, int N, int HW, int C, float* y, void* stream);
+int wm_f32_layernorm(const float* x, const float* gamma, const float* beta, float eps, long long rows, int C, float* y,
+                     void* stream);
+/* y = act(x + bias) + residual, element-wise on [rows][C] (bias, residual optional). */
+int wm_f32_bias_act(const float* x, const float* bias, const float* residual, int act, long long rows, int C, float* y,
+                    void* stream);
+/* softmax(q k^T * scale) v per (image, head): qkv [B*S][3][H][HD] -> out [B*S][H*HD]; HD 64 or 32. */
+int wm_f32_attention(const float* qkv, int B, int S, int H, int HD, float scale, float* out, void* stream);
+/* rows of softmax((x - subtract) * inv_temp) (log_softmax != 0: its logarithm); subtract [D] or NULL. */
+int wm_f32_softmax_rows(const float* x, const float* subtract, float inv_temp, int log_softmax, long long rows, int D,
+                        float* y, void* stream);
+/* pair_loss[(t * SV + s) * B + b] = -sum_d probs[t][b][d] * logq[s][b][d], 0 where t == s (lightly DINOLoss's zeroed diagonal). */
+int wm_f32_pair_ce(const float* probs, const float* logq, int T, int SV, int B, int D, float* pair_loss, void* stream);
+/* *out = scale * sum_i f(a_i, b_i): mode 0 a_i, 1 (a_i - b_i)^2, 2 |a_i - b_i|; one ordered double-precision sum. */
+int wm_f32_reduce(const float* a, const float* b, long long n, int mode, double scale, float* out, void* stream);
+/* center = center * momentum + (1 - momentum) * column mean of teacher [rows][D]. */
+int wm_f32_center_update(float* center, const float* teacher, int rows, int D, float momentum, void* stream);
 
 /* Debugging probe (no reference counterpart): *slot = max(*slot, max_i |x[i]|), NaN if any x[i] is NaN
  * (+inf stays +inf).  x: n elements of WM_F32 / WM_BF16; *slot must hold a non-negative float (zero it

@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_float, c_int, c_int32, c_longlong, c_size_t, c_uint32, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int32, c_longlong, c_size_t, c_uint32, c_void_p
 from pathlib import Path
 
 _HERE = Path(__file__).resolve().parent
@@ -50,6 +50,21 @@ class WmViewParams(ctypes.Structure):
 
 # name -> (restype, argtypes); kept in one table so tests can check it against the header.
 SIGNATURES = {
+    "wm_f32_conv2d_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int]),
+    "wm_f32_conv2d_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int,
+                                  c_int, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "wm_f32_bn_workspace_bytes": (c_size_t, [c_longlong, c_int, c_int]),
+    "wm_f32_bn_fwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int,
+                              c_int, c_float, c_float, c_int, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wm_f32_maxpool3x3s2": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_f32_gap": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_f32_layernorm": (c_int, [c_void_p, c_void_p, c_void_p, c_float, c_longlong, c_int, c_void_p, c_void_p]),
+    "wm_f32_bias_act": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_longlong, c_int, c_void_p, c_void_p]),
+    "wm_f32_attention": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p]),
+    "wm_f32_softmax_rows": (c_int, [c_void_p, c_void_p, c_float, c_int, c_longlong, c_int, c_void_p, c_void_p]),
+    "wm_f32_pair_ce": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_f32_reduce": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_double, c_void_p, c_void_p]),
+    "wm_f32_center_update": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
     "wm_version": (c_int, []),
     "wm_error_string": (c_char_p, [c_int]),
     "wm_ln_linear_fwd_ok": (c_int, [c_int, c_int, c_int]),

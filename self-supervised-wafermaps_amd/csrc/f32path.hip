@@ -1,0 +1,561 @@
+// Float32 "parity" preset: the forward pass of the three models of the path with EVERY activation, weight and
+// accumulator in float32 (fmaf chains, double for the normalisation statistics).
+//
+// Why it exists (profiles/r04_error_budget_bf16.md): north_star asks the whole-step loss within 1e-4 relative and the
+// embeddings within 1e-3 cosine of the reference's float32 CPU path.  The production kernels keep activations and
+// MFMA operands in bf16 (2^-9 per stored value); the error budget shows that this storage -- not a kernel defect --
+// puts the SimCLR / DINO / MAE step losses 0.4e-4 .. 3.4e-4 from the float32 oracle, the same distance torch's own
+// bf16 autocast of the oracle code lands at (profiles/r04_bf16_gradient_noise.md).  This file is the preset that keeps
+// those activations in float32: same module tree, same state_dict, same call sites
+// (scripts/WM811k_benchmark.py:236-248 SimCLR, :578-588 DINOViT, :902-947 MAE), plain loops instead of MFMA tiles.
+// It is a validation preset (forward only, ~50x slower than the bf16 path), not a training path.
+//
+// Layouts: activations NHWC float32 ([rows][C] for token / feature matrices), weights in their float32 master layout
+// (OIHW / [K][C]); the implicit-GEMM kernel reads them through a [R*S*C][K] copy made per call.
+#include "common.h"
+#include <math.h>
+
+namespace {
+
+constexpr int FT = 256;
+
+__global__ __launch_bounds__(FT) void f32_weights_qk(const float* __restrict__ w, int K, int C, int RS, float* __restrict__ wt) {
+  const size_t total = (size_t)K * C * RS;
+  for (size_t i = (size_t)blockIdx.x * FT + threadIdx.x; i < total; i += (size_t)gridDim.x * FT) {
+    const int k = (int)(i % K);
+    const size_t q = i / K;
+    const int c = (int)(q % C), rs = (int)(q / C);
+    wt[i] = w[((size_t)k * C + c) * RS + rs];
+  }
+}
+
+__device__ __forceinline__ float f32_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
+
+struct F32Conv {
+  const float* x;    // [N][H][W][C]
+  const float* wt;   // [R*S*C][K]
+  const float* bias; // [K] or null
+  const float* res;  // [M][K] or null
+  float* y;          // [M][K], M = N*P*Q
+  int N, H, W, C, K, R, S, P, Q, stride, pad, act;
+};
+
+// Implicit GEMM, 64 x 64 output tile per block, 16-deep reduction steps over the flattened (r, s, c) index, 4 x 4
+// outputs per thread; the reduction runs in increasing (r, s, c) order as one fmaf chain per output.
+__global__ __launch_bounds__(FT) void f32_conv_fwd(const F32Conv a) {
+  __shared__ __attribute__((aligned(16))) float As[16][68];
+  __shared__ __attribute__((aligned(16))) float Bs[16][64];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const long long M = (long long)a.N * a.P * a.Q;
+  const long long m0 = (long long)blockIdx.x * 64;
+  const int n0 = blockIdx.y * 64;
+  const int Kd = a.R * a.S * a.C;
+  // A fetch: this thread's reduction slot and its four tile rows
+  const int ql = tid & 15;
+  long long rbase[4];
+  int rh[4], rw[4];
+  bool rv[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long m = m0 + (tid >> 4) + 16 * i;
+    rv[i] = m < M;
+    const long long mm = rv[i] ? m : 0;
+    const int n = (int)(mm / ((long long)a.P * a.Q));
+    const int pq = (int)(mm - (long long)n * a.P * a.Q);
+    const int p = pq / a.Q, q = pq - p * a.Q;
+    rh[i] = p * a.stride - a.pad;
+    rw[i] = q * a.stride - a.pad;
+    rbase[i] = (long long)n * a.H * a.W;
+  }
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < Kd; k0 += 16) {
+    const int qg = k0 + ql;
+    const bool qv = qg < Kd;
+    const int qq = qv ? qg : 0;
+    const int r = qq / (a.S * a.C);
+    const int rem = qq - r * a.S * a.C;
+    const int s = rem / a.C, c = rem - s * a.C;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int h = rh[i] + r, w = rw[i] + s;
+      float v = 0.f;
+      if (rv[i] && qv && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+        v = a.x[((rbase[i] + (long long)h * a.W + w) * a.C) + c];
+      As[ql][(tid >> 4) + 16 * i] = v;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int e = tid + i * FT;
+      const int col = e & 63, qr = e >> 6;
+      float v = 0.f;
+      if (k0 + qr < Kd && n0 + col < a.K) v = a.wt[(size_t)(k0 + qr) * a.K + n0 + col];
+      Bs[qr][col] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float4 av = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
+      const float4 bv = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
+      const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(aa[i], bb[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const long long m = m0 + ty * 4 + i;
+    if (m >= M) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int k = n0 + tx * 4 + j;
+      if (k >= a.K) continue;
+      float v = acc[i][j];
+      if (a.bias) v += a.bias[k];
+      if (a.act == 1) v = f32_gelu(v);
+      else if (a.act == 2) v = fmaxf(v, 0.f);
+      if (a.res) v += a.res[m * a.K + k];
+      a.y[m * a.K + k] = v;
+    }
+  }
+}
+
+// ---- BatchNorm: per (group, channel) sums in double over row slices, ordered finalize, element-wise apply
+__global__ __launch_bounds__(FT) void f32_colsums(const float* __restrict__ y, long long rpg, int C, int RB,
+                                                 double* __restrict__ part) {  // part [G][RB][2][C]
+  __shared__ double red[2][8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx, g = blockIdx.y, rb = blockIdx.z;
+  double s = 0.0, ss = 0.0;
+  if (c < C) {
+    for (long long r = (long long)rb * 8 + ty; r < rpg; r += (long long)RB * 8) {
+      const double v = (double)y[((long long)g * rpg + r) * C + c];
+      s += v;
+      ss += v * v;
+    }
+  }
+  red[0][ty][tx] = s;
+  red[1][ty][tx] = ss;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < 8; ++i) {
+      a += red[0][i][tx];
+      b += red[1][i][tx];
+    }
+    part[(((size_t)g * RB + rb) * 2 + 0) * C + c] = a;
+    part[(((size_t)g * RB + rb) * 2 + 1) * C + c] = b;
+  }
+}
+
+__global__ __launch_bounds__(FT) void f32_bn_finalize(const double* __restrict__ part, int RB, int G, int C, long long rpg,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta, float eps,
+                                                     float momentum, float* __restrict__ rmean, float* __restrict__ rvar,
+                                                     long long* __restrict__ counter, float* __restrict__ mean,
+                                                     float* __restrict__ invstd, float* __restrict__ scale,
+                                                     float* __restrict__ shift) {
+  const int c = blockIdx.x * FT + threadIdx.x;
+  if (counter != nullptr && c == 0) *counter += G;
+  if (c >= C) return;
+  float rm = rmean ? rmean[c] : 0.f, rv = rvar ? rvar[c] : 0.f;
+  for (int g = 0; g < G; ++g) {
+    double s = 0.0, ss = 0.0;
+    for (int rb = 0; rb < RB; ++rb) {
+      s += part[(((size_t)g * RB + rb) * 2 + 0) * C + c];
+      ss += part[(((size_t)g * RB + rb) * 2 + 1) * C + c];
+    }
+    const double m = s / (double)rpg;
+    double var = ss / (double)rpg - m * m;
+    if (var < 0.0) var = 0.0;
+    const float fm = (float)m, is = (float)(1.0 / sqrt(var + (double)eps));
+    mean[(size_t)g * C + c] = fm;
+    invstd[(size_t)g * C + c] = is;
+    const float sc = (gamma ? gamma[c] : 1.f) * is;
+    scale[(size_t)g * C + c] = sc;
+    shift[(size_t)g * C + c] = (beta ? beta[c] : 0.f) - fm * sc;
+    const double unb = rpg > 1 ? var * (double)rpg / (double)(rpg - 1) : var;
+    rm = (1.f - momentum) * rm + momentum * fm;
+    rv = (1.f - momentum) * rv + momentum * (float)unb;
+  }
+  if (rmean) rmean[c] = rm;
+  if (rvar) rvar[c] = rv;
+}
+
+__global__ __launch_bounds__(FT) void f32_bn_eval_coef(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ rmean, const float* __restrict__ rvar, int C,
+                                                      float eps, float* __restrict__ scale, float* __restrict__ shift) {
+  const int c = blockIdx.x * FT + threadIdx.x;
+  if (c >= C) return;
+  const float is = (float)(1.0 / sqrt((double)rvar[c] + (double)eps));
+  const float sc = (gamma ? gamma[c] : 1.f) * is;
+  scale[c] = sc;
+  shift[c] = (beta ? beta[c] : 0.f) - rmean[c] * sc;
+}
+
+__global__ __launch_bounds__(FT) void f32_affine_rows(const float* __restrict__ y, const float* __restrict__ res,
+                                                     const float* __restrict__ scale, const float* __restrict__ shift,
+                                                     long long rows, int C, long long rpg, int relu, float* __restrict__ out) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * FT + threadIdx.x; i < total; i += (long long)gridDim.x * FT) {
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    const int g = (int)(r / rpg);
+    float v = fmaf(y[i], scale[(size_t)g * C + c], shift[(size_t)g * C + c]);
+    if (res) v += res[i];
+    if (relu) v = fmaxf(v, 0.f);
+    out[i] = v;
+  }
+}
+
+__global__ __launch_bounds__(FT) void f32_maxpool3x3s2(const float* __restrict__ x, int N, int H, int W, int C, int P, int Q,
+                                                      float* __restrict__ y) {
+  const long long total = (long long)N * P * Q * C;
+  for (long long i = (long long)blockIdx.x * FT + threadIdx.x; i < total; i += (long long)gridDim.x * FT) {
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int q = (int)(t % Q);
+    t /= Q;
+    const int p = (int)(t % P), n = (int)(t / P);
+    float m = -INFINITY;
+    for (int r = 0; r < 3; ++r)
+      for (int s = 0; s < 3; ++s) {
+        const int h = 2 * p - 1 + r, w = 2 * q - 1 + s;
+        if ((unsigned)h < (unsigned)H && (unsigned)w < (unsigned)W) m = fmaxf(m, x[(((long long)n * H + h) * W + w) * C + c]);
+      }
+    y[i] = m;
+  }
+}
+
+__global__ __launch_bounds__(FT) void f32_gap(const float* __restrict__ x, int N, int HW, int C, float* __restrict__ y) {
+  const int i = blockIdx.x * FT + threadIdx.x;
+  if (i >= N * C) return;
+  const int n = i / C, c = i - n * C;
+  double s = 0.0;
+  for (int p = 0; p < HW; ++p) s += (double)x[((long long)n * HW + p) * C + c];
+  y[i] = (float)(s / (double)HW);
+}
+
+// one wave per row: mean, biased variance (double), normalise
+__global__ __launch_bounds__(64) void f32_layernorm(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                   const float* __restrict__ beta, float eps, int C, float* __restrict__ y) {
+  const long long row = blockIdx.x;
+  const float* xr = x + row * C;
+  double s = 0.0;
+  for (int c = threadIdx.x; c < C; c += 64) s += (double)xr[c];
+  for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+  const double mean = s / C;
+  double q = 0.0;
+  for (int c = threadIdx.x; c < C; c += 64) {
+    const double d = (double)xr[c] - mean;
+    q += d * d;
+  }
+  for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+  const float rstd = (float)(1.0 / sqrt(q / C + (double)eps)), fm = (float)mean;
+  for (int c = threadIdx.x; c < C; c += 64) y[row * C + c] = (xr[c] - fm) * rstd * gamma[c] + beta[c];
+}
+
+__global__ __launch_bounds__(FT) void f32_bias_act(const float* __restrict__ x, const float* __restrict__ bias,
+                                                  const float* __restrict__ res, int act, long long rows, int C,
+                                                  float* __restrict__ y) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * FT + threadIdx.x; i < total; i += (long long)gridDim.x * FT) {
+    float v = x[i];
+    if (bias) v += bias[i % C];
+    if (act == 1) v = f32_gelu(v);
+    else if (act == 2) v = fmaxf(v, 0.f);
+    if (res) v += res[i];
+    y[i] = v;
+  }
+}
+
+// Attention of one (image, head): K and V of the head in LDS, one query per thread (strided), softmax in two passes
+// over the keys (maximum, then exponentials) exactly as torch's softmax does.  qkv [B*S][3][H][HD], out [B*S][H*HD].
+template <int HD>
+__global__ __launch_bounds__(FT) void f32_attention(const float* __restrict__ qkv, int S, int H, float scale,
+                                                   float* __restrict__ out) {
+  extern __shared__ __attribute__((aligned(16))) float f32_smem[];
+  float* ks = f32_smem;
+  float* vs = f32_smem + (size_t)S * HD;
+  const int b = blockIdx.x / H, h = blockIdx.x - b * H;
+  const size_t rs = (size_t)3 * H * HD;
+  for (int i = threadIdx.x; i < S * HD; i += FT) {
+    const int j = i / HD, d = i - j * HD;
+    const float* base = qkv + ((size_t)b * S + j) * rs + (size_t)h * HD + d;
+    ks[i] = base[(size_t)H * HD];
+    vs[i] = base[(size_t)2 * H * HD];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < S; i += FT) {
+    float q[HD], o[HD];
+    const float* qp = qkv + ((size_t)b * S + i) * rs + (size_t)h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) {
+      q[d] = qp[d];
+      o[d] = 0.f;
+    }
+    float mx = -INFINITY;
+    for (int j = 0; j < S; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) s = fmaf(q[d], ks[j * HD + d], s);
+      mx = fmaxf(mx, s * scale);
+    }
+    float l = 0.f;
+    for (int j = 0; j < S; ++j) {
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) s = fmaf(q[d], ks[j * HD + d], s);
+      const float p = expf(s * scale - mx);
+      l += p;
+#pragma unroll
+      for (int d = 0; d < HD; ++d) o[d] = fmaf(p, vs[j * HD + d], o[d]);
+    }
+    const float inv = 1.f / l;
+    float* op = out + ((size_t)b * S + i) * ((size_t)H * HD) + (size_t)h * HD;
+#pragma unroll
+    for (int d = 0; d < HD; ++d) op[d] = o[d] * inv;
+  }
+}
+
+// rows of softmax((x - sub) * inv_temp) or its logarithm; one block per row
+__global__ __launch_bounds__(FT) void f32_softmax_rows(const float* __restrict__ x, const float* __restrict__ sub, float inv_temp,
+                                                      int logp, int D, float* __restrict__ y) {
+  __shared__ float red[FT];
+  const long long row = blockIdx.x;
+  const float* xr = x + row * D;
+  float m = -INFINITY;
+  for (int d = threadIdx.x; d < D; d += FT) m = fmaxf(m, (xr[d] - (sub ? sub[d] : 0.f)) * inv_temp);
+  red[threadIdx.x] = m;
+  __syncthreads();
+  for (int o = FT / 2; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] = fmaxf(red[threadIdx.x], red[threadIdx.x + o]);
+    __syncthreads();
+  }
+  m = red[0];
+  __syncthreads();
+  float s = 0.f;
+  for (int d = threadIdx.x; d < D; d += FT) s += expf((xr[d] - (sub ? sub[d] : 0.f)) * inv_temp - m);
+  red[threadIdx.x] = s;
+  __syncthreads();
+  for (int o = FT / 2; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  s = red[0];
+  const float ls = logf(s);
+  for (int d = threadIdx.x; d < D; d += FT) {
+    const float z = (xr[d] - (sub ? sub[d] : 0.f)) * inv_temp - m;
+    y[row * D + d] = logp ? z - ls : expf(z) / s;
+  }
+}
+
+// out[i] = -sum_d p[rows_p(i)][d] * lq[rows_q(i)][d] for the pair list of the DINO / soft cross-entropy losses:
+// pair i = (t, s, b), t < T teacher views, s < SV student views, 0 on the diagonal t == s.  One block per pair.
+__global__ __launch_bounds__(FT) void f32_pair_ce(const float* __restrict__ p, const float* __restrict__ lq, int T, int SV, int B,
+                                                 int D, float* __restrict__ out) {
+  __shared__ double red[FT];
+  const int i = blockIdx.x;
+  const int b = i % B, s = (i / B) % SV, t = i / (B * SV);
+  double acc = 0.0;
+  if (t != s) {
+    const float* pr = p + ((size_t)t * B + b) * D;
+    const float* qr = lq + ((size_t)s * B + b) * D;
+    for (int d = threadIdx.x; d < D; d += FT) acc += (double)pr[d] * (double)qr[d];
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = FT / 2; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[i] = (float)(-red[0]);
+}
+
+// *out = scale * sum_i f(a[i], b[i]): mode 0 a[i] (b unused), 1 (a - b)^2, 2 |a - b|; one block, ordered, double
+__global__ __launch_bounds__(1024) void f32_reduce(const float* __restrict__ a, const float* __restrict__ b, long long n, int mode,
+                                                  double scale, float* __restrict__ out) {
+  __shared__ double red[1024];
+  double acc = 0.0;
+  for (long long i = threadIdx.x; i < n; i += 1024) {
+    const double x = (double)a[i];
+    if (mode == 0) acc += x;
+    else {
+      const double d = x - (double)b[i];
+      acc += mode == 1 ? d * d : fabs(d);
+    }
+  }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int o = 512; o >= 1; o >>= 1) {
+    if ((int)threadIdx.x < o) red[threadIdx.x] += red[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = (float)(red[0] * scale);
+}
+
+// center = center * momentum + (1 - momentum) * column mean of t [rows][D]
+__global__ __launch_bounds__(FT) void f32_center_update(float* __restrict__ center, const float* __restrict__ t, int rows, int D,
+                                                       float momentum) {
+  const int d = blockIdx.x * FT + threadIdx.x;
+  if (d >= D) return;
+  double s = 0.0;
+  for (int r = 0; r < rows; ++r) s += (double)t[(size_t)r * D + d];
+  center[d] = center[d] * momentum + (1.f - momentum) * (float)(s / rows);
+}
+
+inline int grid_for(long long items) {
+  long long b = (items + FT - 1) / FT;
+  if (b > 65535) b = 65535;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+
+}  // namespace
+
+extern "C" size_t wm_f32_conv2d_workspace_bytes(int C, int K, int R, int S) {
+  if (C <= 0 || K <= 0 || R <= 0 || S <= 0) return 0;
+  return (size_t)R * S * C * K * sizeof(float);
+}
+
+extern "C" int wm_f32_conv2d_fwd(const float* x, const float* w_oihw, const float* bias, const float* residual, float* y, int N,
+                                 int H, int W, int C, int K, int R, int S, int P, int Q, int stride, int pad, int act,
+                                 void* workspace, size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(x && w_oihw && y && workspace, WM_EINVAL);
+  WM_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0, WM_EINVAL);
+  WM_REQUIRE(P == (H + 2 * pad - R) / stride + 1 && Q == (W + 2 * pad - S) / stride + 1 && P > 0 && Q > 0, WM_EINVAL);
+  WM_REQUIRE(act >= 0 && act <= 2, WM_EINVAL);
+  WM_REQUIRE(workspace_bytes >= wm_f32_conv2d_workspace_bytes(C, K, R, S), WM_EWORKSPACE);
+  const long long M = (long long)N * P * Q;
+  WM_REQUIRE((M + 63) / 64 < (1ll << 31) && (long long)R * S * C < (1ll << 31), WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* wt = static_cast<float*>(workspace);
+  f32_weights_qk<<<grid_for((long long)K * C * R * S), FT, 0, st>>>(w_oihw, K, C, R * S, wt);
+  WM_LAUNCH_CHECK();
+  F32Conv a{x, wt, bias, residual, y, N, H, W, C, K, R, S, P, Q, stride, pad, act};
+  f32_conv_fwd<<<dim3((unsigned)((M + 63) / 64), (unsigned)((K + 63) / 64)), FT, 0, st>>>(a);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" size_t wm_f32_bn_workspace_bytes(long long rows, int C, int G) {
+  if (rows <= 0 || C <= 0 || G <= 0) return 0;
+  const int RB = 64;
+  return ((size_t)G * RB * 2 * C) * sizeof(double) + (size_t)2 * G * C * sizeof(float) + 64;
+}
+
+extern "C" int wm_f32_bn_fwd(const float* y, const float* residual, const float* gamma, const float* beta, float* running_mean,
+                             float* running_var, long long* num_batches_tracked, long long rows, int C, int G, int training,
+                             float eps, float momentum, int relu, float* save_mean, float* save_invstd, float* out,
+                             void* workspace, size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(y && out && workspace, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && C > 0 && G > 0 && rows % G == 0, WM_EINVAL);
+  WM_REQUIRE(workspace_bytes >= wm_f32_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int RB = 64;
+  double* part = static_cast<double*>(workspace);
+  float* scale = reinterpret_cast<float*>(part + (size_t)G * RB * 2 * C);
+  float* shift = scale + (size_t)G * C;
+  const long long rpg = rows / G;
+  if (training) {
+    WM_REQUIRE(save_mean && save_invstd, WM_EINVAL);
+    f32_colsums<<<dim3((C + 31) / 32, G, RB), FT, 0, st>>>(y, rpg, C, RB, part);
+    WM_LAUNCH_CHECK();
+    f32_bn_finalize<<<(C + FT - 1) / FT, FT, 0, st>>>(part, RB, G, C, rpg, gamma, beta, eps, momentum, running_mean, running_var,
+                                                     num_batches_tracked, save_mean, save_invstd, scale, shift);
+    WM_LAUNCH_CHECK();
+    f32_affine_rows<<<grid_for(rows * C), FT, 0, st>>>(y, residual, scale, shift, rows, C, rpg, relu, out);
+  } else {
+    WM_REQUIRE(running_mean && running_var, WM_EINVAL);
+    f32_bn_eval_coef<<<(C + FT - 1) / FT, FT, 0, st>>>(gamma, beta, running_mean, running_var, C, eps, scale, shift);
+    WM_LAUNCH_CHECK();
+    f32_affine_rows<<<grid_for(rows * C), FT, 0, st>>>(y, residual, scale, shift, rows, C, rows, relu, out);
+  }
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_maxpool3x3s2(const float* x, int N, int H, int W, int C, float* y, void* stream) {
+  WM_REQUIRE(x && y && N > 0 && H > 0 && W > 0 && C > 0, WM_EINVAL);
+  const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1;
+  f32_maxpool3x3s2<<<grid_for((long long)N * P * Q * C), FT, 0, static_cast<hipStream_t>(stream)>>>(x, N, H, W, C, P, Q, y);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_gap(const float* x, int N, int HW, int C, float* y, void* stream) {
+  WM_REQUIRE(x && y && N > 0 && HW > 0 && C > 0, WM_EINVAL);
+  f32_gap<<<(N * C + FT - 1) / FT, FT, 0, static_cast<hipStream_t>(stream)>>>(x, N, HW, C, y);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_layernorm(const float* x, const float* gamma, const float* beta, float eps, long long rows, int C, float* y,
+                                void* stream) {
+  WM_REQUIRE(x && gamma && beta && y && rows > 0 && rows < (1ll << 31) && C > 0, WM_EINVAL);
+  f32_layernorm<<<(unsigned)rows, 64, 0, static_cast<hipStream_t>(stream)>>>(x, gamma, beta, eps, C, y);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_bias_act(const float* x, const float* bias, const float* residual, int act, long long rows, int C, float* y,
+                               void* stream) {
+  WM_REQUIRE(x && y && rows > 0 && C > 0 && act >= 0 && act <= 2, WM_EINVAL);
+  f32_bias_act<<<grid_for(rows * C), FT, 0, static_cast<hipStream_t>(stream)>>>(x, bias, residual, act, rows, C, y);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_attention(const float* qkv, int B, int S, int H, int HD, float scale, float* out, void* stream) {
+  WM_REQUIRE(qkv && out && B > 0 && S > 0 && H > 0, WM_EINVAL);
+  WM_REQUIRE(HD == 64 || HD == 32, WM_EUNSUPPORTED);
+  const size_t lds = (size_t)2 * S * HD * sizeof(float);
+  WM_REQUIRE(lds <= 160 * 1024, WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  hipError_t e;
+  if (HD == 64) {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&f32_attention<64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    f32_attention<64><<<B * H, FT, lds, st>>>(qkv, S, H, scale, out);
+  } else {
+    e = hipFuncSetAttribute(reinterpret_cast<const void*>(&f32_attention<32>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    f32_attention<32><<<B * H, FT, lds, st>>>(qkv, S, H, scale, out);
+  }
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_softmax_rows(const float* x, const float* subtract, float inv_temp, int log_softmax, long long rows, int D,
+                                   float* y, void* stream) {
+  WM_REQUIRE(x && y && rows > 0 && rows < (1ll << 31) && D > 0, WM_EINVAL);
+  f32_softmax_rows<<<(unsigned)rows, FT, 0, static_cast<hipStream_t>(stream)>>>(x, subtract, inv_temp, log_softmax, D, y);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_pair_ce(const float* probs, const float* logq, int T, int SV, int B, int D, float* pair_loss, void* stream) {
+  WM_REQUIRE(probs && logq && pair_loss && T > 0 && SV > 0 && B > 0 && D > 0, WM_EINVAL);
+  f32_pair_ce<<<T * SV * B, FT, 0, static_cast<hipStream_t>(stream)>>>(probs, logq, T, SV, B, D, pair_loss);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_reduce(const float* a, const float* b, long long n, int mode, double scale, float* out, void* stream) {
+  WM_REQUIRE(a && out && n > 0 && mode >= 0 && mode <= 2 && (mode == 0 || b), WM_EINVAL);
+  f32_reduce<<<1, 1024, 0, static_cast<hipStream_t>(stream)>>>(a, b, n, mode, scale, out);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_center_update(float* center, const float* teacher, int rows, int D, float momentum, void* stream) {
+  WM_REQUIRE(center && teacher && rows > 0 && D > 0, WM_EINVAL);
+  f32_center_update<<<(D + FT - 1) / FT, FT, 0, static_cast<hipStream_t>(stream)>>>(center, teacher, rows, D, momentum);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}

@@ -20,7 +20,7 @@ import torch
 import torch.nn as nn
 
 from .. import nn as hnn
-from .. import optim, vit_ops
+from .. import ops, optim, vit_ops
 from ..utils import debug, model_utils, scheduler
 from .knn import KNNBenchmarkModule
 from .vit import _PatchConv
@@ -156,7 +156,7 @@ class MAEBackbone(nn.Module):
     def encode_tokens(self, tokens, batch: int):
         """lightly MAEEncoder.forward(tokens): + positional embedding, encoder blocks, final LayerNorm."""
         seq, c = self.seq_length, self.hidden_dim
-        pos = self.encoder.pos_embedding.to(torch.bfloat16).expand(batch, seq, c).reshape(batch * seq, c)
+        pos = self.encoder.pos_embedding.to(ops.act_dtype()).expand(batch, seq, c).reshape(batch * seq, c)
         t = vit_ops.bias_act(tokens.reshape(batch * seq, c), None, vit_ops.ACT_NONE, residual=pos)
         return self.encoder.run_layers(t, batch, seq).view(batch, seq, c)
 
@@ -199,7 +199,7 @@ class MAEDecoder(nn.Module):
 
     def decode(self, x):
         b, s, c = x.shape
-        pos = self.pos_embedding.to(torch.bfloat16).expand(b, s, c).reshape(b * s, c)
+        pos = self.pos_embedding.to(ops.act_dtype()).expand(b, s, c).reshape(b * s, c)
         t = vit_ops.bias_act(x.reshape(b * s, c), None, vit_ops.ACT_NONE, residual=pos)
         for blk in self.layers:
             t = blk(t, b, s)
@@ -251,7 +251,7 @@ class MAE(KNNBenchmarkModule):
     def forward_decoder(self, x_encoded, idx_keep, idx_mask):
         batch_size = x_encoded.shape[0]
         x_decode = self.decoder.embed(x_encoded)
-        x_masked = model_utils.repeat_token(self.mask_token.to(torch.bfloat16), (batch_size, self.sequence_length))
+        x_masked = model_utils.repeat_token(self.mask_token.to(ops.act_dtype()), (batch_size, self.sequence_length))
         x_masked = model_utils.set_at_index(x_masked, idx_keep, x_decode)
         x_decoded = self.decoder.decode(x_masked)
         x_pred = model_utils.get_at_index(x_decoded, idx_mask)

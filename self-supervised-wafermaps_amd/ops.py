@@ -13,7 +13,8 @@ from typing import Optional
 
 import torch
 
-from . import _lib
+from . import _lib, f32path
+from . import precision as _precision
 from ._lib import check, ptr, stream_ptr
 
 _WEIGHT_EPOCH = 0  # bumped by optimisers that update parameters through raw pointers
@@ -114,8 +115,16 @@ def _need_cuda(t: torch.Tensor, what: str) -> None:
         raise _lib.WaferHipError(f"{what}: the HIP path needs a device tensor (no CPU fallback)")
 
 
+def act_dtype() -> torch.dtype:
+    """Storage dtype of activations under the current precision preset (precision.py)."""
+    return torch.float32 if _precision.is_f32() else torch.bfloat16
+
+
 def to_nhwc_bf16(x: torch.Tensor) -> torch.Tensor:
-    """[N,C,H,W] any float dtype/layout -> bf16 channels_last (no copy when already so)."""
+    """[N,C,H,W] any float dtype/layout -> bf16 channels_last (no copy when already so); under the float32 preset the
+    activation dtype is float32."""
+    if _precision.is_f32():
+        return f32path.as_nhwc(x)
     if x.dim() != 4:
         raise ValueError("expected a 4-D [N,C,H,W] tensor")
     if x.dtype != torch.bfloat16:
@@ -592,6 +601,8 @@ def conv2d(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, padding: int 
     """bias-free conv2d; x bf16 NHWC (converted if not), weight float32 [K, C, R, S].
     `stats`: a StatSlots object into whose per-tile slots the epilogue stores the BatchNorm statistics of the output
     (used when `stats_fusable(rows, groups)`)."""
+    if _precision.is_f32():
+        return f32path.conv2d(x, weight, int(stride), int(padding))
     return _Conv2d.apply(x, weight, int(stride), int(padding), stats, int(groups), False, getattr(x, "_hip_bn", None))
 
 
@@ -600,6 +611,8 @@ def conv2d_passthrough(x: torch.Tensor, weight: torch.Tensor, stride: int = 1, p
     """conv2d that also hands back its input as a second (identity) output: use that output for the
     residual path of a block, and the gradient of the shortcut is added inside the dgrad kernel's
     epilogue (wm_conv2d_dgrad_add) instead of by a separate elementwise kernel."""
+    if _precision.is_f32():
+        return f32path.conv2d(x, weight, int(stride), int(padding)), x
     return _Conv2d.apply(x, weight, int(stride), int(padding), stats, int(groups), True, getattr(x, "_hip_bn", None))
 
 
@@ -664,6 +677,11 @@ class _StemConv(torch.autograd.Function):
 
 
 def stem_conv(x: torch.Tensor, weight: torch.Tensor, stats: Optional[torch.Tensor] = None, groups: int = 1) -> torch.Tensor:
+    if _precision.is_f32():
+        if x.shape[1] != 3:
+            raise ValueError("stem_conv (float32 preset): give [N,3,H,W] images (augment_views fmt \"nchw_f32\"), not the "
+                             "space-to-depth bf16 layout")
+        return f32path.conv2d(x, weight, 2, 3)
     return _StemConv.apply(x, weight, stats, int(groups))
 
 
@@ -805,6 +823,9 @@ def batch_norm(y, gamma, beta, running_mean, running_var, training: bool, residu
     same kind; when given (training, ReLU, 4-D), the output carries a BnLink and the convolution that consumes it runs
     this BatchNorm's backward reduction in its dgrad epilogue."""
     g = current_bn_groups() if groups is None else groups
+    if _precision.is_f32():
+        return f32path.batch_norm(y, gamma, beta, running_mean, running_var, bool(training), residual, bool(relu), eps, momentum,
+                                  int(g), num_batches_tracked)
     out = _BatchNorm.apply(y, residual, gamma, beta, running_mean, running_var, bool(training), int(g), float(eps),
                            float(momentum), bool(relu), stats, num_batches_tracked, bwd_stats)
     link = getattr(out.grad_fn, "link", None) if out.grad_fn is not None else None
@@ -893,6 +914,8 @@ def sync_batch_norm(y, gamma, beta, running_mean, running_var, residual=None, re
                     process_group=None):
     """Training-mode BatchNorm with statistics over all ranks of `process_group` (see _SyncBatchNorm)."""
     g = current_bn_groups() if groups is None else groups
+    if _precision.is_f32():
+        raise NotImplementedError("sync_batch_norm: not part of the float32 (parity) preset")
     return _SyncBatchNorm.apply(y, residual, gamma, beta, running_mean, running_var, int(g), float(eps), float(momentum),
                                 bool(relu), stats, num_batches_tracked, process_group)
 
@@ -969,6 +992,9 @@ def bn_relu_maxpool(y, gamma, beta, running_mean, running_var, training: bool, e
                     momentum: float = 0.1, groups: Optional[int] = None, stats=None, num_batches_tracked=None):
     """max_pool3x3s2(relu(batch_norm(y))) in one pass over y (ResNet stem)."""
     g = current_bn_groups() if groups is None else groups
+    if _precision.is_f32():
+        return f32path.max_pool3x3s2(f32path.batch_norm(y, gamma, beta, running_mean, running_var, bool(training), None, True, eps,
+                                                         momentum, int(g), num_batches_tracked))
     return _BnReluMaxPool.apply(y, gamma, beta, running_mean, running_var, bool(training), int(g), float(eps),
                                 float(momentum), stats, num_batches_tracked)
 
@@ -1001,6 +1027,8 @@ class _MaxPool(torch.autograd.Function):
 
 def max_pool3x3s2(x: torch.Tensor) -> torch.Tensor:
     """nn.MaxPool2d(kernel_size=3, stride=2, padding=1)."""
+    if _precision.is_f32():
+        return f32path.max_pool3x3s2(x)
     return _MaxPool.apply(x)
 
 
@@ -1026,6 +1054,8 @@ class _GlobalAvgPool(torch.autograd.Function):
 
 def global_avg_pool(x: torch.Tensor) -> torch.Tensor:
     """[N,C,H,W] -> [N,C] (mean over H*W), bf16."""
+    if _precision.is_f32():
+        return f32path.global_avg_pool(x)
     return _GlobalAvgPool.apply(x)
 
 
@@ -1071,4 +1101,6 @@ class _Linear(torch.autograd.Function):
 
 def linear(x: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """Bias-free nn.Linear: x bf16 [B, C], weight float32 [K, C] -> bf16 [B, K]."""
+    if _precision.is_f32():
+        return f32path.linear(x, weight)
     return _Linear.apply(x, weight)

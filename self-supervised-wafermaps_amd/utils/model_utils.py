@@ -122,6 +122,12 @@ def patchify(images: torch.Tensor, patch_size: int) -> torch.Tensor:
     n, c, h, w = images.shape
     if c != 3 or h != w or h % patch_size:
         raise ValueError(f"patchify: unsupported shape {tuple(images.shape)} for patch {patch_size}")
+    from .. import precision
+
+    if precision.is_f32():   # float32 preset: pure data movement (lightly's einsum "nchpwq->nhwpqc")
+        g = h // patch_size
+        x = images.detach().float().reshape(n, c, g, patch_size, g, patch_size)
+        return x.permute(0, 2, 4, 3, 5, 1).reshape(n, g * g, patch_size * patch_size * c).contiguous()
     x = ops._as_nhwc(images)
     g = h // patch_size
     rows = torch.empty((n * g * g, patch_size * patch_size * 3), dtype=torch.bfloat16, device=x.device)

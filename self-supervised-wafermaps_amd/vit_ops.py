@@ -13,7 +13,8 @@ from typing import Optional
 
 import torch
 
-from . import _lib, ops
+from . import _lib, f32path, ops
+from . import precision as _precision
 from ._lib import check, ptr, stream_ptr
 from .ops import _arena_grad, _need_cuda
 
@@ -127,6 +128,8 @@ class _LayerNorm(torch.autograd.Function):
 
 def layer_norm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6) -> torch.Tensor:
     """nn.LayerNorm over the last dim of bf16 [rows, C]."""
+    if _precision.is_f32():
+        return f32path.layer_norm(x, gamma, beta, eps)
     return _LayerNorm.apply(x, gamma, beta, float(eps))
 
 
@@ -164,6 +167,8 @@ class _LayerNormSkip(torch.autograd.Function):
 
 def layer_norm_skip(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-6):
     """(LayerNorm(x), x) for a pre-norm residual block; use the second value as the residual operand."""
+    if _precision.is_f32():
+        return f32path.layer_norm(x, gamma, beta, eps), x
     return _LayerNormSkip.apply(x, gamma, beta, float(eps))
 
 
@@ -221,6 +226,8 @@ class _BiasAct(torch.autograd.Function):
 
 def bias_act(x: torch.Tensor, bias: Optional[torch.Tensor], act: int = ACT_NONE,
              residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    if _precision.is_f32():
+        return f32path.bias_act(x, bias, int(act), residual)
     return _BiasAct.apply(x, bias, residual, int(act))
 
 
@@ -276,6 +283,8 @@ class _LinearBias(torch.autograd.Function):
 def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None, act: int = ACT_NONE,
            residual: Optional[torch.Tensor] = None) -> torch.Tensor:
     """act(x @ W^T + bias) (+ residual) on bf16 [rows, C]: the GEMM kernel, then one epilogue pass."""
+    if _precision.is_f32():
+        return f32path.linear(x, weight, bias, int(act), residual)
     if act == ACT_NONE and (bias is not None or residual is not None):
         return _LinearBias.apply(x, weight, bias, residual)
     y = ops.linear(x, weight)
@@ -381,6 +390,9 @@ def mlp_gelu(x: torch.Tensor, fc1_weight: torch.Tensor, fc1_bias: torch.Tensor, 
     When no gradient is being recorded (DINO teacher, validation, embedding inference) and the shape is served
     (wm_mlp_fused_fwd_ok: C = 192, ViT-Tiny), the whole block is ONE launch with the hidden activation kept in LDS
     (wm_mlp_fused_fwd) -- bit-identical to the two-launch path."""
+    if _precision.is_f32():
+        h = f32path.linear(x, fc1_weight, fc1_bias, ACT_GELU)
+        return f32path.linear(h, fc2_weight, fc2_bias, ACT_NONE, residual)
     needs_grad = torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in
                                                  (x, fc1_weight, fc1_bias, fc2_weight, fc2_bias, residual))
     if not needs_grad and os.environ.get("WM_MLP_FUSED", "1") != "0":
@@ -408,6 +420,8 @@ def ln_linear(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: torch.Tensor, e
     """Linear(LayerNorm(x)) as ONE launch (wm_ln_linear_fwd: the normalised rows exist only as register fragments), for
     passes that record no gradient and shapes the kernel serves (192-wide rows: ViT-Tiny's norm1 -> qkv).  Returns None
     when it does not apply: the caller runs the two launches."""
+    if _precision.is_f32():
+        return None
     if os.environ.get("WM_LN_FUSED", "1") == "0" or not _no_grad_for(x, ln_weight, ln_bias, weight, bias):
         return None
     if not (x.is_cuda and x.dim() == 2):
@@ -430,6 +444,8 @@ def ln_mlp_gelu(x: torch.Tensor, ln_weight: torch.Tensor, ln_bias: torch.Tensor,
                 fc1_bias: torch.Tensor, fc2_weight: torch.Tensor, fc2_bias: torch.Tensor):
     """x + fc2(gelu(fc1(LayerNorm(x)))): the second half of a pre-norm block as ONE launch (wm_ln_mlp_fused_fwd), under the
     same conditions as ln_linear; None when it does not apply."""
+    if _precision.is_f32():
+        return None
     if os.environ.get("WM_LN_FUSED", "1") == "0" or os.environ.get("WM_MLP_FUSED", "1") == "0":
         return None
     if not _no_grad_for(x, ln_weight, ln_bias, fc1_weight, fc1_bias, fc2_weight, fc2_bias) or not (x.is_cuda and x.dim() == 2):
@@ -479,6 +495,8 @@ def attention(qkv: torch.Tensor, batch: int, seq: int, heads: int, scale: Option
               head_dim: int = 64) -> torch.Tensor:
     """softmax(scale q k^T) v per head; qkv bf16 [B*S, 3*H*hd] as the qkv Linear emits it -> [B*S, H*hd]
     (head_dim 64: ViT-S/16, ViT-B/32; 32: the MAE decoder's 512 / 16)."""
+    if _precision.is_f32():
+        return f32path.attention(qkv, int(batch), int(seq), int(heads), scale, int(head_dim))
     return _Attention.apply(qkv, int(batch), int(seq), int(heads), int(head_dim),
                             float(head_dim ** -0.5 if scale is None else scale))
 
@@ -528,6 +546,8 @@ class _AttentionSegments(torch.autograd.Function):
 def attention_segments(qkv: torch.Tensor, segments, heads: int, scale: Optional[float] = None,
                        head_dim: int = 64) -> torch.Tensor:
     """attention() over row-concatenated segments [(batch, seq), ...] of one qkv tensor."""
+    if _precision.is_f32():
+        return f32path.attention_segments(qkv, segments, int(heads), scale, int(head_dim))
     segments = [(int(b), int(s)) for b, s in segments]
     if len(segments) == 1:
         return attention(qkv, segments[0][0], segments[0][1], heads, scale, head_dim)
@@ -583,6 +603,8 @@ class _PatchEmbed(torch.autograd.Function):
 
 def patch_embed(images: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     """images [N,3,S,S] (bf16 channels_last) x weight [D,3,p,p] -> bf16 [N*(S/p)^2, D] (no bias)."""
+    if _precision.is_f32():
+        return f32path.patch_embed(images, weight)
     return _PatchEmbed.apply(images, weight)
 
 
@@ -626,6 +648,8 @@ class _TokensAssemble(torch.autograd.Function):
 
 def tokens_assemble(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, n: int, np_: int) -> torch.Tensor:
     """[cls + pos[0]; patches + pos[1:]] per image: bf16 [N*np, D] -> [N*(np+1), D]."""
+    if _precision.is_f32():
+        return f32path.tokens_assemble(patches, cls, pos, int(n), int(np_))
     return _TokensAssemble.apply(patches, cls, pos, int(n), int(np_))
 
 
@@ -655,6 +679,8 @@ class _GatherRows(torch.autograd.Function):
 
 def gather_rows(x: torch.Tensor, idx: torch.Tensor, batch: int, seq: int) -> torch.Tensor:
     """lightly get_at_index: x bf16 [B*S, C], idx int64 [B, K] (distinct per row) -> [B*K, C]."""
+    if _precision.is_f32():
+        return f32path.gather_rows(x, idx, int(batch), int(seq))
     return _GatherRows.apply(x, idx, int(batch), int(seq))
 
 
@@ -688,6 +714,8 @@ class _ScatterRows(torch.autograd.Function):
 
 def scatter_rows(base: torch.Tensor, src: torch.Tensor, idx: torch.Tensor, batch: int, seq: int) -> torch.Tensor:
     """lightly set_at_index: copy of base [B*S, C] with rows idx [B, K] replaced by src [B*K, C]."""
+    if _precision.is_f32():
+        return f32path.scatter_rows(base, src, idx, int(batch), int(seq))
     return _ScatterRows.apply(base, src, idx, int(batch), int(seq))
 
 
@@ -715,11 +743,15 @@ class _MSE(torch.autograd.Function):
 
 def mse_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """nn.MSELoss() (mean) on bf16 tensors; the gradient is produced in the same pass."""
+    if _precision.is_f32():
+        return f32path.mse_loss(pred, target)
     return _MSE.apply(pred, target, False)
 
 
 def l1_loss(pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
     """nn.L1Loss() (mean) on bf16 tensors."""
+    if _precision.is_f32():
+        return f32path.l1_loss(pred, target)
     return _MSE.apply(pred, target, True)
 
 
@@ -752,6 +784,8 @@ class _DinoLoss(torch.autograd.Function):
 
 def dino_teacher_probs(teacher: torch.Tensor, center: torch.Tensor, temp: float) -> torch.Tensor:
     """softmax((teacher - center) / temp) per row: bf16 [rows, D] -> float32 [rows, D] (no gradient)."""
+    if _precision.is_f32():
+        return f32path.softmax_rows(teacher.detach(), center, 1.0 / float(temp))
     _need_cuda(teacher, "dino_teacher_probs")
     teacher = _bf16_rows(teacher.detach())
     rows, d = teacher.shape
@@ -764,11 +798,15 @@ def dino_teacher_probs(teacher: torch.Tensor, center: torch.Tensor, temp: float)
 def dino_loss(student: torch.Tensor, probs: torch.Tensor, n_student_views: int, n_teacher_views: int, batch: int,
               student_temp: float = 0.1) -> torch.Tensor:
     """Mean over (teacher view t, student view s != t) and batch of -<p_t, log_softmax(student_s / T)>."""
+    if _precision.is_f32():
+        return f32path.dino_loss(student, probs, int(n_student_views), int(n_teacher_views), int(batch), float(student_temp))
     return _DinoLoss.apply(student, probs, int(n_student_views), int(n_teacher_views), int(batch), float(student_temp))
 
 
 def dino_center_update(center: torch.Tensor, teacher: torch.Tensor, momentum: float) -> None:
     """center <- m center + (1 - m) mean_rows(teacher), in place (float32 [D] / [1, D])."""
+    if _precision.is_f32():
+        return f32path.dino_center_update(center, teacher.detach(), float(momentum))
     teacher = _bf16_rows(teacher.detach())
     rows, d = teacher.shape
     check(_lib.load().wm_dino_center_update(ptr(teacher), rows, d, float(momentum), ptr(center), stream_ptr()),

@@ -53,7 +53,7 @@ def test_ctypes_table_matches_header(lib):
 def test_version_and_error_strings(lib):
     from ssl_wafermap_amd import _lib
 
-    assert lib.wm_version() == 3
+    assert lib.wm_version() == 4
     assert b"unsupported" in lib.wm_error_string(-2)
     with pytest.raises(_lib.WaferHipError):
         _lib.check(-1, "probe")
