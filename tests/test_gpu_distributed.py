@@ -282,11 +282,11 @@ def test_sync_batchnorm_wide_world2_equals_whole_batch_statistics(tmp_path):
     for n, a, b in zip(["output", "input gradient"], d["got"], d["ref"]):
         # the unsynchronised wide kernel takes a two-pass variance, the synchronised one sum / sum of squares (it has to:
         # the totals cross ranks): outputs on a bf16 rounding boundary may land on the other side
-        parity(f"wide SyncBN (4096 channels) world 2 vs whole-batch BN, {n} (relative L2)", float((a - b).norm() / b.norm()), 2e-3)
+        parity(f"wide SyncBN (4096 channels) world 2 vs whole-batch BN, {n} (relative L2)", float((a - b).norm() / b.norm()), 1e-4)  # measured 0 / 3.1e-7 (one bf16 flip of one element would be ~1e-5)
     worst = max(float((a - b).norm() / b.norm().clamp_min(1e-12)) for a, b in zip(d["got_g"], d["ref_g"]))
-    parity("wide SyncBN world 2 vs whole-batch BN, parameter gradients summed over ranks (relative L2, worst)", worst, 1e-4)
+    parity("wide SyncBN world 2 vs whole-batch BN, parameter gradients summed over ranks (relative L2, worst)", worst, 1e-6)  # measured 1.0e-7
     worst_b = max(float((a.float() - b.float()).abs().max() / b.float().abs().max().clamp_min(1e-12)) for a, b in zip(d["got_b"], d["ref_b"]))
-    parity("wide SyncBN world 2 vs whole-batch BN, running statistics (relative max)", worst_b, 1e-5)
+    parity("wide SyncBN world 2 vs whole-batch BN, running statistics (relative max)", worst_b, 1e-6)  # measured 1.5e-7
 
 
 def _barlow_gather_case(rank, world, out_path):

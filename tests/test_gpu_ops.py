@@ -624,7 +624,7 @@ def test_bn_backward_fused_epilogue_with_a_large_channel_mean():
     assert ratio > 30, ratio   # the case the finding describes
     for k in fused:
         rel = float((fused[k] - plain[k]).norm() / plain[k].norm().clamp_min(1e-20))
-        parity(f"BatchNorm backward in the dgrad epilogue vs separate pass, |mean|/std = {ratio:.0f}: {k} (relative L2)", rel, 5e-2 if k == "dx" else 2e-2)
+        parity(f"BatchNorm backward in the dgrad epilogue vs separate pass, |mean|/std = {ratio:.0f}: {k} (relative L2)", rel, 1e-3 if k == "dx" else 1e-5)  # measured 0 (dx) / 1.7e-7 (dgamma) / 4.6e-9 (dbeta) at |mean|/std = 330
 
 
 def test_conv_bn_backward_is_bit_reproducible():

@@ -56,13 +56,39 @@ def main():
         geom = (N, H, W, C, K, R, R, P, Q, stride, pad)
         flops = 2.0 * N * P * Q * K * R * R * C
         res = {"shape": name, "GFLOP": round(flops / 1e9, 1)}
+        # BatchNorm-backward epilogue forms of dgrad (wm_conv2d_dgrad_bnstat): the step's 15 ReLU'd BatchNorm layers
+        G = 2
+        bnb_ok = C != 16 and bool(lib.wm_conv2d_dgrad_bnstat_ok(*geom, G))
+        if bnb_ok:
+            tiles = N * H * W // G // 128
+            bn_y = torch.randn(N, H, W, C, generator=g, device=dev).bfloat16()
+            resid = torch.randn(N, H, W, C, generator=g, device=dev).bfloat16()
+            mask = torch.randint(0, 256, (N * H * W, C // 8), generator=g, device=dev, dtype=torch.uint8)
+            gam, bet = torch.rand(C, generator=g, device=dev) + 0.5, torch.randn(C, generator=g, device=dev) * 0.1
+            mean, istd = torch.randn(G, C, generator=g, device=dev) * 0.1, torch.rand(G, C, generator=g, device=dev) + 0.5
+            slots = torch.empty(G, tiles, 2, C, device=dev)
+
+            def bnb(with_res):
+                return check(lib.wm_conv2d_dgrad_bnstat(ptr(y), ptr(wc), ptr(resid) if with_res else 0, ptr(dx), *geom, ptr(bn_y), 0,
+                                                        ptr(mask) if with_res else 0, ptr(gam), ptr(bet), ptr(mean), ptr(istd), G,
+                                                        ptr(slots), tiles, st), "dgrad_bnstat")
+        stat_tiles = int(lib.wm_conv2d_fwd_stats_tiles(*geom, N * P * Q // 2)) if (N * P * Q // 2) % 128 == 0 else 0
+        fslots = torch.empty(2, max(stat_tiles, 1), 2, K, device=dev)
         calls = {
+            "fwd_stats": lambda: check(lib.wm_conv2d_fwd_stats(ptr(x), ptr(wk), ptr(y), *geom, ptr(fslots), stat_tiles,
+                                                               N * P * Q // 2, st), "fwd_stats"),
+            "dgrad_bnb": lambda: bnb(False),
+            "dgrad_bnb_res": lambda: bnb(True),
             "fwd": lambda: check(lib.wm_conv2d_fwd(ptr(x), ptr(wk), ptr(y), *geom, st), "fwd"),
             "dgrad": lambda: check(lib.wm_conv2d_dgrad(ptr(y), ptr(wc), ptr(dx), *geom, st), "dgrad"),
             "wgrad": lambda: check(lib.wm_conv2d_wgrad(ptr(y), ptr(x), ptr(dw), *geom, st), "wgrad"),
         }
         for mode in a.modes.split(","):
-            if mode == "dgrad" and C == 16:
+            if mode.startswith("dgrad") and C == 16:
+                continue
+            if mode.startswith("dgrad_bnb") and not bnb_ok:
+                continue
+            if mode == "fwd_stats" and stat_tiles <= 0:
                 continue
             f = calls[mode]
             for _ in range(2):
@@ -77,7 +103,7 @@ def main():
             us = e0.elapsed_time(e1) / a.reps * 1e3
             res[mode + "_us"] = round(us, 1)
             res[mode + "_TF"] = round(flops / us / 1e6, 0)
-            tot[mode] += us * cnt
+            tot[mode] = tot.get(mode, 0.0) + us * cnt
         print(json.dumps(res), flush=True)
     if a.only < 0:
         print(json.dumps({"per_step_ms": {k: round(v / 1e3, 3) for k, v in tot.items()},
