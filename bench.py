@@ -443,9 +443,9 @@ def main():
             raise SystemExit(3)
         return v
 
-    def roofline_from(timer, sampled_steps, kernel_label, traffic_key=None):
+    def roofline_from(timer, sampled_steps, kernel_label, traffic_key=None, overhead_ms=0.0):
         traffic, traffic_source, traffic_commit, traffic_stale = traffic_entry(traffic_key) if traffic_key else (None,) * 4
-        summ = timer.summary()
+        summ = timer.summary(overhead_ms)
         work = sum(v["work"] for v in summ.values())
         ms = sum(v["ms"] for v in summ.values())
         ach = work / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -457,6 +457,10 @@ def main():
                                "ms_per_step": round(v["ms"] / max(sampled_steps, 1), 3)} for k, v in summ.items()}}
         if traffic_source:
             r["traffic_source"], r["traffic_commit"], r["traffic_stale"] = traffic_source, traffic_commit, traffic_stale
+        if overhead_ms > 0.0:
+            # subtracted from every bracketed launch: what the two timing events of a bracket add to a short launch
+            # (ops.KernelTimer.bracket_overhead_ms: the same Linear launch bracketed singly against back to back)
+            r["bracket_overhead_us_per_launch"] = round(overhead_ms * 1e3, 2)
         return r
 
     # ------------------------------------------------------------------------------------------ kNN all-pairs
@@ -673,8 +677,25 @@ def main():
             if simclr:
                 roof = roofline_from(timer, roof_steps, "conv_igemm + conv3x3_patch + conv_wgrad (implicit-GEMM, bf16 MFMA)", "simclr_r18")
             else:
+                # the transformer steps are ~400 launches of 10 - 60 us: calibrate the bracket's own cost on a Linear launch of
+                # the step's shape (token rows x embedding width -> 3 x width) and take it out of every bracketed launch
+                d_model = model.backbone.embed_dim if hasattr(model.backbone, "embed_dim") else model.backbone.hidden_dim
+                rows_c = 64 * 197
+                xs = [torch.randn(rows_c, d_model, device=dev).bfloat16()]
+                w1 = torch.randn(4 * d_model, d_model, device=dev) * 0.02
+                w2 = torch.randn(d_model, 4 * d_model, device=dev) * 0.02
+                bufs = {}
+
+                def fc1():
+                    bufs["h"] = ops.linear(xs[0], w1)
+
+                def fc2():
+                    bufs["y"] = ops.linear(bufs["h"], w2)
+
+                with torch.no_grad():   # a dependent chain of two different GEMMs of the block's MLP shapes
+                    over = ops.KernelTimer.bracket_overhead_ms([fc1, fc2])
                 roof = roofline_from(timer, roof_steps, "Linear GEMMs (conv_igemm 1x1 fwd / dgrad, conv_wgrad) + attn_fwd / attn_bwd, bf16 MFMA",
-                                     workload)
+                                     workload, overhead_ms=over)
         imgs = B * world * steps
         value = imgs / dt
         res = {

@@ -165,9 +165,9 @@ int wm_knn_vote(const float* sim, const int32_t* idx, const int64_t* bank_labels
 int wm_l2_normalize(const void* x, int in_dtype, int rows, int d, float eps, void* y,
                     int out_dtype, float* inv_norm, void* stream);
 /* Backward of the above: dx = (dy - y * <dy,y>) * inv_norm ; all float32. */
-/* dx (out_dtype WM_F32 or WM_BF16) = (dy - y <dy, y>) * inv_norm (* *scale_dev when non-NULL: the device-resident
+/* dx (out_dtype WM_F32 or WM_BF16) = (dy (dy_dtype WM_F32 or WM_BF16) - y <dy, y>) * inv_norm (* *scale_dev when non-NULL: the device-resident
  * gradient of the scalar loss the normalised rows feed, so that no separate scaling pass is needed). */
-int wm_l2_normalize_bwd(const float* dy, const float* y, const float* inv_norm, int rows, int d,
+int wm_l2_normalize_bwd(const void* dy, int dy_dtype, const float* y, const float* inv_norm, int rows, int d,
                         void* dx, int out_dtype, const float* scale_dev, void* stream);
 
 /* ---------------------------------------------------------------------------------------------

@@ -101,7 +101,7 @@ SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],
     ),
     "wm_l2_normalize": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_void_p, c_int, c_void_p, c_void_p]),
-    "wm_l2_normalize_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
+    "wm_l2_normalize_bwd": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_int, c_int, c_void_p, c_int, c_void_p, c_void_p]),
     "wm_ntxent_fwd": (
         c_int,
         [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_float, c_void_p, c_void_p, c_void_p],

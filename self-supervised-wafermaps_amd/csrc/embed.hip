@@ -37,23 +37,27 @@ __global__ __launch_bounds__(256) void l2norm_fwd(const TIn* __restrict__ x, int
   if (inv_norm && lane == 0) inv_norm[row] = 1.0f / denom;
 }
 
-template <typename TO>
-__global__ __launch_bounds__(256) void l2norm_bwd(const float* __restrict__ dy,
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void l2norm_bwd(const TI* __restrict__ dy,
                                                   const float* __restrict__ y,
                                                   const float* __restrict__ inv_norm, int rows,
                                                   int d, TO* __restrict__ dx, const float* __restrict__ scale) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   if (row >= rows) return;
-  const float* dyr = dy + (size_t)row * d;
+  const TI* dyr = dy + (size_t)row * d;
   const float* yr = y + (size_t)row * d;
+  auto ld = [&](int c) -> float {
+    if constexpr (sizeof(TI) == 2) return bf2f(dyr[c]);
+    else return dyr[c];
+  };
   float dot = 0.f;
-  for (int c = lane; c < d; c += 64) dot += dyr[c] * yr[c];
+  for (int c = lane; c < d; c += 64) dot += ld(c) * yr[c];
   dot = wave_sum(dot);
   // scale: the (device) gradient of the scalar loss this normalisation feeds -- dy is then the unscaled gradient
   const float s = inv_norm[row] * (scale != nullptr ? *scale : 1.f);
   for (int c = lane; c < d; c += 64) {
-    const float v = (dyr[c] - yr[c] * dot) * s;
+    const float v = (ld(c) - yr[c] * dot) * s;
     if constexpr (sizeof(TO) == 2) dx[(size_t)row * d + c] = f2bf(v);
     else dx[(size_t)row * d + c] = v;
   }
@@ -300,16 +304,21 @@ extern "C" int wm_l2_normalize(const void* x, int in_dtype, int rows, int d, flo
   return WM_OK;
 }
 
-extern "C" int wm_l2_normalize_bwd(const float* dy, const float* y, const float* inv_norm, int rows,
+extern "C" int wm_l2_normalize_bwd(const void* dy, int dy_dtype, const float* y, const float* inv_norm, int rows,
                                    int d, void* dx, int out_dtype, const float* scale_dev, void* stream) {
   WM_REQUIRE(dy && y && inv_norm && dx, WM_EINVAL);
   WM_REQUIRE(rows > 0 && d > 0, WM_EINVAL);
-  WM_REQUIRE(out_dtype == WM_F32 || out_dtype == WM_BF16, WM_EUNSUPPORTED);
+  WM_REQUIRE((out_dtype == WM_F32 || out_dtype == WM_BF16) && (dy_dtype == WM_F32 || dy_dtype == WM_BF16), WM_EUNSUPPORTED);
   hipStream_t st = static_cast<hipStream_t>(stream);
-  if (out_dtype == WM_F32)
-    l2norm_bwd<float><<<wm_cdiv(rows, 4), 256, 0, st>>>(dy, y, inv_norm, rows, d, static_cast<float*>(dx), scale_dev);
+  const dim3 grid(wm_cdiv(rows, 4));
+  if (dy_dtype == WM_F32 && out_dtype == WM_F32)
+    l2norm_bwd<float, float><<<grid, 256, 0, st>>>(static_cast<const float*>(dy), y, inv_norm, rows, d, static_cast<float*>(dx), scale_dev);
+  else if (dy_dtype == WM_F32)
+    l2norm_bwd<float, uint16_t><<<grid, 256, 0, st>>>(static_cast<const float*>(dy), y, inv_norm, rows, d, static_cast<uint16_t*>(dx), scale_dev);
+  else if (out_dtype == WM_F32)
+    l2norm_bwd<uint16_t, float><<<grid, 256, 0, st>>>(static_cast<const uint16_t*>(dy), y, inv_norm, rows, d, static_cast<float*>(dx), scale_dev);
   else
-    l2norm_bwd<uint16_t><<<wm_cdiv(rows, 4), 256, 0, st>>>(dy, y, inv_norm, rows, d, static_cast<uint16_t*>(dx), scale_dev);
+    l2norm_bwd<uint16_t, uint16_t><<<grid, 256, 0, st>>>(static_cast<const uint16_t*>(dy), y, inv_norm, rows, d, static_cast<uint16_t*>(dx), scale_dev);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

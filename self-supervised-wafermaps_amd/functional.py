@@ -194,35 +194,54 @@ def knn_vote(sim: torch.Tensor, idx: torch.Tensor, bank_labels: torch.Tensor, nu
 
 class _L2Normalize(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eps):
+    def forward(ctx, x, eps, out_bf16=False):
         require_gpu(x)
         rows, d = x.shape
         y = torch.empty((rows, d), dtype=torch.float32, device=x.device)
         inv = torch.empty((rows,), dtype=torch.float32, device=x.device)
-        check(_lib.load().wm_l2_normalize(ptr(x), dtype_code(x), rows, d, float(eps), ptr(y), _lib.WM_F32,
-                                          ptr(inv), stream_ptr()), "wm_l2_normalize")
+        lib = _lib.load()
+        check(lib.wm_l2_normalize(ptr(x), dtype_code(x), rows, d, float(eps), ptr(y), _lib.WM_F32, ptr(inv), stream_ptr()),
+              "wm_l2_normalize")
         ctx.save_for_backward(y, inv)
         ctx.in_dtype = x.dtype
+        ctx.x_ref = x if x.is_leaf else None   # a PARAMETER (weight-normalised last layer of the DINO head)
+        if out_bf16:   # the consumer is an MFMA operand: hand it bf16 rows (own cast kernel; the float32 rows stay saved)
+            yb = torch.empty((rows, d), dtype=torch.bfloat16, device=x.device)
+            check(lib.wm_cast_f32_bf16(ptr(y), y.numel(), ptr(yb), stream_ptr()), "wm_cast_f32_bf16")
+            return yb
         return y
 
     @staticmethod
     def backward(ctx, dy):
         y, inv = ctx.saved_tensors
-        dy = dy.contiguous().float()
+        dy = dy.contiguous()
+        if dy.dtype not in (torch.float32, torch.bfloat16):
+            dy = dy.float()
         out_dtype = ctx.in_dtype if ctx.in_dtype in (torch.float32, torch.bfloat16) else torch.float32
         dx = torch.empty(y.shape, dtype=out_dtype, device=y.device)   # written in the input's dtype: no cast pass
-        check(_lib.load().wm_l2_normalize_bwd(ptr(dy), ptr(y), ptr(inv), y.shape[0], y.shape[1], ptr(dx), dtype_code(dx),
-                                              0, stream_ptr()), "wm_l2_normalize_bwd")
-        return dx.to(ctx.in_dtype), None
+        check(_lib.load().wm_l2_normalize_bwd(ptr(dy), dtype_code(dy), ptr(y), ptr(inv), y.shape[0], y.shape[1], ptr(dx),
+                                              dtype_code(dx), 0, stream_ptr()), "wm_l2_normalize_bwd")
+        x = ctx.x_ref
+        slot = x.grad if (x is not None and getattr(x, "_hip_arena_grad", False)) else None
+        if slot is not None and slot.is_contiguous() and dx.dtype == torch.float32:
+            # the parameter's gradient slot belongs to a fused optimiser: added by the library's own kernel
+            check(_lib.load().wm_wgrad_finalize(ptr(dx), 1, 1, dx.numel(), 1, 1, ptr(slot), 1, stream_ptr()), "wm_wgrad_finalize(add)")
+            return None, None, None
+        return dx.to(ctx.in_dtype), None, None
 
 
-def l2_normalize(x: torch.Tensor, eps: float = 1e-12, out_dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+def l2_normalize(x: torch.Tensor, eps: float = 1e-12, out_dtype: Optional[torch.dtype] = None,
+                 differentiable_bf16: bool = False) -> torch.Tensor:
     """torch.nn.functional.normalize(x, dim=1) for a 2-D tensor.  With out_dtype=None the result is
     float32 and differentiable; with out_dtype=torch.bfloat16 it is an inference-only cast (the
-    kNN bank build, reference src/ssl_wafermap/models/knn.py:76-80)."""
+    kNN bank build, reference src/ssl_wafermap/models/knn.py:76-80) -- unless differentiable_bf16: bf16 rows WITH a backward
+    pass (gradients arrive and leave in bf16 too), for a normalisation that feeds a Linear layer (the DINO head's
+    bottleneck -> last layer): the float32 <-> bf16 casts around the GEMM are then the library's, not the framework's."""
     if x.dim() != 2:
         raise ValueError("l2_normalize expects [rows, d]")
     x = x.contiguous()
+    if differentiable_bf16:
+        return _L2Normalize.apply(x, eps, True)
     if out_dtype is None or out_dtype == torch.float32:
         return _L2Normalize.apply(x, eps)
     require_gpu(x)

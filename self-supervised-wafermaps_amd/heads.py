@@ -10,6 +10,7 @@ import torch.nn as nn
 from . import functional as F_hip
 from . import nn as hnn
 from . import ops, vit_ops
+from . import precision as _precision
 
 
 class ProjectionHead(nn.Module):
@@ -183,7 +184,9 @@ class DINOProjectionHead(ProjectionHead):
 
     def forward(self, x):
         x = super().forward(x)
-        x = F_hip.l2_normalize(x)
+        # the normalised bottleneck feeds the last layer's GEMM: bf16 rows with a bf16 backward (no framework cast passes
+        # around the GEMM); float32 throughout under the float32 preset
+        x = F_hip.l2_normalize(x, differentiable_bf16=not _precision.is_f32())
         return self.last_layer(x)
 
 

@@ -90,7 +90,7 @@ class _NTXentProjections(torch.autograd.Function):
         out_dtype = in_dtype if in_dtype in (torch.float32, torch.bfloat16) else torch.float32
         dz = torch.empty(zn.shape, dtype=out_dtype, device=zn.device)
         g = grad_out.detach().reshape(-1).to(torch.float32)
-        check(_lib.load().wm_l2_normalize_bwd(ptr(dzn), ptr(zn), ptr(inv), zn.shape[0], zn.shape[1], ptr(dz),
+        check(_lib.load().wm_l2_normalize_bwd(ptr(dzn), _lib.WM_F32, ptr(zn), ptr(inv), zn.shape[0], zn.shape[1], ptr(dz),
                                               _lib.dtype_code(dz), ptr(g), stream_ptr()), "wm_l2_normalize_bwd")
         return dz.to(in_dtype), None, None, None
 
@@ -303,8 +303,8 @@ class NTXentLoss(nn.Module):
             raise ValueError("NTXentLoss expects two [batch, dim] tensors of equal shape")
         b = out0.shape[0]
         if self.size > 0:
-            if self.gather_distributed and _world() > 1:
-                raise NotImplementedError("NTXentLoss: memory bank with gather_distributed is not built")
+            # (lightly takes this branch whenever the bank returns negatives and never reaches its gather code then: with a
+            # memory bank `gather_distributed` has no effect -- SURVEY Appendix A.1; the reference's MoCo leaves it False)
             q = F_hip.l2_normalize(out0.float().contiguous())
             k = F_hip.l2_normalize(out1.float().contiguous())
             if self.bank.numel() == 0 or self.bank.shape[0] != q.shape[1] or self.bank.device != q.device:

@@ -139,9 +139,12 @@ class MAEBackbone(nn.Module):
             basis = torch.eye(n, dtype=torch.float32).reshape(1, g, g, n).permute(0, 3, 1, 2)
             sf = (g_new + 0.1) / g
             out = nn.functional.interpolate(basis, scale_factor=(sf, sf), mode="bicubic")
-            m = out.permute(0, 2, 3, 1).reshape(g_new * g_new, n).contiguous().to(pos.device)
+            full = torch.zeros(g_new * g_new + 1, n + 1, dtype=torch.float32)   # row 0: the class-token position passes through
+            full[0, 0] = 1.0
+            full[1:, 1:] = out.permute(0, 2, 3, 1).reshape(g_new * g_new, n)
+            m = full.contiguous().to(pos.device)
             cache[key] = m
-        return torch.cat([pos[:, :1], vit_ops.const_matmul(m, pos[0, 1:]).unsqueeze(0)], dim=1)
+        return vit_ops.const_matmul(m, pos).unsqueeze(0)
 
     def images_to_tokens(self, images, add_pos: bool = True):
         """[B,3,S,S] -> bf16 [B*seq, D] rows: class token prepended; the positional embedding is added here

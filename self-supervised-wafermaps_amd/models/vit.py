@@ -128,8 +128,10 @@ class VisionTransformer(nn.Module):
 
     # ---- positional embedding for other crop sizes (dino: interpolate_pos_encoding) -------------
     def _interp_matrix(self, g_new: int) -> torch.Tensor:
-        """[g_new^2, g^2] matrix of dino's bicubic resize of the patch position grid (scale factor
-        (g_new + 0.1) / g), built once per crop size by resizing the identity basis on the host."""
+        """[1 + g_new^2, 1 + g^2] matrix of dino's interpolate_pos_encoding: row 0 passes the class-token position through,
+        the other rows are dino's bicubic resize of the patch position grid (scale factor (g_new + 0.1) / g), built once
+        per crop size by resizing the identity basis on the host.  As ONE product with the whole embedding the resize
+        needs no slice / cat of the parameter (each a framework kernel forward and backward)."""
         n = self.pos_embed.shape[1] - 1
         g = int(math.sqrt(n))
         key = (g, g_new)
@@ -140,7 +142,10 @@ class VisionTransformer(nn.Module):
             out = nn.functional.interpolate(basis, scale_factor=(sf, sf), mode="bicubic")
             if out.shape[-1] != g_new or out.shape[-2] != g_new:
                 raise RuntimeError(f"pos-embed resize {g}->{g_new} produced {tuple(out.shape)}")
-            m = out.permute(0, 2, 3, 1).reshape(g_new * g_new, n).contiguous().to(self.pos_embed.device)
+            full = torch.zeros(g_new * g_new + 1, n + 1, dtype=torch.float32)
+            full[0, 0] = 1.0
+            full[1:, 1:] = out.permute(0, 2, 3, 1).reshape(g_new * g_new, n)
+            m = full.contiguous().to(self.pos_embed.device)
             self._interp[key] = m
         return m
 
@@ -148,9 +153,8 @@ class VisionTransformer(nn.Module):
         n = self.pos_embed.shape[1] - 1
         if g_new * g_new == n:
             return self.pos_embed
-        m = self._interp_matrix(g_new)
-        patch = vit_ops.const_matmul(m, self.pos_embed[0, 1:])  # [g_new^2, D]: a 36 x 196 x 384 product, parameter-side
-        return torch.cat([self.pos_embed[:, :1], patch.unsqueeze(0)], dim=1)
+        # [1 + g_new^2, D]: a 37 x 197 x D product, parameter-side
+        return vit_ops.const_matmul(self._interp_matrix(g_new), self.pos_embed).unsqueeze(0)
 
     # ---- forward ----------------------------------------------------------------------------------
     def prepare_tokens(self, x):
@@ -166,14 +170,16 @@ class VisionTransformer(nn.Module):
         once per resolution; here the token rows of all groups are concatenated, so every per-token layer (LayerNorm,
         the four Linear layers of a block and their weight gradients) is ONE launch over all rows, and only the attention
         itself runs per group (vit_ops.attention_segments).  Per-row arithmetic is unchanged."""
-        toks, segments = [], []
-        for x in xs:
-            tok, n, seq = self.prepare_tokens(x)
-            toks.append(tok)
-            segments.append((n, seq))
-        if len(toks) == 1:
+        if len(xs) == 1:
             return self.forward(xs[0])
-        tok = torch.cat(toks, dim=0)
+        groups, segments = [], []
+        p = self.patch_embed.patch_size
+        for x in xs:
+            n, g = x.shape[0], x.shape[-1] // p
+            groups.append((self.patch_embed(x), self.pos_for(g), n, g * g))
+            segments.append((n, g * g + 1))
+        # every group's token rows written into ONE buffer (no concatenation pass)
+        tok = vit_ops.tokens_assemble_multi(groups, self.cls_token)
         for blk in self.blocks:
             tok = blk(tok, 0, 0, segments=segments)
         # the class-token rows of all segments in ONE gather over the concatenated rows (one zero-filled gradient buffer

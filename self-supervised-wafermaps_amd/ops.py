@@ -35,14 +35,47 @@ class KernelTimer:
         self.records.append((name, work, a, b))
         return rc
 
-    def summary(self):
+    def summary(self, overhead_ms: float = 0.0):
+        """Per name: launches, work and bracketed time; `overhead_ms` (see bracket_overhead_ms) is subtracted per launch."""
         out = {}
         for name, work, a, b in self.records:
             d = out.setdefault(name, {"launches": 0, "work": 0.0, "ms": 0.0})
             d["launches"] += 1
             d["work"] += work
-            d["ms"] += a.elapsed_time(b)
+            d["ms"] += max(a.elapsed_time(b) - overhead_ms, 0.0)
         return out
+
+    @staticmethod
+    def bracket_overhead_ms(fns, reps: int = 20) -> float:
+        """What an event bracket adds to ONE short launch: the launches `fns` (a dependent chain of DIFFERENT kernels, as
+        in a training step) `reps` times over, each inside its own bracket, against the same sequence inside one bracket
+        (the time a launch takes in an unbroken stream, which is what a kernel trace reports).  A timing event is a barrier
+        packet: it keeps the next kernel from ramping up under the tail of the previous one, costs a few microseconds
+        itself, and on a slow host the device idles between the event and the launch -- on 10 - 60 us launches that
+        inflated the ViT roofline's denominator by 13 % (8.03 ms bracketed against 7.11 ms in the rocprof trace, round 3)
+        to 70 % (12.0 ms on a box with a slow host, round 4)."""
+        for f in fns:
+            f()
+        torch.cuda.synchronize()
+        n = len(fns) * reps
+        pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+        it = iter(pairs)
+        for _ in range(reps):
+            for f in fns:
+                a, b = next(it)
+                a.record()
+                f()
+                b.record()
+        torch.cuda.synchronize()
+        single = sum(a.elapsed_time(b) for a, b in pairs) / n
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            for f in fns:
+                f()
+        b.record()
+        torch.cuda.synchronize()
+        return max(single - a.elapsed_time(b) / n, 0.0)
 
 
 TIMER = None  # set to a KernelTimer to bracket the conv launches
@@ -457,8 +490,10 @@ def _arena_grad(p: torch.Tensor):
     """The parameter's gradient slot when a fused optimiser owns it (a view of the flat gradient
     arena, zeroed by optimizer.zero_grad): backward kernels then accumulate straight into it and
     autograd receives None, which skips one tiny AccumulateGrad add per parameter per step."""
+    if not getattr(p, "_hip_arena_grad", False):   # (also keeps .grad of non-leaf tensors -- e.g. a normalised weight -- untouched)
+        return None
     g = p.grad
-    if g is not None and getattr(p, "_hip_arena_grad", False) and g.is_contiguous():
+    if g is not None and g.is_contiguous():
         return g
     return None
 

@@ -294,28 +294,38 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] =
 
 
 class _ConstMatmul(torch.autograd.Function):
-    """m @ p for a CONSTANT float32 matrix m [M, K] and a parameter-side float32 p [K, N] (the resized positional
-    embedding): wm_matmul_f32 forward, m^T @ dout backward."""
+    """m @ p for a CONSTANT float32 matrix m [M, K] and a parameter-side float32 p ([K, N], or [1, K, N]: the positional
+    embedding parameter itself): wm_matmul_f32 forward, m^T @ dout backward.  When `p` is a parameter whose gradient slot
+    a fused optimiser owns, the backward adds its product into the slot with the library's own kernel and hands autograd
+    None: a parameter used by several nodes (the positional embedding: directly by the 224 x 224 crops, through this
+    resize by the 96 x 96 crops) would otherwise cost one framework add kernel per use."""
 
     @staticmethod
     def forward(ctx, m, p):
         _need_cuda(p, "const_matmul")
-        m, p = m.contiguous().float(), p.contiguous().float()
-        out = torch.empty((m.shape[0], p.shape[1]), dtype=torch.float32, device=p.device)
-        check(_lib.load().wm_matmul_f32(ptr(m), ptr(p), ptr(out), m.shape[0], p.shape[1], m.shape[1], 0, stream_ptr()),
+        m = m.contiguous().float()
+        p2 = p.detach().reshape(-1, p.shape[-1]).contiguous().float()
+        out = torch.empty((m.shape[0], p2.shape[1]), dtype=torch.float32, device=p.device)
+        check(_lib.load().wm_matmul_f32(ptr(m), ptr(p2), ptr(out), m.shape[0], p2.shape[1], m.shape[1], 0, stream_ptr()),
               "wm_matmul_f32")
         ctx.save_for_backward(m)
+        ctx.p = p
         return out
 
     @staticmethod
     def backward(ctx, dout):
         (m,) = ctx.saved_tensors
+        p = ctx.p
         dout = dout.contiguous().float()
         dp = torch.empty((m.shape[1], dout.shape[1]), dtype=torch.float32, device=dout.device)
         # dp [K, N] = m^T [K, M] @ dout [M, N]: op(a) = a^T with a = m stored [M][K]
         check(_lib.load().wm_matmul_f32(ptr(m), ptr(dout), ptr(dp), m.shape[1], dout.shape[1], m.shape[0], 1, stream_ptr()),
               "wm_matmul_f32")
-        return None, dp
+        slot = _arena_grad(p) if p.is_leaf else None
+        if slot is not None:
+            check(_lib.load().wm_wgrad_finalize(ptr(dp), 1, 1, dp.numel(), 1, 1, ptr(slot), 1, stream_ptr()), "wm_wgrad_finalize(add)")
+            return None, None
+        return None, dp.reshape(p.shape)
 
 
 def const_matmul(m: torch.Tensor, p: torch.Tensor) -> torch.Tensor:
@@ -608,42 +618,108 @@ def patch_embed(images: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
     return _PatchEmbed.apply(images, weight)
 
 
+def _tokens_assemble_fwd(patches, cls, pos, n, np_, out):
+    """wm_tokens_assemble of one group into `out` (a [n * (np + 1), d] bf16 row range)."""
+    d = patches.shape[1]
+    cls_c, pos_c = cls.detach().reshape(-1).contiguous(), pos.detach().reshape(-1, d).contiguous()
+    if pos_c.shape[0] != np_ + 1 or patches.shape[0] != n * np_:
+        raise ValueError(f"tokens_assemble: {tuple(patches.shape)} patches, pos {tuple(pos.shape)}, N={n}, np={np_}")
+    check(_lib.load().wm_tokens_assemble(ptr(patches), ptr(cls_c), ptr(pos_c), n, np_, d, ptr(out), stream_ptr()),
+          "wm_tokens_assemble")
+
+
+def _tokens_assemble_bwd(dx, cls_p, pos_p, n, np_, d):
+    """Gradients of one group: (dpatch, dcls or None, dpos or None) -- None where the sums went straight into a fused
+    optimiser's gradient slot by the library's own add (the class token / positional embedding PARAMETERS are used once
+    per crop resolution: autograd's accumulation would be one framework add kernel per use and parameter)."""
+    s = np_ + 1
+    lib = _lib.load()
+    # sum over the images of the [s * d] token rows: per-block slots added in order (no f32 atomics)
+    dpos = torch.empty(s * d, dtype=torch.float32, device=dx.device)
+    nb = int(lib.wm_colsum_blocks(n, s * d))
+    part = torch.empty(nb * s * d, dtype=torch.float32, device=dx.device)
+    check(lib.wm_bias_act_bwd_parts(0, 0, ptr(dx), ACT_NONE, n, s * d, 0, ptr(part), stream_ptr()), "wm_bias_act_bwd_parts")
+    check(lib.wm_wgrad_finalize(ptr(part), nb, 1, s * d, 1, 1, ptr(dpos), 0, stream_ptr()), "wm_wgrad_finalize")
+    # the patch rows (every token but the class token of each image) by the row-gather kernel: a strided slice +
+    # reshape would be an ATen copy kernel
+    idx = cached_index(("patch_rows", n, np_, str(dx.device)),
+                       lambda: torch.arange(1, s, dtype=torch.int64, device=dx.device).repeat(n, 1).contiguous())
+    dpatch = torch.empty((n * np_, d), dtype=torch.bfloat16, device=dx.device)
+    check(lib.wm_gather_rows(ptr(dx), ptr(idx), n, s, np_, d, ptr(dpatch), stream_ptr()), "wm_gather_rows")
+    dcls, dposr = dpos[:d].reshape(cls_p.shape), dpos.reshape(pos_p.shape)
+    sc = _arena_grad(cls_p) if cls_p.is_leaf else None
+    sp = _arena_grad(pos_p) if pos_p.is_leaf else None
+    if sc is not None:
+        check(lib.wm_wgrad_finalize(ptr(dpos), 1, 1, d, 1, 1, ptr(sc), 1, stream_ptr()), "wm_wgrad_finalize(add cls)")
+        dcls = None
+    if sp is not None:
+        check(lib.wm_wgrad_finalize(ptr(dpos), 1, 1, s * d, 1, 1, ptr(sp), 1, stream_ptr()), "wm_wgrad_finalize(add pos)")
+        dposr = None
+    return dpatch, dcls, dposr
+
+
 class _TokensAssemble(torch.autograd.Function):
     @staticmethod
     def forward(ctx, patches, cls, pos, n, np_):
         _need_cuda(patches, "tokens_assemble")
         patches = _bf16_rows(patches)
         d = patches.shape[1]
-        cls_c, pos_c = cls.detach().reshape(-1).contiguous(), pos.detach().reshape(-1, d).contiguous()
-        if pos_c.shape[0] != np_ + 1 or patches.shape[0] != n * np_:
-            raise ValueError(f"tokens_assemble: {tuple(patches.shape)} patches, pos {tuple(pos.shape)}, N={n}, np={np_}")
         out = torch.empty((n * (np_ + 1), d), dtype=torch.bfloat16, device=patches.device)
-        check(_lib.load().wm_tokens_assemble(ptr(patches), ptr(cls_c), ptr(pos_c), n, np_, d, ptr(out), stream_ptr()),
-              "wm_tokens_assemble")
+        _tokens_assemble_fwd(patches, cls, pos, n, np_, out)
         ctx.geom = (n, np_, d)
-        ctx.shapes = (cls.shape, pos.shape)
+        ctx.params = (cls, pos)
         return out
 
     @staticmethod
     def backward(ctx, dx):
         n, np_, d = ctx.geom
+        dpatch, dcls, dpos = _tokens_assemble_bwd(_bf16_rows(dx), ctx.params[0], ctx.params[1], n, np_, d)
+        return dpatch, dcls, dpos, None, None
+
+
+class _TokensAssembleMulti(torch.autograd.Function):
+    """tokens_assemble of SEVERAL groups (DINO's crop resolutions) into ONE row-concatenated token tensor: every group
+    writes its row range of the shared buffer, so no concatenation pass follows (forward) and the gradient of a group is
+    a row range of the incoming gradient (backward)."""
+
+    @staticmethod
+    def forward(ctx, cls, geoms, *flat):
+        groups = [(flat[2 * i], flat[2 * i + 1]) for i in range(len(geoms))]
+        _need_cuda(groups[0][0], "tokens_assemble_multi")
+        d = groups[0][0].shape[1]
+        rows = [n * (np_ + 1) for n, np_ in geoms]
+        out = torch.empty((sum(rows), d), dtype=torch.bfloat16, device=groups[0][0].device)
+        off = 0
+        for (patches, pos), (n, np_), r in zip(groups, geoms, rows):
+            _tokens_assemble_fwd(_bf16_rows(patches), cls, pos, n, np_, out[off:off + r])
+            off += r
+        ctx.geoms, ctx.d, ctx.cls = geoms, d, cls
+        ctx.pos = [pos for _, pos in groups]
+        return out
+
+    @staticmethod
+    def backward(ctx, dx):
         dx = _bf16_rows(dx)
-        s = np_ + 1
-        # sum over the images of the [s * d] token rows: per-block slots added in order (no f32 atomics)
-        lib = _lib.load()
-        dpos = torch.empty(s * d, dtype=torch.float32, device=dx.device)
-        nb = int(lib.wm_colsum_blocks(n, s * d))
-        part = torch.empty(nb * s * d, dtype=torch.float32, device=dx.device)
-        check(lib.wm_bias_act_bwd_parts(0, 0, ptr(dx), ACT_NONE, n, s * d, 0, ptr(part), stream_ptr()), "wm_bias_act_bwd_parts")
-        check(lib.wm_wgrad_finalize(ptr(part), nb, 1, s * d, 1, 1, ptr(dpos), 0, stream_ptr()), "wm_wgrad_finalize")
-        # the patch rows (every token but the class token of each image) by the row-gather kernel: a strided slice +
-        # reshape would be an ATen copy kernel
-        idx = cached_index(("patch_rows", n, np_, str(dx.device)),
-                           lambda: torch.arange(1, s, dtype=torch.int64, device=dx.device).repeat(n, 1).contiguous())
-        dpatch = torch.empty((n * np_, d), dtype=torch.bfloat16, device=dx.device)
-        check(_lib.load().wm_gather_rows(ptr(dx), ptr(idx), n, s, np_, d, ptr(dpatch), stream_ptr()), "wm_gather_rows")
-        cls_shape, pos_shape = ctx.shapes
-        return dpatch, dpos[:d].reshape(cls_shape), dpos.reshape(pos_shape), None, None
+        grads, dcls_sum, off = [], None, 0
+        for (n, np_), pos in zip(ctx.geoms, ctx.pos):
+            r = n * (np_ + 1)
+            dpatch, dcls, dpos = _tokens_assemble_bwd(dx[off:off + r], ctx.cls, pos, n, np_, ctx.d)
+            off += r
+            grads += [dpatch, dpos]
+            if dcls is not None:   # (no gradient slot: plain tensors; the framework adds them)
+                dcls_sum = dcls if dcls_sum is None else dcls_sum + dcls
+        return (dcls_sum, None, *grads)
+
+
+def tokens_assemble_multi(groups, cls: torch.Tensor) -> torch.Tensor:
+    """groups: [(patches [n * np, d], pos, n, np), ...] -> bf16 [sum n * (np + 1), d], the groups' token rows in order."""
+    if _precision.is_f32():
+        return torch.cat([f32path.tokens_assemble(p, cls, pos, int(n), int(np_)) for p, pos, n, np_ in groups], dim=0)
+    geoms = tuple((int(n), int(np_)) for _, _, n, np_ in groups)
+    flat = []
+    for p, pos, _, _ in groups:
+        flat += [p, pos]
+    return _TokensAssembleMulti.apply(cls, geoms, *flat)
 
 
 def tokens_assemble(patches: torch.Tensor, cls: torch.Tensor, pos: torch.Tensor, n: int, np_: int) -> torch.Tensor:

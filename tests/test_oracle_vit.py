@@ -80,8 +80,10 @@ def test_pos_embed_resize_matrix_equals_interpolation():
     assert m.pos_for(14) is m.pos_embed
     for g_new in (6, 7):
         mat = m._interp_matrix(g_new)
-        assert mat.shape == (g_new * g_new, 196)
-        got = torch.cat([pe[:, :1], (mat @ pe[0, 1:]).unsqueeze(0)], dim=1)
+        # one product with the WHOLE embedding: row 0 passes the class-token position through, the rest is the bicubic resize
+        assert mat.shape == (g_new * g_new + 1, 197)
+        assert float(mat[0, 0]) == 1.0 and float(mat[0, 1:].abs().max()) == 0.0 and float(mat[1:, 0].abs().max()) == 0.0
+        got = (mat @ pe[0]).unsqueeze(0)
         want = ov.pos_embed_for(pe, g_new)
         assert got.shape == (1, g_new * g_new + 1, 64)
         torch.testing.assert_close(got, want, rtol=1e-5, atol=1e-6)
