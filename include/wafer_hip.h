@@ -656,6 +656,24 @@ int wm_f32_softmax_rows(const float* x, const float* subtract, float inv_temp, i
 int wm_f32_pair_ce(const float* probs, const float* logq, int T, int SV, int B, int D, float* pair_loss, void* stream);
 /* *out = scale * sum_i f(a_i, b_i): mode 0 a_i, 1 (a_i - b_i)^2, 2 |a_i - b_i|; one ordered double-precision sum. */
 int wm_f32_reduce(const float* a, const float* b, long long n, int mode, double scale, float* out, void* stream);
+/* Backward pieces of the convolution / BatchNorm / pooling / Linear path (the float32 preset can take a whole SimCLR optimiser
+ * step: scripts/WM811k_benchmark.py:242-255).  dx [N][H][W][C] = input gradient of wm_f32_conv2d_fwd for dy [N][P][Q][K];
+ * dw_oihw [K][C][R][S] = its weight gradient (pixel ranges summed in a fixed order; workspace from
+ * wm_f32_conv2d_wgrad_workspace_bytes); wm_f32_colsum: bias gradients. */
+int wm_f32_conv2d_dgrad(const float* dy, const float* w_oihw, float* dx, int N, int H, int W, int C, int K, int R, int S, int P,
+                        int Q, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
+size_t wm_f32_conv2d_wgrad_workspace_bytes(int N, int P, int Q, int C, int K, int R, int S);
+int wm_f32_conv2d_wgrad(const float* dy, const float* x, float* dw_oihw, int N, int H, int W, int C, int K, int R, int S, int P,
+                        int Q, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream);
+int wm_f32_colsum(const float* x, long long rows, int C, float* out, void* stream);
+/* BatchNorm (training statistics, G groups) backward: gm = dout taken through the ReLU where out_relu (the forward's output)
+ * is given; dgamma / dbeta [C] (sums over all groups), dy = gamma * invstd * (gm - mean(gm) - xhat * mean(gm * xhat)), dz (optional)
+ * = gm, the gradient of the residual branch.  Workspace: wm_f32_bn_workspace_bytes. */
+int wm_f32_bn_bwd(const float* y, const float* dout, const float* out_relu, const float* gamma, const float* save_mean,
+                  const float* save_invstd, long long rows, int C, int G, float* dgamma, float* dbeta, float* dy, float* dz,
+                  void* workspace, size_t workspace_bytes, void* stream);
+int wm_f32_maxpool3x3s2_bwd(const float* x, const float* dy, int N, int H, int W, int C, float* dx, void* stream);
+int wm_f32_gap_bwd(const float* dy, int N, int HW, int C, float* dx, void* stream);
 /* center = center * momentum + (1 - momentum) * column mean of teacher [rows][D]. */
 int wm_f32_center_update(float* center, const float* teacher, int rows, int D, float momentum, void* stream);
 

@@ -65,6 +65,16 @@ SIGNATURES = {
     "wm_f32_pair_ce": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_f32_reduce": (c_int, [c_void_p, c_void_p, c_longlong, c_int, c_double, c_void_p, c_void_p]),
     "wm_f32_center_update": (c_int, [c_void_p, c_void_p, c_int, c_int, c_float, c_void_p]),
+    "wm_f32_conv2d_dgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "wm_f32_conv2d_wgrad_workspace_bytes": (c_size_t, [c_int] * 7),
+    "wm_f32_conv2d_wgrad": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int, c_int,
+                                    c_int, c_int, c_void_p, c_size_t, c_void_p]),
+    "wm_f32_colsum": (c_int, [c_void_p, c_longlong, c_int, c_void_p, c_void_p]),
+    "wm_f32_bn_bwd": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_longlong, c_int, c_int, c_void_p,
+                              c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "wm_f32_maxpool3x3s2_bwd": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]),
+    "wm_f32_gap_bwd": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]),
     "wm_version": (c_int, []),
     "wm_error_string": (c_char_p, [c_int]),
     "wm_ln_linear_fwd_ok": (c_int, [c_int, c_int, c_int]),

@@ -32,25 +32,39 @@ __global__ __launch_bounds__(FT) void f32_weights_qk(const float* __restrict__ w
 __device__ __forceinline__ float f32_gelu(float v) { return 0.5f * v * (1.f + erff(v * 0.70710678118654752440f)); }
 
 struct F32Conv {
-  const float* x;    // [N][H][W][C]
-  const float* wt;   // [R*S*C][K]
-  const float* bias; // [K] or null
-  const float* res;  // [M][K] or null
-  float* y;          // [M][K], M = N*P*Q
-  int N, H, W, C, K, R, S, P, Q, stride, pad, act;
+  const float* x;    // source tensor [N][SH][SW][SC]: the input (forward) or the output gradient (input gradient)
+  const float* wt;   // [R*S*SC][DC]
+  const float* bias; // [DC] or null
+  const float* res;  // [M][DC] or null
+  float* y;          // [M][DC], M = N*DH*DW
+  int N, SH, SW, SC, DH, DW, DC, R, S, stride, pad, act;
 };
 
-// Implicit GEMM, 64 x 64 output tile per block, 16-deep reduction steps over the flattened (r, s, c) index, 4 x 4
-// outputs per thread; the reduction runs in increasing (r, s, c) order as one fmaf chain per output.
-__global__ __launch_bounds__(FT) void f32_conv_fwd(const F32Conv a) {
+// weights OIHW [K][C][R][S] -> [R*S*K][C] (the input gradient reduces over (tap, output channel))
+__global__ __launch_bounds__(FT) void f32_weights_qc(const float* __restrict__ w, int K, int C, int RS, float* __restrict__ wt) {
+  const size_t total = (size_t)K * C * RS;
+  for (size_t i = (size_t)blockIdx.x * FT + threadIdx.x; i < total; i += (size_t)gridDim.x * FT) {
+    const int c = (int)(i % C);
+    const size_t q = i / C;
+    const int k = (int)(q % K), rs = (int)(q / K);
+    wt[i] = w[((size_t)k * C + c) * RS + rs];
+  }
+}
+
+// Implicit GEMM, 64 x 64 output tile per block, 16-deep reduction steps over the flattened (r, s, source channel) index,
+// 4 x 4 outputs per thread; the reduction runs in increasing index order as one fmaf chain per output.
+// DGRAD = false: forward, source pixel of tap (r, s) = (dh * stride - pad + r, dw * stride - pad + s).
+// DGRAD = true : input gradient, source = output-gradient pixel ((dh + pad - r) / stride, (dw + pad - s) / stride) where
+//                both divide exactly (a tap that does not hit an output pixel contributes nothing).
+template <bool DGRAD>
+__global__ __launch_bounds__(FT) void f32_conv_kernel(const F32Conv a) {
   __shared__ __attribute__((aligned(16))) float As[16][68];
   __shared__ __attribute__((aligned(16))) float Bs[16][64];
   const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
-  const long long M = (long long)a.N * a.P * a.Q;
+  const long long M = (long long)a.N * a.DH * a.DW;
   const long long m0 = (long long)blockIdx.x * 64;
   const int n0 = blockIdx.y * 64;
-  const int Kd = a.R * a.S * a.C;
-  // A fetch: this thread's reduction slot and its four tile rows
+  const int Kd = a.R * a.S * a.SC;
   const int ql = tid & 15;
   long long rbase[4];
   int rh[4], rw[4];
@@ -60,12 +74,12 @@ __global__ __launch_bounds__(FT) void f32_conv_fwd(const F32Conv a) {
     const long long m = m0 + (tid >> 4) + 16 * i;
     rv[i] = m < M;
     const long long mm = rv[i] ? m : 0;
-    const int n = (int)(mm / ((long long)a.P * a.Q));
-    const int pq = (int)(mm - (long long)n * a.P * a.Q);
-    const int p = pq / a.Q, q = pq - p * a.Q;
-    rh[i] = p * a.stride - a.pad;
-    rw[i] = q * a.stride - a.pad;
-    rbase[i] = (long long)n * a.H * a.W;
+    const int n = (int)(mm / ((long long)a.DH * a.DW));
+    const int pq = (int)(mm - (long long)n * a.DH * a.DW);
+    const int p = pq / a.DW, q = pq - p * a.DW;
+    rh[i] = DGRAD ? p + a.pad : p * a.stride - a.pad;
+    rw[i] = DGRAD ? q + a.pad : q * a.stride - a.pad;
+    rbase[i] = (long long)n * a.SH * a.SW;
   }
   float acc[4][4];
 #pragma unroll
@@ -76,15 +90,25 @@ __global__ __launch_bounds__(FT) void f32_conv_fwd(const F32Conv a) {
     const int qg = k0 + ql;
     const bool qv = qg < Kd;
     const int qq = qv ? qg : 0;
-    const int r = qq / (a.S * a.C);
-    const int rem = qq - r * a.S * a.C;
-    const int s = rem / a.C, c = rem - s * a.C;
+    const int r = qq / (a.S * a.SC);
+    const int rem = qq - r * a.S * a.SC;
+    const int s = rem / a.SC, c = rem - s * a.SC;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int h = rh[i] + r, w = rw[i] + s;
+      int h, w;
+      bool ok = rv[i] && qv;
+      if constexpr (DGRAD) {
+        const int th = rh[i] - r, tw = rw[i] - s;
+        ok = ok && th >= 0 && tw >= 0 && th % a.stride == 0 && tw % a.stride == 0;
+        h = th / a.stride;
+        w = tw / a.stride;
+      } else {
+        h = rh[i] + r;
+        w = rw[i] + s;
+      }
       float v = 0.f;
-      if (rv[i] && qv && (unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
-        v = a.x[((rbase[i] + (long long)h * a.W + w) * a.C) + c];
+      if (ok && (unsigned)h < (unsigned)a.SH && (unsigned)w < (unsigned)a.SW)
+        v = a.x[((rbase[i] + (long long)h * a.SW + w) * a.SC) + c];
       As[ql][(tid >> 4) + 16 * i] = v;
     }
 #pragma unroll
@@ -92,7 +116,7 @@ __global__ __launch_bounds__(FT) void f32_conv_fwd(const F32Conv a) {
       const int e = tid + i * FT;
       const int col = e & 63, qr = e >> 6;
       float v = 0.f;
-      if (k0 + qr < Kd && n0 + col < a.K) v = a.wt[(size_t)(k0 + qr) * a.K + n0 + col];
+      if (k0 + qr < Kd && n0 + col < a.DC) v = a.wt[(size_t)(k0 + qr) * a.DC + n0 + col];
       Bs[qr][col] = v;
     }
     __syncthreads();
@@ -115,14 +139,106 @@ __global__ __launch_bounds__(FT) void f32_conv_fwd(const F32Conv a) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int k = n0 + tx * 4 + j;
-      if (k >= a.K) continue;
+      if (k >= a.DC) continue;
       float v = acc[i][j];
       if (a.bias) v += a.bias[k];
       if (a.act == 1) v = f32_gelu(v);
       else if (a.act == 2) v = fmaxf(v, 0.f);
-      if (a.res) v += a.res[m * a.K + k];
-      a.y[m * a.K + k] = v;
+      if (a.res) v += a.res[m * a.DC + k];
+      a.y[m * a.DC + k] = v;
     }
+  }
+}
+
+// Weight gradient: dw[k][(r, s, c)] = sum over output pixels m of dy[m][k] * x[pixel m shifted by tap (r, s)][c].
+// 64 x 64 tile of (k, column) per block, pixel range z of Z per block (its partial sums go to slab z: ordered sum afterwards).
+struct F32Wgrad {
+  const float* dy;  // [M][K]
+  const float* x;   // [N][H][W][C]
+  float* slabs;     // [Z][K][R*S*C]
+  int N, H, W, C, K, R, S, P, Q, stride, pad;
+  long long chunk;  // pixels per slab
+};
+__global__ __launch_bounds__(FT) void f32_conv_wgrad(const F32Wgrad a) {
+  __shared__ __attribute__((aligned(16))) float As[16][68];
+  __shared__ __attribute__((aligned(16))) float Bs[16][68];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const long long M = (long long)a.N * a.P * a.Q;
+  const int RSC = a.R * a.S * a.C;
+  const int k0 = blockIdx.x * 64, j0 = blockIdx.y * 64;
+  const long long mb = (long long)blockIdx.z * a.chunk;
+  long long me = mb + a.chunk;
+  if (me > M) me = M;
+  // this thread's column (tap, channel) for the B fetch: fixed for the whole block
+  const int jl = tid & 63;
+  const int j = j0 + jl;
+  const bool jv = j < RSC;
+  const int jj = jv ? j : 0;
+  const int r = jj / (a.S * a.C);
+  const int rem = jj - r * a.S * a.C;
+  const int s = rem / a.C, c = rem - s * a.C;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[i][q] = 0.f;
+  for (long long m0 = mb; m0 < me; m0 += 16) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int kk = (tid >> 6) + 4 * i;          // pixel of the step: 0 .. 15
+      const long long m = m0 + kk;
+      float va = 0.f, vb = 0.f;
+      if (m < me) {
+        if (k0 + jl < a.K) va = a.dy[m * a.K + k0 + jl];
+        if (jv) {
+          const int n = (int)(m / ((long long)a.P * a.Q));
+          const int pq = (int)(m - (long long)n * a.P * a.Q);
+          const int p = pq / a.Q, q = pq - p * a.Q;
+          const int h = p * a.stride - a.pad + r, w = q * a.stride - a.pad + s;
+          if ((unsigned)h < (unsigned)a.H && (unsigned)w < (unsigned)a.W)
+            vb = a.x[(((long long)n * a.H + h) * a.W + w) * a.C + c];
+        }
+      }
+      As[kk][jl] = va;
+      Bs[kk][jl] = vb;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float4 av = *reinterpret_cast<const float4*>(&As[kk][ty * 4]);
+      const float4 bv = *reinterpret_cast<const float4*>(&Bs[kk][tx * 4]);
+      const float aa[4] = {av.x, av.y, av.z, av.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[i][q] = fmaf(aa[i], bb[q], acc[i][q]);
+    }
+    __syncthreads();
+  }
+  float* slab = a.slabs + (size_t)blockIdx.z * a.K * RSC;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int k = k0 + ty * 4 + i;
+    if (k >= a.K) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int col = j0 + tx * 4 + q;
+      if (col < RSC) slab[(size_t)k * RSC + col] = acc[i][q];
+    }
+  }
+}
+
+// dw OIHW [K][C][R][S] = sum over slabs (in slab order, double) of slab[z][k][(r, s, c)]
+__global__ __launch_bounds__(FT) void f32_wgrad_finalize(const float* __restrict__ slabs, int Z, int K, int C, int RS,
+                                                        float* __restrict__ dw) {
+  const size_t total = (size_t)K * C * RS;
+  for (size_t i = (size_t)blockIdx.x * FT + threadIdx.x; i < total; i += (size_t)gridDim.x * FT) {
+    const int rs = (int)(i % RS);
+    const size_t t = i / RS;
+    const int c = (int)(t % C), k = (int)(t / C);
+    double v = 0.0;
+    for (int z = 0; z < Z; ++z) v += (double)slabs[((size_t)z * K + k) * ((size_t)RS * C) + (size_t)rs * C + c];
+    dw[i] = (float)v;
   }
 }
 
@@ -409,6 +525,143 @@ __global__ __launch_bounds__(FT) void f32_center_update(float* __restrict__ cent
   center[d] = center[d] * momentum + (1.f - momentum) * (float)(s / rows);
 }
 
+// ---- backward pieces of the ResNet / head path (the float32 preset can take a whole SimCLR optimiser step)
+// BatchNorm backward sums: per (group, channel) s1 = sum gm, s2 = sum gm * xhat over the group's rows, gm = the incoming
+// gradient taken through the ReLU (out > 0) when `out` is given; doubles, row slices as f32_colsums.
+__global__ __launch_bounds__(FT) void f32_bn_bwd_sums(const float* __restrict__ y, const float* __restrict__ g,
+                                                     const float* __restrict__ out, const float* __restrict__ mean,
+                                                     const float* __restrict__ invstd, long long rpg, int C, int RB,
+                                                     double* __restrict__ part) {  // [G][RB][2][C]
+  __shared__ double red[2][8][32];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + tx, gi = blockIdx.y, rb = blockIdx.z;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    const float mu = mean[(size_t)gi * C + c], is = invstd[(size_t)gi * C + c];
+    for (long long r = (long long)rb * 8 + ty; r < rpg; r += (long long)RB * 8) {
+      const size_t o = ((size_t)gi * rpg + r) * C + c;
+      float gv = g[o];
+      if (out != nullptr && !(out[o] > 0.f)) gv = 0.f;
+      s1 += (double)gv;
+      s2 += (double)gv * (double)((y[o] - mu) * is);
+    }
+  }
+  red[0][ty][tx] = s1;
+  red[1][ty][tx] = s2;
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    double a = 0.0, b = 0.0;
+    for (int i = 0; i < 8; ++i) {
+      a += red[0][i][tx];
+      b += red[1][i][tx];
+    }
+    part[(((size_t)gi * RB + rb) * 2 + 0) * C + c] = a;
+    part[(((size_t)gi * RB + rb) * 2 + 1) * C + c] = b;
+  }
+}
+
+// coef [G][2][C] = (s1 / rows, s2 / rows); dgamma = sum over groups of s2, dbeta = sum of s1
+__global__ __launch_bounds__(FT) void f32_bn_bwd_finalize(const double* __restrict__ part, int RB, int G, int C, long long rpg,
+                                                         float* __restrict__ coef, float* __restrict__ dgamma,
+                                                         float* __restrict__ dbeta) {
+  const int c = blockIdx.x * FT + threadIdx.x;
+  if (c >= C) return;
+  double tg = 0.0, tb = 0.0;
+  for (int g = 0; g < G; ++g) {
+    double s1 = 0.0, s2 = 0.0;
+    for (int rb = 0; rb < RB; ++rb) {
+      s1 += part[(((size_t)g * RB + rb) * 2 + 0) * C + c];
+      s2 += part[(((size_t)g * RB + rb) * 2 + 1) * C + c];
+    }
+    coef[((size_t)g * 2 + 0) * C + c] = (float)(s1 / (double)rpg);
+    coef[((size_t)g * 2 + 1) * C + c] = (float)(s2 / (double)rpg);
+    tb += s1;
+    tg += s2;
+  }
+  if (dgamma) dgamma[c] = (float)tg;
+  if (dbeta) dbeta[c] = (float)tb;
+}
+
+// dy = gamma * invstd * (gm - mean(gm) - xhat * mean(gm * xhat)); dz (gradient of the residual branch) = gm
+__global__ __launch_bounds__(FT) void f32_bn_bwd_apply(const float* __restrict__ y, const float* __restrict__ g,
+                                                      const float* __restrict__ out, const float* __restrict__ gamma,
+                                                      const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                      const float* __restrict__ coef, long long rows, int C, long long rpg,
+                                                      float* __restrict__ dy, float* __restrict__ dz) {
+  const long long total = rows * C;
+  for (long long i = (long long)blockIdx.x * FT + threadIdx.x; i < total; i += (long long)gridDim.x * FT) {
+    const long long r = i / C;
+    const int c = (int)(i - r * C);
+    const int gi = (int)(r / rpg);
+    float gv = g[i];
+    if (out != nullptr && !(out[i] > 0.f)) gv = 0.f;
+    const float is = invstd[(size_t)gi * C + c];
+    const float xh = (y[i] - mean[(size_t)gi * C + c]) * is;
+    const float c1 = coef[((size_t)gi * 2 + 0) * C + c], c2 = coef[((size_t)gi * 2 + 1) * C + c];
+    dy[i] = (gamma ? gamma[c] : 1.f) * is * (gv - c1 - xh * c2);
+    if (dz) dz[i] = gv;
+  }
+}
+
+// max-pool 3x3 / stride 2 / pad 1 backward: every input element collects the gradient of the windows whose FIRST maximum
+// (scan order, strict >, as torch's forward records it) it is
+__global__ __launch_bounds__(FT) void f32_maxpool3x3s2_bwd(const float* __restrict__ x, const float* __restrict__ dy, int N,
+                                                          int H, int W, int C, int P, int Q, float* __restrict__ dx) {
+  const long long total = (long long)N * H * W * C;
+  for (long long i = (long long)blockIdx.x * FT + threadIdx.x; i < total; i += (long long)gridDim.x * FT) {
+    const int c = (int)(i % C);
+    long long t = i / C;
+    const int w = (int)(t % W);
+    t /= W;
+    const int h = (int)(t % H), n = (int)(t / H);
+    float acc = 0.f;
+    // windows p with 2p - 1 <= h <= 2p + 1: p in {ceil((h - 1) / 2), ..., floor((h + 1) / 2)} (the loop re-checks)
+    const int p_lo = h / 2, p_hi = (h + 1) / 2;
+    const int q_lo = w / 2, q_hi = (w + 1) / 2;
+    for (int p = p_lo; p <= p_hi; ++p) {
+      if (p >= P || 2 * p - 1 > h || 2 * p + 1 < h) continue;
+      for (int q = q_lo; q <= q_hi; ++q) {
+        if (q >= Q || 2 * q - 1 > w || 2 * q + 1 < w) continue;
+        float best = -INFINITY;
+        int bh = -1, bw = -1;
+        for (int r = 0; r < 3; ++r)
+          for (int s = 0; s < 3; ++s) {
+            const int hh = 2 * p - 1 + r, ww = 2 * q - 1 + s;
+            if ((unsigned)hh < (unsigned)H && (unsigned)ww < (unsigned)W) {
+              const float v = x[(((long long)n * H + hh) * W + ww) * C + c];
+              if (v > best || bh < 0) {
+                best = v;
+                bh = hh;
+                bw = ww;
+              }
+            }
+          }
+        if (bh == h && bw == w) acc += dy[(((long long)n * P + p) * Q + q) * C + c];
+      }
+    }
+    dx[i] = acc;
+  }
+}
+
+__global__ __launch_bounds__(FT) void f32_gap_bwd(const float* __restrict__ dy, int N, int HW, int C, float* __restrict__ dx) {
+  const long long total = (long long)N * HW * C;
+  const float inv = 1.f / (float)HW;
+  for (long long i = (long long)blockIdx.x * FT + threadIdx.x; i < total; i += (long long)gridDim.x * FT) {
+    const int c = (int)(i % C);
+    const int n = (int)(i / ((long long)HW * C));
+    dx[i] = dy[(size_t)n * C + c] * inv;
+  }
+}
+
+// out[c] = sum over rows of x[r][c] (bias gradients): one thread per column, double
+__global__ __launch_bounds__(FT) void f32_colsum(const float* __restrict__ x, long long rows, int C, float* __restrict__ out) {
+  const int c = blockIdx.x * FT + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (long long r = 0; r < rows; ++r) s += (double)x[r * C + c];
+  out[c] = (float)s;
+}
+
 inline int grid_for(long long items) {
   long long b = (items + FT - 1) / FT;
   if (b > 65535) b = 65535;
@@ -437,8 +690,8 @@ extern "C" int wm_f32_conv2d_fwd(const float* x, const float* w_oihw, const floa
   float* wt = static_cast<float*>(workspace);
   f32_weights_qk<<<grid_for((long long)K * C * R * S), FT, 0, st>>>(w_oihw, K, C, R * S, wt);
   WM_LAUNCH_CHECK();
-  F32Conv a{x, wt, bias, residual, y, N, H, W, C, K, R, S, P, Q, stride, pad, act};
-  f32_conv_fwd<<<dim3((unsigned)((M + 63) / 64), (unsigned)((K + 63) / 64)), FT, 0, st>>>(a);
+  F32Conv a{x, wt, bias, residual, y, N, H, W, C, P, Q, K, R, S, stride, pad, act};
+  f32_conv_kernel<false><<<dim3((unsigned)((M + 63) / 64), (unsigned)((K + 63) / 64)), FT, 0, st>>>(a);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }
@@ -556,6 +809,97 @@ extern "C" int wm_f32_reduce(const float* a, const float* b, long long n, int mo
 extern "C" int wm_f32_center_update(float* center, const float* teacher, int rows, int D, float momentum, void* stream) {
   WM_REQUIRE(center && teacher && rows > 0 && D > 0, WM_EINVAL);
   f32_center_update<<<(D + FT - 1) / FT, FT, 0, static_cast<hipStream_t>(stream)>>>(center, teacher, rows, D, momentum);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_conv2d_dgrad(const float* dy, const float* w_oihw, float* dx, int N, int H, int W, int C, int K, int R, int S,
+                                   int P, int Q, int stride, int pad, void* workspace, size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(dy && w_oihw && dx && workspace, WM_EINVAL);
+  WM_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0, WM_EINVAL);
+  WM_REQUIRE(P == (H + 2 * pad - R) / stride + 1 && Q == (W + 2 * pad - S) / stride + 1 && P > 0 && Q > 0, WM_EINVAL);
+  WM_REQUIRE(workspace_bytes >= wm_f32_conv2d_workspace_bytes(C, K, R, S), WM_EWORKSPACE);
+  const long long M = (long long)N * H * W;
+  WM_REQUIRE((M + 63) / 64 < (1ll << 31) && (long long)R * S * K < (1ll << 31), WM_EUNSUPPORTED);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  float* wt = static_cast<float*>(workspace);
+  f32_weights_qc<<<grid_for((long long)K * C * R * S), FT, 0, st>>>(w_oihw, K, C, R * S, wt);
+  WM_LAUNCH_CHECK();
+  // rows = input pixels, source = the output gradient [N][P][Q][K], reduction over (tap, output channel)
+  F32Conv a{dy, wt, nullptr, nullptr, dx, N, P, Q, K, H, W, C, R, S, stride, pad, 0};
+  f32_conv_kernel<true><<<dim3((unsigned)((M + 63) / 64), (unsigned)((C + 63) / 64)), FT, 0, st>>>(a);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+static int f32_wgrad_slabs(long long M) {
+  long long z = (M + 4095) / 4096;
+  if (z > 256) z = 256;
+  if (z < 1) z = 1;
+  return (int)z;
+}
+
+extern "C" size_t wm_f32_conv2d_wgrad_workspace_bytes(int N, int P, int Q, int C, int K, int R, int S) {
+  if (N <= 0 || P <= 0 || Q <= 0 || C <= 0 || K <= 0 || R <= 0 || S <= 0) return 0;
+  return (size_t)f32_wgrad_slabs((long long)N * P * Q) * K * R * S * C * sizeof(float);
+}
+
+extern "C" int wm_f32_conv2d_wgrad(const float* dy, const float* x, float* dw_oihw, int N, int H, int W, int C, int K, int R,
+                                   int S, int P, int Q, int stride, int pad, void* workspace, size_t workspace_bytes,
+                                   void* stream) {
+  WM_REQUIRE(dy && x && dw_oihw && workspace, WM_EINVAL);
+  WM_REQUIRE(N > 0 && H > 0 && W > 0 && C > 0 && K > 0 && R > 0 && S > 0 && stride > 0 && pad >= 0, WM_EINVAL);
+  WM_REQUIRE(P == (H + 2 * pad - R) / stride + 1 && Q == (W + 2 * pad - S) / stride + 1 && P > 0 && Q > 0, WM_EINVAL);
+  WM_REQUIRE(workspace_bytes >= wm_f32_conv2d_wgrad_workspace_bytes(N, P, Q, C, K, R, S), WM_EWORKSPACE);
+  const long long M = (long long)N * P * Q;
+  const int Z = f32_wgrad_slabs(M);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  F32Wgrad a{dy, x, static_cast<float*>(workspace), N, H, W, C, K, R, S, P, Q, stride, pad, (M + Z - 1) / Z};
+  f32_conv_wgrad<<<dim3((K + 63) / 64, (R * S * C + 63) / 64, Z), FT, 0, st>>>(a);
+  WM_LAUNCH_CHECK();
+  f32_wgrad_finalize<<<grid_for((long long)K * C * R * S), FT, 0, st>>>(static_cast<const float*>(workspace), Z, K, C, R * S, dw_oihw);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_colsum(const float* x, long long rows, int C, float* out, void* stream) {
+  WM_REQUIRE(x && out && rows > 0 && C > 0, WM_EINVAL);
+  f32_colsum<<<(C + FT - 1) / FT, FT, 0, static_cast<hipStream_t>(stream)>>>(x, rows, C, out);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_bn_bwd(const float* y, const float* dout, const float* out_relu, const float* gamma, const float* save_mean,
+                             const float* save_invstd, long long rows, int C, int G, float* dgamma, float* dbeta, float* dy,
+                             float* dz, void* workspace, size_t workspace_bytes, void* stream) {
+  WM_REQUIRE(y && dout && save_mean && save_invstd && dy && workspace, WM_EINVAL);
+  WM_REQUIRE(rows > 0 && C > 0 && G > 0 && rows % G == 0, WM_EINVAL);
+  WM_REQUIRE(workspace_bytes >= wm_f32_bn_workspace_bytes(rows, C, G), WM_EWORKSPACE);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  const int RB = 64;
+  double* part = static_cast<double*>(workspace);
+  float* coef = reinterpret_cast<float*>(part + (size_t)G * RB * 2 * C);   // [G][2][C]: the forward's scale / shift space
+  const long long rpg = rows / G;
+  f32_bn_bwd_sums<<<dim3((C + 31) / 32, G, RB), FT, 0, st>>>(y, dout, out_relu, save_mean, save_invstd, rpg, C, RB, part);
+  WM_LAUNCH_CHECK();
+  f32_bn_bwd_finalize<<<(C + FT - 1) / FT, FT, 0, st>>>(part, RB, G, C, rpg, coef, dgamma, dbeta);
+  WM_LAUNCH_CHECK();
+  f32_bn_bwd_apply<<<grid_for(rows * C), FT, 0, st>>>(y, dout, out_relu, gamma, save_mean, save_invstd, coef, rows, C, rpg, dy, dz);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_maxpool3x3s2_bwd(const float* x, const float* dy, int N, int H, int W, int C, float* dx, void* stream) {
+  WM_REQUIRE(x && dy && dx && N > 0 && H > 0 && W > 0 && C > 0, WM_EINVAL);
+  const int P = (H - 1) / 2 + 1, Q = (W - 1) / 2 + 1;
+  f32_maxpool3x3s2_bwd<<<grid_for((long long)N * H * W * C), FT, 0, static_cast<hipStream_t>(stream)>>>(x, dy, N, H, W, C, P, Q, dx);
+  WM_LAUNCH_CHECK();
+  return WM_OK;
+}
+
+extern "C" int wm_f32_gap_bwd(const float* dy, int N, int HW, int C, float* dx, void* stream) {
+  WM_REQUIRE(dy && dx && N > 0 && HW > 0 && C > 0, WM_EINVAL);
+  f32_gap_bwd<<<grid_for((long long)N * HW * C), FT, 0, static_cast<hipStream_t>(stream)>>>(dy, N, HW, C, dx);
   WM_LAUNCH_CHECK();
   return WM_OK;
 }

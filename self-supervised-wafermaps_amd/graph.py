@@ -141,13 +141,15 @@ class GraphedTrainStep:
             ts += [t for t in (a.momentum, a.second) if t is not None]
         return ts
 
-    def capture(self, sample_idx: np.ndarray, rng: np.random.Generator, sync=None, restore: bool = True):
+    def capture(self, sample_idx: np.ndarray, rng: np.random.Generator, sync=None, restore: bool = True, timer=None):
         """Warm up eagerly on a side stream, then record the graph(s) (torch.cuda.graph).  `sync` (a
         distributed.GradSync) keeps the warm-up steps data-parallel: without the gradient exchange the
         replicas' weights would drift apart before the first captured step.
         restore: the warm-up steps (and the capture pass itself) are real optimiser steps on the first batch; with
         restore=True the training state is put back afterwards (parameters, buffers, moments, step counters), so a
-        graph-replayed run is step-for-step the eager run -- only torch's RNG stream has advanced."""
+        graph-replayed run is step-for-step the eager run -- only torch's RNG stream has advanced.
+        timer: an ops.KernelTimer(external=True): its brackets are recorded INSIDE the captured graph(s) as event-record
+        nodes (not around the eager warm-up), so every replay times its own MFMA launches."""
         params = self.tr.sample(self.ds.store, np.asarray(sample_idx), rng)
         snap = None
         if restore:
@@ -176,21 +178,25 @@ class GraphedTrainStep:
         # thread_local: other threads of the process (the RCCL watchdog of torch.distributed polls its
         # events while we record) must not invalidate the capture
         g0 = torch.cuda.CUDAGraph()
-        if not self.staged:
-            with torch.cuda.graph(g0, capture_error_mode="thread_local"):
-                self.loss = self._body()
-            self.graphs = [g0]
-        else:
-            with torch.cuda.graph(g0, capture_error_mode="thread_local"):
-                self.loss, cuts = self._forward()
-                self._backward(self.loss)
-            self.graphs = [g0]
-            self._cuts = cuts   # keeps the stage-boundary activations and their gradients alive in the pool
-            for _, x, leaf in reversed(cuts):
-                gk = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(gk, pool=g0.pool(), capture_error_mode="thread_local"):
-                    x.backward(leaf.grad)
-                self.graphs.append(gk)
+        old_timer, ops.TIMER = ops.TIMER, (timer if timer is not None else ops.TIMER)
+        try:
+            if not self.staged:
+                with torch.cuda.graph(g0, capture_error_mode="thread_local"):
+                    self.loss = self._body()
+                self.graphs = [g0]
+            else:
+                with torch.cuda.graph(g0, capture_error_mode="thread_local"):
+                    self.loss, cuts = self._forward()
+                    self._backward(self.loss)
+                self.graphs = [g0]
+                self._cuts = cuts   # keeps the stage-boundary activations and their gradients alive in the pool
+                for _, x, leaf in reversed(cuts):
+                    gk = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(gk, pool=g0.pool(), capture_error_mode="thread_local"):
+                        x.backward(leaf.grad)
+                    self.graphs.append(gk)
+        finally:
+            ops.TIMER = old_timer
         self.graph = g0
         if snap is not None:
             # (the capture pass enqueues nothing, but the warm-up steps ran: undo them)

@@ -21,28 +21,52 @@ _WEIGHT_EPOCH = 0  # bumped by optimisers that update parameters through raw poi
 
 
 class KernelTimer:
-    """HIP-event bracket around selected launches (bench.py's live roofline measurement): events
-    are recorded on the stream the kernel is enqueued on, elapsed times are read after a sync."""
+    """HIP-event bracket around selected launches (bench.py's live roofline measurement): events are recorded on the
+    stream the kernel is enqueued on, elapsed times are read after a sync.
+    external=True: the events become event-record NODES when the launches are captured into a hipGraph
+    (torch.cuda.Event(external=True)): the brackets then time the kernels of a REPLAYED step -- the configuration the
+    benchmark times -- without the host gaps an eager step of 10 - 60 us launches has on a slow host.  After every
+    replay (and a synchronize) call accumulate()."""
 
-    def __init__(self):
+    def __init__(self, external: bool = False):
         self.records = []  # (name, algorithmic work, start event, end event)
+        self.external = external
+        self.sums = None   # external mode: per-record elapsed ms summed over the replays seen by accumulate()
+        self.replays = 0
 
     def run(self, name, work, fn, *args):
-        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if self.external:
+            a = torch.cuda.Event(enable_timing=True, external=True)
+            b = torch.cuda.Event(enable_timing=True, external=True)
+        else:
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         a.record()
         rc = fn(*args)
         b.record()
         self.records.append((name, work, a, b))
         return rc
 
+    def accumulate(self) -> None:
+        """external mode: read every bracket of the replay that has just completed."""
+        if self.sums is None:
+            self.sums = [0.0] * len(self.records)
+        for i, (_, _, a, b) in enumerate(self.records):
+            self.sums[i] += a.elapsed_time(b)
+        self.replays += 1
+
     def summary(self, overhead_ms: float = 0.0):
         """Per name: launches, work and bracketed time; `overhead_ms` (see bracket_overhead_ms) is subtracted per launch."""
         out = {}
-        for name, work, a, b in self.records:
+        for i, (name, work, a, b) in enumerate(self.records):
             d = out.setdefault(name, {"launches": 0, "work": 0.0, "ms": 0.0})
-            d["launches"] += 1
-            d["work"] += work
-            d["ms"] += max(a.elapsed_time(b) - overhead_ms, 0.0)
+            if self.sums is not None:   # external mode: `replays` executions of the same captured launch
+                d["launches"] += self.replays
+                d["work"] += work * self.replays
+                d["ms"] += max(self.sums[i] - overhead_ms * self.replays, 0.0)
+            else:
+                d["launches"] += 1
+                d["work"] += work
+                d["ms"] += max(a.elapsed_time(b) - overhead_ms, 0.0)
         return out
 
     @staticmethod
@@ -328,12 +352,21 @@ def _slab_buffers(owner: torch.Tensor, nsplit: int, numel: int, bias_k: int = 0)
     while len(bufs) <= idx:
         bufs.append(None)
     ent = bufs[idx]
+    capturing = owner.is_cuda and torch.cuda.is_current_stream_capturing()
     if (ent is None or ent[0].numel() != nsplit * numel or ent[0].device != owner.device
             or (bias_k > 0 and (ent[1] is None or ent[1].numel() != nsplit * bias_k))):
-        ent = (torch.empty(nsplit * numel, dtype=torch.float32, device=owner.device),
-               torch.empty(nsplit * bias_k, dtype=torch.float32, device=owner.device) if bias_k > 0 else None)
+        if ent is not None and ent[2]:
+            # (as StatSlots.get: the slabs a captured graph writes stay alive beside their replacement)
+            retired = getattr(owner, "_hip_wgrad_retired", None)
+            if retired is None:
+                retired = owner._hip_wgrad_retired = []
+            retired.append(ent)
+        ent = [torch.empty(nsplit * numel, dtype=torch.float32, device=owner.device),
+               torch.empty(nsplit * bias_k, dtype=torch.float32, device=owner.device) if bias_k > 0 else None, False]
         bufs[idx] = ent
-    return ent
+    if capturing:
+        ent[2] = True
+    return ent[0], ent[1]
 
 
 # ---- weight gradients on a SIDE stream.  Nothing in the backward chain waits for a weight gradient: only the fold at
@@ -525,9 +558,18 @@ class StatSlots:
         self._hip_busy = None
 
     def get(self, groups: int, tiles: int, device) -> torch.Tensor:
+        capturing = torch.cuda.is_current_stream_capturing()
         if self.buf is None or self.tiles != tiles or self.groups != groups or self.buf.device != device:
+            if getattr(self, "_captured", False):
+                # a captured hipGraph writes / reads the old buffer at every replay: it is kept alive beside the new one
+                # (another batch size run eagerly while the graph exists must not hand its memory back to the allocator
+                # under the graph)
+                self.__dict__.setdefault("_retired", []).append(self.buf)
+                self._captured = False
             self.buf = torch.empty((groups, tiles, 2, self.channels), dtype=torch.float32, device=device)
             self.tiles, self.groups = tiles, groups
+        if capturing:
+            self._captured = True
         return self.buf
 
 

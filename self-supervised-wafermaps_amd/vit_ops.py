@@ -38,15 +38,22 @@ def _zeros(shape, dtype, device) -> torch.Tensor:
 
 
 _INDEX_CACHE = {}
+_INDEX_PINNED = set()   # keys looked up while a hipGraph was being captured: their device address is baked into the graph
 
 
 def cached_index(key, build) -> torch.Tensor:
-    """A constant int64 index tensor (class-token rows, patch rows of a token grid) built once per (shape, device)."""
+    """A constant int64 index tensor (class-token rows, patch rows of a token grid) built once per (shape, device).
+    An entry used during a hipGraph capture is never evicted (the captured kernels read it at every replay: an evicted
+    tensor's block would return to the caching allocator and be recycled under the graph)."""
     t = _INDEX_CACHE.get(key)
+    capturing = torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()
     if t is None:
         if len(_INDEX_CACHE) > 256:
-            _INDEX_CACHE.clear()
+            for k in [k for k in _INDEX_CACHE if k not in _INDEX_PINNED][:128]:
+                del _INDEX_CACHE[k]
         t = _INDEX_CACHE[key] = build()
+    if capturing:
+        _INDEX_PINNED.add(key)
     return t
 
 
