@@ -626,7 +626,7 @@ int wm_matmul_f32(const float* a, const float* b, float* c, int M, int N, int K,
  * weight and accumulator in float32 (reference call sites scripts/WM811k_benchmark.py:236-248, :578-588, :902-947).  The
  * production kernels keep activations in bf16; profiles/r04_error_budget_bf16.md shows that storage puts the step losses
  * 0.4e-4 .. 3.4e-4 from the float32 reference (north_star: 1e-4).  These entry points keep them in float32: a validation
- * preset (forward only), selected by ssl_wafermap_amd.precision("float32").  Activations NHWC float32 / [rows][C]. */
+ * preset (forward for all three models, backward for the ResNet-18 / head ops), selected by ssl_wafermap_amd.precision("float32").  Activations NHWC float32 / [rows][C]. */
 size_t wm_f32_conv2d_workspace_bytes(int C, int K, int R, int S);
 /* y = act(conv(x, w) + bias) + residual: x [N][H][W][C], w_oihw [K][C][R][S] (the float32 master layout), bias [K] or NULL,
  * residual [N][P][Q][K] or NULL, act 0 none / 1 GELU (erf) / 2 ReLU.  A Linear layer is the 1x1 case on a 1x1 image. */

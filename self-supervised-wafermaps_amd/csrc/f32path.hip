@@ -8,7 +8,8 @@
 // bf16 autocast of the oracle code lands at (profiles/r04_bf16_gradient_noise.md).  This file is the preset that keeps
 // those activations in float32: same module tree, same state_dict, same call sites
 // (scripts/WM811k_benchmark.py:236-248 SimCLR, :578-588 DINOViT, :902-947 MAE), plain loops instead of MFMA tiles.
-// It is a validation preset (forward only, ~50x slower than the bf16 path), not a training path.
+// It is a validation preset (~50x slower than the bf16 path): forward for all three models, backward for the ResNet-18 /
+// projection-head ops (whole SimCLR optimiser steps follow the oracle to 1e-5).
 //
 // Layouts: activations NHWC float32 ([rows][C] for token / feature matrices), weights in their float32 master layout
 // (OIHW / [K][C]); the implicit-GEMM kernel reads them through a [R*S*C][K] copy made per call.

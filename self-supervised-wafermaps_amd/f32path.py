@@ -1,6 +1,8 @@
 """Float32 ("parity") preset: tensor-level wrappers over the wm_f32_* entry points (csrc/f32path.hip).
 
-Forward only.  Activations are float32: images / feature maps [N, C, H, W] in channels_last memory (NHWC), token and
+The convolution / BatchNorm / pooling / Linear ops (the ResNet-18 + projection-head path) have backward passes, so a whole SimCLR
+optimiser step runs under the preset; the transformer-specific ops (LayerNorm, attention, fused activations, the DINO / MSE losses) are
+forward-only and say so when differentiated.  Activations are float32: images / feature maps [N, C, H, W] in channels_last memory (NHWC), token and
 feature matrices [rows, C]; parameters are used in their float32 master layout.  torch moves data here (cat, index
 gather / scatter, reshape); every FLOP runs in the HIP kernels.  See precision.py for why the preset exists."""
 from __future__ import annotations
@@ -61,84 +63,172 @@ def _workspace(nbytes: int, device) -> torch.Tensor:
     return ws
 
 
+class _Conv2d(torch.autograd.Function):
+    """y = act(conv(x, w) + bias) + residual on NHWC float32; backward (act = none): input gradient, weight gradient (pixel
+    ranges summed in a fixed order), bias gradient = column sums, residual gradient = dy."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, residual, stride, padding, act):
+        xs = as_nhwc(x)
+        n, c, h, w = xs.shape
+        k, c2, r, s = weight.shape
+        if c2 != c:
+            raise ValueError(f"conv2d: input channels {c} vs weight {tuple(weight.shape)}")
+        p, q = (h + 2 * padding - r) // stride + 1, (w + 2 * padding - s) // stride + 1
+        y = torch.empty((n, p, q, k), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+        lib = _lib.load()
+        ws = _workspace(lib.wm_f32_conv2d_workspace_bytes(c, k, r, s), x.device)
+        res = as_nhwc(residual) if residual is not None else None
+        wf = _f32(weight)
+        check(lib.wm_f32_conv2d_fwd(ptr(xs), ptr(wf), ptr(_f32(bias)), ptr(res), ptr(y), n, h, w, c, k, r, s, p, q, stride,
+                                    padding, int(act), ptr(ws), ws.numel(), stream_ptr()), "wm_f32_conv2d_fwd")
+        ctx.save_for_backward(xs, wf)
+        ctx.geom = (n, h, w, c, k, r, s, p, q, stride, padding)
+        ctx.act, ctx.has_bias, ctx.has_res = int(act), bias is not None, residual is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        if ctx.act != ACT_NONE:
+            raise NotImplementedError("float32 preset: no backward through a fused activation (the transformer path is forward-only)")
+        xs, wf = ctx.saved_tensors
+        n, h, w, c, k, r, s, p, q, stride, padding = ctx.geom
+        dy = as_nhwc(dy)
+        lib = _lib.load()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device).permute(0, 3, 1, 2)
+            ws = _workspace(lib.wm_f32_conv2d_workspace_bytes(c, k, r, s), dy.device)
+            check(lib.wm_f32_conv2d_dgrad(ptr(dy), ptr(wf), ptr(dx), n, h, w, c, k, r, s, p, q, stride, padding, ptr(ws),
+                                          ws.numel(), stream_ptr()), "wm_f32_conv2d_dgrad")
+        if ctx.needs_input_grad[1]:
+            dw = torch.empty((k, c, r, s), dtype=torch.float32, device=dy.device)
+            ws = _workspace(lib.wm_f32_conv2d_wgrad_workspace_bytes(n, p, q, c, k, r, s), dy.device)
+            check(lib.wm_f32_conv2d_wgrad(ptr(dy), ptr(xs), ptr(dw), n, h, w, c, k, r, s, p, q, stride, padding, ptr(ws),
+                                          ws.numel(), stream_ptr()), "wm_f32_conv2d_wgrad")
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            db = torch.empty((k,), dtype=torch.float32, device=dy.device)
+            check(lib.wm_f32_colsum(ptr(dy), n * p * q, k, ptr(db), stream_ptr()), "wm_f32_colsum")
+        return dx, dw, db, (dy if ctx.has_res else None), None, None, None
+
+
 def conv2d(x, weight, stride=1, padding=0, bias=None, act=ACT_NONE, residual=None):
     _cuda(x, "conv2d(float32)")
-    xs = as_nhwc(x)
-    n, c, h, w = xs.shape
-    k, c2, r, s = weight.shape
-    if c2 != c:
-        raise ValueError(f"conv2d: input channels {c} vs weight {tuple(weight.shape)}")
-    p, q = (h + 2 * padding - r) // stride + 1, (w + 2 * padding - s) // stride + 1
-    y = torch.empty((n, p, q, k), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
-    lib = _lib.load()
-    need = lib.wm_f32_conv2d_workspace_bytes(c, k, r, s)
-    ws = _workspace(need, x.device)
-    res = as_nhwc(residual) if residual is not None else None
-    check(lib.wm_f32_conv2d_fwd(ptr(xs), ptr(_f32(weight)), ptr(_f32(bias)), ptr(res), ptr(y), n, h, w, c, k, r, s, p, q, stride,
-                                padding, int(act), ptr(ws), ws.numel(), stream_ptr()), "wm_f32_conv2d_fwd")
-    return _mark(y, x, weight, bias, residual)
+    return _Conv2d.apply(x, weight, bias, residual, int(stride), int(padding), int(act))
 
 
 def linear(x, weight, bias=None, act=ACT_NONE, residual=None):
+    """act(x @ W^T + bias) + residual on [rows, C]: the 1 x 1 convolution on a 1 x 1 image (same kernels, same backward)."""
     _cuda(x, "linear(float32)")
     if x.dim() != 2 or weight.dim() != 2 or x.shape[1] != weight.shape[1]:
         raise ValueError(f"linear: x {tuple(x.shape)} vs weight {tuple(weight.shape)}")
-    xs = _f32(x)
-    rows, c = xs.shape
+    rows, c = x.shape
     k = weight.shape[0]
-    y = torch.empty((rows, k), dtype=torch.float32, device=x.device)
-    lib = _lib.load()
-    need = lib.wm_f32_conv2d_workspace_bytes(c, k, 1, 1)
-    ws = _workspace(need, x.device)
-    check(lib.wm_f32_conv2d_fwd(ptr(xs), ptr(_f32(weight)), ptr(_f32(bias)), ptr(_f32(residual)), ptr(y), rows, 1, 1, c, k, 1, 1, 1,
-                                1, 1, 0, int(act), ptr(ws), ws.numel(), stream_ptr()), "wm_f32_conv2d_fwd(linear)")
-    return _mark(y, x, weight, bias, residual)
+    res4 = residual.reshape(rows, k, 1, 1) if residual is not None else None
+    y = _Conv2d.apply(x.reshape(rows, c, 1, 1), weight.reshape(k, c, 1, 1), bias, res4, 1, 0, int(act))
+    return y.reshape(rows, k)
+
+
+class _BatchNorm(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y, residual, gamma, beta, running_mean, running_var, training, relu, eps, momentum, groups, counter):
+        four = y.dim() == 4
+        ys = as_nhwc(y) if four else _f32(y)
+        if four:
+            n, c, h, w = ys.shape
+            rows = n * h * w
+        else:
+            rows, c = ys.shape
+        g = groups if training else 1
+        if rows % g:
+            raise ValueError("batch_norm: rows not divisible by groups")
+        res = None
+        if residual is not None:
+            res = as_nhwc(residual) if four else _f32(residual)
+        out = torch.empty_like(ys)
+        mean = torch.empty((g, c), dtype=torch.float32, device=y.device)
+        invstd = torch.empty_like(mean)
+        lib = _lib.load()
+        ws = _workspace(lib.wm_f32_bn_workspace_bytes(rows, c, g), y.device)
+        check(lib.wm_f32_bn_fwd(ptr(ys), ptr(res), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
+                                ptr(counter) if training else 0, rows, c, g, int(bool(training)), float(eps),
+                                float(momentum), int(bool(relu)), ptr(mean), ptr(invstd), ptr(out), ptr(ws), ws.numel(),
+                                stream_ptr()), "wm_f32_bn_fwd")
+        ctx.save_for_backward(ys, out if relu else None, mean, invstd, _f32(gamma))
+        ctx.meta = (rows, c, g, bool(training), residual is not None, gamma is not None and gamma.requires_grad)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        ys, out, mean, invstd, gamma = ctx.saved_tensors
+        rows, c, g, training, has_res, affine = ctx.meta
+        if not training:
+            raise NotImplementedError("batch_norm (float32 preset): backward through eval-mode statistics is not implemented")
+        dout = as_nhwc(dout) if dout.dim() == 4 else _f32(dout)
+        lib = _lib.load()
+        dy = torch.empty_like(ys)
+        dz = torch.empty_like(ys) if has_res else None
+        dgamma = torch.empty((c,), dtype=torch.float32, device=ys.device)
+        dbeta = torch.empty_like(dgamma)
+        ws = _workspace(lib.wm_f32_bn_workspace_bytes(rows, c, g), ys.device)
+        check(lib.wm_f32_bn_bwd(ptr(ys), ptr(dout), ptr(out), ptr(gamma), ptr(mean), ptr(invstd), rows, c, g, ptr(dgamma),
+                                ptr(dbeta), ptr(dy), ptr(dz), ptr(ws), ws.numel(), stream_ptr()), "wm_f32_bn_bwd")
+        return dy, dz, (dgamma if affine else None), (dbeta if affine else None), None, None, None, None, None, None, None, None
 
 
 def batch_norm(y, gamma, beta, running_mean, running_var, training, residual=None, relu=False, eps=1e-5, momentum=0.1,
                groups=1, num_batches_tracked=None):
     _cuda(y, "batch_norm(float32)")
-    four = y.dim() == 4
-    ys = as_nhwc(y) if four else _f32(y)
-    if four:
-        n, c, h, w = ys.shape
-        rows = n * h * w
-    else:
-        rows, c = ys.shape
-    g = groups if training else 1
-    if rows % g:
-        raise ValueError("batch_norm: rows not divisible by groups")
-    res = None
-    if residual is not None:
-        res = as_nhwc(residual) if four else _f32(residual)
-    out = torch.empty_like(ys)
-    mean = torch.empty((g, c), dtype=torch.float32, device=y.device)
-    invstd = torch.empty_like(mean)
-    lib = _lib.load()
-    need = lib.wm_f32_bn_workspace_bytes(rows, c, g)
-    ws = _workspace(need, y.device)
-    check(lib.wm_f32_bn_fwd(ptr(ys), ptr(res), ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var),
-                            ptr(num_batches_tracked) if training else 0, rows, c, g, int(bool(training)), float(eps),
-                            float(momentum), int(bool(relu)), ptr(mean), ptr(invstd), ptr(out), ptr(ws), ws.numel(),
-                            stream_ptr()), "wm_f32_bn_fwd")
-    return _mark(out, y, gamma, beta, residual)
+    return _BatchNorm.apply(y, residual, gamma, beta, running_mean, running_var, bool(training), bool(relu), float(eps),
+                            float(momentum), int(groups), num_batches_tracked)
+
+
+class _MaxPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xs = as_nhwc(x)
+        n, c, h, w = xs.shape
+        p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+        y = torch.empty((n, p, q, c), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
+        check(_lib.load().wm_f32_maxpool3x3s2(ptr(xs), n, h, w, c, ptr(y), stream_ptr()), "wm_f32_maxpool3x3s2")
+        ctx.save_for_backward(xs)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (xs,) = ctx.saved_tensors
+        n, c, h, w = xs.shape
+        dy = as_nhwc(dy)
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device).permute(0, 3, 1, 2)
+        check(_lib.load().wm_f32_maxpool3x3s2_bwd(ptr(xs), ptr(dy), n, h, w, c, ptr(dx), stream_ptr()), "wm_f32_maxpool3x3s2_bwd")
+        return dx
 
 
 def max_pool3x3s2(x):
-    xs = as_nhwc(x)
-    n, c, h, w = xs.shape
-    p, q = (h - 1) // 2 + 1, (w - 1) // 2 + 1
-    y = torch.empty((n, p, q, c), dtype=torch.float32, device=x.device).permute(0, 3, 1, 2)
-    check(_lib.load().wm_f32_maxpool3x3s2(ptr(xs), n, h, w, c, ptr(y), stream_ptr()), "wm_f32_maxpool3x3s2")
-    return _mark(y, x)
+    return _MaxPool.apply(x)
+
+
+class _Gap(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        xs = as_nhwc(x)
+        n, c, h, w = xs.shape
+        y = torch.empty((n, c), dtype=torch.float32, device=x.device)
+        check(_lib.load().wm_f32_gap(ptr(xs), n, h * w, c, ptr(y), stream_ptr()), "wm_f32_gap")
+        ctx.geom = (n, c, h, w)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        n, c, h, w = ctx.geom
+        dy = _f32(dy)
+        dx = torch.empty((n, h, w, c), dtype=torch.float32, device=dy.device).permute(0, 3, 1, 2)
+        check(_lib.load().wm_f32_gap_bwd(ptr(dy), n, h * w, c, ptr(dx), stream_ptr()), "wm_f32_gap_bwd")
+        return dx
 
 
 def global_avg_pool(x):
-    xs = as_nhwc(x)
-    n, c, h, w = xs.shape
-    y = torch.empty((n, c), dtype=torch.float32, device=x.device)
-    check(_lib.load().wm_f32_gap(ptr(xs), n, h * w, c, ptr(y), stream_ptr()), "wm_f32_gap")
-    return _mark(y, x)
+    return _Gap.apply(x)
 
 
 def layer_norm(x, gamma, beta, eps=1e-6):

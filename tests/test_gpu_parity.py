@@ -107,8 +107,6 @@ def test_simclr_bs64_step_under_the_float32_preset_meets_the_contract():
         cz = 1 - F.cosine_similarity(got["z"], torch.cat([z0, z1]), dim=1)
         parity(f"SimCLR bs 64 backbone embeddings, float32 preset (1 - cosine, worst row), seed {seed}", float(cf.max()), 1e-3)
         parity(f"SimCLR bs 64 projections, float32 preset (1 - cosine, worst row), seed {seed}", float(cz.max()), 1e-3)
-        with precision.precision("float32"), pytest.raises(NotImplementedError):
-            model.training_step(((v[:B], v[B:]), None), 0).backward()     # the preset is forward-only and says so
 
 
 def test_resnet18_small_images_projections_under_the_float32_preset():
@@ -141,6 +139,101 @@ def test_resnet18_small_images_projections_under_the_float32_preset():
     cz = 1 - F.cosine_similarity(z.float().cpu(), torch.cat([z0, z1]), dim=1)
     parity("ResNet-18 + SimCLR head projections, bs 32 of 64x64, float32 preset (1 - cosine, worst row)", float(cz.max()), 1e-3)
     parity("ResNet-18 + head + NT-Xent loss, bs 32 of 64x64, float32 preset (relative)", _rel(loss.detach(), ref), 1e-4)
+
+
+def test_simclr_optimiser_steps_under_the_float32_preset_stay_within_float32_noise_of_a_float64_run():
+    """The whole SimCLR step (scripts/WM811k_benchmark.py:242-255: two-view forward, NT-Xent, backward, SGD with momentum and
+    weight decay) under the float32 preset, at three successive points of a training run (bs 32, identical augmentation
+    decisions).  The yardstick is the oracle run in FLOAT64: once the zero-initialised residual BatchNorm scales leave zero
+    (after the first update) the float32 gradient of this network is itself only good to ~1e-2 -- torch's own float32 autograd
+    differs from its float64 autograd by 0.2-1 % per tensor at IDENTICAL parameters on steps 2 and 3
+    (profiles/r04_error_budget_bf16.md, "float32 gradient noise") -- so two float32 implementations cannot be held to 1e-5
+    of each other along a free-running trajectory.  Each step therefore starts from the float64 run's parameters (rounded),
+    and asserts: the loss within 1e-5 of float64; the whole gradient no further from float64 than 3x the float32 oracle's
+    own distance; every tensor of step 1 (where float32 is still well conditioned) within 1e-3 of the float32 oracle; and
+    the fused SGD update, fed its own gradients and momentum, within 1e-6 of the oracle's update rule."""
+    from oracle import resnet as orn
+    from ssl_wafermap_amd import ops, precision
+    from ssl_wafermap_amd.data import WaferMapDataset
+    from ssl_wafermap_amd.data.synthetic import synthetic_wafers
+    from ssl_wafermap_amd.models import SimCLR
+    from ssl_wafermap_amd.transforms import BaseViewTransform, augment_views
+
+    B, steps = 32, 3
+    wafers, labels = synthetic_wafers(128, seed=7)
+    ds = WaferMapDataset(wafers, labels, transform=BaseViewTransform(), device=DEV)
+    torch.manual_seed(0)
+    model = SimCLR(None, 9, batch_size=B, max_epochs=150, log_rep_std=False).to(DEV).train()
+    (opt,), _ = model.configure_optimizers()
+    lr = opt.param_groups[0]["lr"]
+    names = [k for k, _ in model.named_parameters()]
+    sd64 = {k: v.detach().double().cpu().clone() for k, v in model.state_dict().items()}
+    for k in names:
+        sd64[k].requires_grad_(True)
+    bufs64, bufs_own = {}, {}
+    rng = np.random.default_rng(5)
+
+    def flat(gs):
+        return torch.cat([gs[k].reshape(-1).double() for k in names])
+
+    worst_loss = worst_ratio = worst_update = worst_first = 0.0
+    report = []
+    for i in range(steps):
+        idx = (np.arange(B) + i * B) % len(ds)
+        params = ds.transform.sample(ds.store, idx, rng)
+        v = augment_views(ds.store, params[0], fmt="nchw_f32", n_slots=2 * B)
+        vc = v.cpu()
+        # float64 run: the yardstick, and the parameters every float32 evaluation of this step starts from
+        for k in names:
+            sd64[k].grad = None
+        l64, _ = orn.simclr_loss(vc[:B].double(), vc[B:].double(), sd64, 0.5, True)
+        l64.backward()
+        g64 = {k: sd64[k].grad for k in names}
+        # float32 oracle at those parameters
+        sd32 = {k: t.detach().float().clone() for k, t in sd64.items()}
+        for k in names:
+            sd32[k].requires_grad_(True)
+        l32, _ = orn.simclr_loss(vc[:B], vc[B:], sd32, 0.5, True)
+        l32.backward()
+        g32 = {k: sd32[k].grad for k in names}
+        # the HIP float32 preset at those parameters
+        with torch.no_grad():
+            for k, p_ in model.named_parameters():
+                p_.copy_(sd32[k].detach().to(DEV))
+        ops.bump_weight_epoch()
+        opt.zero_grad()
+        with precision.precision("float32"):
+            loss = model.training_step(((v[:B], v[B:]), None), i)
+            loss.backward()
+        gh = {k: p_.grad.detach().float().cpu() for k, p_ in model.named_parameters()}
+        f64 = flat(g64)
+        e_hip = float((flat(gh) - f64).norm() / f64.norm())
+        e_ora = float((flat(g32) - f64).norm() / f64.norm())
+        report.append((i + 1, _rel(loss.detach(), l64.detach()), e_hip, e_ora))
+        worst_loss = max(worst_loss, _rel(loss.detach(), l64.detach()))
+        worst_ratio = max(worst_ratio, e_hip / (3 * e_ora + 1e-6))
+        if i == 0:
+            for k in names:
+                if float(g32[k].norm()) > 1e-12:
+                    worst_first = max(worst_first, float((gh[k] - g32[k]).norm() / g32[k].norm()))
+        # the fused SGD update against the oracle's rule on the same (own) gradients and momentum
+        own = {k: sd32[k].detach().clone() for k in names}
+        opt.step()
+        orn.sgd_step(own, gh, bufs_own, lr=lr)
+        for k, p_ in model.named_parameters():
+            worst_update = max(worst_update, float((p_.detach().float().cpu() - own[k]).abs().max()
+                                                   / own[k].abs().max().clamp_min(1e-12)))
+        with torch.no_grad():
+            orn.sgd_step({k: sd64[k] for k in names}, g64, bufs64, lr=lr)
+    torch.cuda.synchronize()
+    for r in report:
+        print("step %d: loss vs float64 %.2e; gradient vs float64: HIP float32 %.2e, torch float32 %.2e" % r)
+    parity("SimCLR bs 32, three training states, float32 preset: loss vs float64 oracle (relative, worst step)", worst_loss, 1e-5)
+    parity("SimCLR bs 32, float32 preset: step-1 parameter gradients vs float32 oracle (relative L2, worst tensor)", worst_first, 1e-3)
+    parity("SimCLR bs 32, float32 preset: gradient distance to float64 / (3 x the float32 oracle's distance), worst step",
+           worst_ratio, 1.0)
+    parity("SimCLR bs 32, float32 preset: fused SGD update vs the oracle's rule (relative max, worst tensor and step)",
+           worst_update, 1e-6)
 
 
 # ------------------------------------------------------------------------------------------------ DINO ViT-Tiny
@@ -187,6 +280,8 @@ def test_dino_vit_tiny_step_under_the_float32_preset_meets_the_contract():
         feats = torch.cat([ov.vit_features(torch.cat(vd[:2]), s_bb, nh), ov.vit_features(torch.cat(vd[2:]), s_bb, nh)])
     c = 1 - F.cosine_similarity(got["y"], feats, dim=1)
     parity("DINO ViT-Tiny class-token features, float32 preset (1 - cosine, worst row)", float(c.max()), 1e-3)
+    with precision.precision("float32"), pytest.raises(NotImplementedError):
+        model.training_step(([ops.to_nhwc_bf16(v) for v in vd], None), 0).backward()   # the transformer ops are forward-only and say so
 
 
 # ------------------------------------------------------------------------------------------------ MAE ViT-S/16
