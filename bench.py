@@ -427,6 +427,11 @@ def main():
         return dt, gpu_ms, last
 
     def finish(out):
+        from ssl_wafermap_amd import graph as wgraph
+        if wgraph.HOST_TIMES and rank == 0:   # WM_STEP_HOST_TIMES=1: where the host spends a step (diagnostic, stderr)
+            n = max(wgraph.HOST_TIMES.pop("steps", 1), 1)
+            print("[bench] host ms per step: " + ", ".join(f"{k} {1e3 * v / n:.3f}" for k, v in wgraph.HOST_TIMES.items()),
+                  file=sys.stderr)
         if rank == 0:
             print(json.dumps(out), flush=True)
         if world > 1:

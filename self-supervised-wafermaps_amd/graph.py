@@ -24,12 +24,20 @@ stage completes are one contiguous tail range; its all-reduce runs on RCCL's str
 """
 from __future__ import annotations
 
+import os
+import time
+
 import numpy as np
 import torch
 
 from . import ops
 
 from .transforms.augmentations import PARAM_DTYPE, validate_params
+
+
+# WM_STEP_HOST_TIMES=1: host seconds per phase of step() (sample, upload, replay, hook, optimiser), summed in HOST_TIMES --
+# a diagnostic for host-bound steps (the unstaged path only)
+HOST_TIMES = {} if os.environ.get("WM_STEP_HOST_TIMES") == "1" else None
 
 
 class GraphedTrainStep:
@@ -214,8 +222,33 @@ class GraphedTrainStep:
             torch.cuda.synchronize()
         return self
 
+    def _step_timed(self, sample_idx, rng, sync):
+        t = [time.perf_counter()]
+        params = self.tr.sample(self.ds.store, np.asarray(sample_idx), rng)
+        t.append(time.perf_counter())
+        self._upload(params)
+        t.append(time.perf_counter())
+        for g in self.graphs:
+            g.replay()
+        t.append(time.perf_counter())
+        if sync is not None:
+            sync.start()
+            sync.wait()
+        hook = getattr(self.model, "post_graph_step", None)
+        if hook is not None:
+            hook()
+        t.append(time.perf_counter())
+        self.opt.step()
+        t.append(time.perf_counter())
+        for k, a, b in zip(("sample", "upload", "replay", "hook", "optimiser"), t, t[1:]):
+            HOST_TIMES[k] = HOST_TIMES.get(k, 0.0) + (b - a)
+        HOST_TIMES["steps"] = HOST_TIMES.get("steps", 0) + 1
+        return self.loss
+
     def step(self, sample_idx: np.ndarray, rng: np.random.Generator, sync=None):
         """One training step: fresh decisions -> static buffers -> replay -> (all-reduce) -> SGD."""
+        if HOST_TIMES is not None:
+            return self._step_timed(sample_idx, rng, sync)
         self._upload(self.tr.sample(self.ds.store, np.asarray(sample_idx), rng))
         if not self.staged:
             self.graph.replay()

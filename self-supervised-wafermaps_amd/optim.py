@@ -44,6 +44,35 @@ class _Arena:
         self.offsets = offs
 
 
+class _HyperUpload:
+    """Asynchronous host -> device upload of the few floats an update kernel reads (learning rate, decay, bias corrections).
+    `hyper.copy_(torch.tensor(...))` from pageable memory blocks the host until the stream has drained -- with AdamW's
+    per-step bias corrections that was one full synchronisation per training step: the host could not prepare step i + 1
+    under step i, and the GPU idled 0.7 ms of every 9.5-ms DINO ViT-Tiny step (trace: profiles/r04_experiments.md, section 5).
+    Here the values go through a ring of pinned staging rows, each guarded by the event of the copy that last read it; the
+    host only ever waits when it is a whole ring (8 steps) ahead of the device."""
+
+    RING = 8
+
+    def __init__(self, n: int):
+        self.rows = [torch.zeros(n, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
+        self.events = [None] * self.RING
+        self.turn = 0
+
+    def __call__(self, dst: torch.Tensor, values) -> None:
+        slot = self.turn % self.RING
+        self.turn += 1
+        if self.events[slot] is not None:
+            self.events[slot].synchronize()
+        row = self.rows[slot]
+        for i, v in enumerate(values):
+            row[i] = v
+        dst.copy_(row, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self.events[slot] = ev
+
+
 class _ArenaStateMixin:
     """state_dict / load_state_dict in torch.optim's own format (state[i]["momentum_buffer"] for SGD / LARS,
     state[i]["step" | "exp_avg" | "exp_avg_sq"] for Adam(W)), so that a run resumes with its momentum, moments
@@ -118,6 +147,7 @@ class SGD(_ArenaStateMixin, torch.optim.Optimizer):
             self._arenas.append(arena)
             self._hyper.append(torch.zeros(4, dtype=torch.float32, device=arena.params.device))
             self._hyper_host.append(None)
+        self._upload = _HyperUpload(4)
         ops.bump_weight_epoch()
 
     @property
@@ -138,7 +168,7 @@ class SGD(_ArenaStateMixin, torch.optim.Optimizer):
         for group, arena, hyper, i in zip(self.param_groups, self._arenas, self._hyper, range(len(self._arenas))):
             h = (float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]), self.grad_scale)
             if h != self._hyper_host[i]:
-                hyper.copy_(torch.tensor(h, dtype=torch.float32), non_blocking=False)
+                self._upload(hyper, h)
                 self._hyper_host[i] = h
             check(lib.wm_sgd_step(ptr(arena.params), ptr(arena.grads), ptr(arena.momentum), arena.numel, ptr(hyper),
                                   stream_ptr()), "wm_sgd_step")
@@ -168,6 +198,7 @@ class AdamW(_ArenaStateMixin, torch.optim.Optimizer):
             self._arenas.append(arena)
             self._hyper.append(torch.zeros(9, dtype=torch.float32, device=arena.params.device))
             self._steps.append(0)
+        self._upload = _HyperUpload(9)
         ops.bump_weight_epoch()
 
     @property
@@ -190,7 +221,7 @@ class AdamW(_ArenaStateMixin, torch.optim.Optimizer):
             b1, b2 = group["betas"]
             h = (float(group["lr"]), float(b1), float(b2), float(group["eps"]), float(group["weight_decay"]),
                  1.0 - b1 ** t, 1.0 - b2 ** t, self.grad_scale, 1.0 if self._l2 else 0.0)
-            hyper.copy_(torch.tensor(h, dtype=torch.float32), non_blocking=False)
+            self._upload(hyper, h)
             check(lib.wm_adamw_step(ptr(arena.params), ptr(arena.grads), ptr(arena.momentum), ptr(arena.second),
                                     arena.numel, ptr(hyper), stream_ptr()), "wm_adamw_step")
         ops.bump_weight_epoch()
@@ -222,6 +253,7 @@ class LARS(_ArenaStateMixin, torch.optim.Optimizer):
             self._hyper.append(torch.zeros(6, dtype=torch.float32, device=dev))
             self._seg.append((seg.to(dev), len(ps)))
             self._norms.append(torch.zeros(4 * len(ps), dtype=torch.float32, device=dev))
+        self._upload = _HyperUpload(6)
         ops.bump_weight_epoch()
 
     @property
@@ -242,7 +274,7 @@ class LARS(_ArenaStateMixin, torch.optim.Optimizer):
                                                         self._norms):
             h = (float(group["lr"]), float(group["momentum"]), float(group["weight_decay"]), float(group["trust_coeff"]),
                  float(group["eps"]), self.grad_scale)
-            hyper.copy_(torch.tensor(h, dtype=torch.float32), non_blocking=False)
+            self._upload(hyper, h)
             # segments are (begin, end) pairs: 2n entries = n "segments" of stride 2 -> pass as 2n-1 boundaries
             check(lib.wm_lars_step(ptr(arena.params), ptr(arena.grads), ptr(arena.momentum), ptr(seg), 2 * n - 1,
                                    ptr(hyper), ptr(norms), stream_ptr()), "wm_lars_step")
