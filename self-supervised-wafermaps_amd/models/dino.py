@@ -9,6 +9,7 @@ BatchNorm statistics kept per view (`ops.bn_groups`), which is exactly what per-
 """
 from __future__ import annotations
 
+import contextlib
 import copy
 import os
 
@@ -19,6 +20,8 @@ from ..loss import DINOLoss
 from ..utils import debug, model_utils, scheduler
 from .knn import KNNBenchmarkModule
 from .vit import vit_base, vit_small, vit_tiny
+
+_TEACHER_STREAMS = {}   # device -> the side stream of the teacher's pass
 
 _BACKBONES = {"vit_small": vit_small, "vit_tiny": vit_tiny, "vit_base": vit_base}
 
@@ -75,15 +78,29 @@ class DINOViT(KNNBenchmarkModule):
         return torch.cat(list(views[i:j]), dim=0)
 
     def training_step(self, batch, batch_idx):
-        model_utils.update_momentum(self.backbone, self.teacher_backbone, m=0.99)
-        model_utils.update_momentum(self.head, self.teacher_head, m=0.99)
         views = batch[0]
         b = views[0].shape[0]
         n_views = len(views)
-        with torch.no_grad(), ops.bn_groups(2):  # statistics per view wherever the networks have BatchNorm
-            g = self._stack(views, 0, 2)
-            yt = self.teacher_backbone(g).flatten(start_dim=1)
-            teacher_out = self.teacher_head(yt)
+        # The teacher's pass (no gradient; 2 global crops) is independent of the student's forward pass until the loss:
+        # it is enqueued on a side stream, forked here and joined in front of the loss (inside a hipGraph capture: two
+        # parallel branches).  Its launches fill a fraction of the chip each (197 row tiles on 256 CUs at ViT-Tiny), and
+        # so do the student's.  `g` and `teacher_out` stay referenced until this function returns: the caching allocator
+        # must not hand the memory one stream still reads to the other.  WM_DINO_TEACHER_STREAM=0: in line.
+        g = self._stack(views, 0, 2)
+        side = None
+        if g.is_cuda and os.environ.get("WM_DINO_TEACHER_STREAM", "1") != "0":
+            side = _TEACHER_STREAMS.get(g.device)
+            if side is None:
+                side = _TEACHER_STREAMS[g.device] = torch.cuda.Stream(device=g.device)
+            side.wait_stream(torch.cuda.current_stream(g.device))
+        with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+            # (the teacher's momentum update belongs to its branch: only the teacher's pass waits for it; it reads the
+            # student's parameters, which nothing writes before the optimiser step behind the join)
+            model_utils.update_momentum(self.backbone, self.teacher_backbone, m=0.99)
+            model_utils.update_momentum(self.head, self.teacher_head, m=0.99)
+            with torch.no_grad(), ops.bn_groups(2):  # statistics per view wherever the networks have BatchNorm
+                yt = self.teacher_backbone(g).flatten(start_dim=1)
+                teacher_out = self.teacher_head(yt)
         groups = self._group_by_size(views)
         if len(groups) > 1 and hasattr(self.backbone, "forward_multi") and os.environ.get("WM_DINO_MERGE", "1") != "0":
             # ViT backbone: all resolutions through the blocks together (one launch per per-token layer)
@@ -98,6 +115,8 @@ class DINOViT(KNNBenchmarkModule):
             self.log("rep_std", debug.std_of_l2_normalized(y[-b:]))
         with ops.bn_groups(n_views):
             student_out = self.head(y)
+        if side is not None:
+            torch.cuda.current_stream(g.device).wait_stream(side)
         loss = self.criterion(teacher_out, student_out, epoch=self.current_epoch, batch=b)
         self.log("train_loss_ssl", loss)
         return loss

@@ -769,10 +769,13 @@ def _bn_workspace(rows: int, c: int, g: int, device) -> torch.Tensor:
     need = _lib.load().wm_bn_workspace_bytes(rows, c, g)
     if need == 0:
         raise ValueError(f"batch_norm: unsupported shape rows={rows} C={c} G={g}")
-    ws = _BN_WS.get(device)
+    # one scratch buffer per (device, stream): two forward passes may be in flight on different streams (the DINO
+    # teacher runs beside the student's forward pass)
+    key = (device, torch.cuda.current_stream(device).cuda_stream if device.type == "cuda" else 0)
+    ws = _BN_WS.get(key)
     if ws is None or ws.numel() < need:
         ws = torch.empty(max(need, 1 << 20), dtype=torch.uint8, device=device)
-        _BN_WS[device] = ws
+        _BN_WS[key] = ws
     return ws
 
 
