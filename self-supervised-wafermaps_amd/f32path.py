@@ -57,9 +57,11 @@ _WS = {}
 
 
 def _workspace(nbytes: int, device) -> torch.Tensor:
-    ws = _WS.get(device)
+    # per (device, stream): two passes may be in flight on different streams (the DINO teacher beside the student)
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _WS.get(key)
     if ws is None or ws.numel() < nbytes:
-        ws = _WS[device] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        ws = _WS[key] = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
     return ws
 
 
