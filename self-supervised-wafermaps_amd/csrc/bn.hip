@@ -275,7 +275,9 @@ __global__ __launch_bounds__(1024) void bn_fwd_finalize(
     float* __restrict__ mean, float* __restrict__ invstd, float* __restrict__ scale, float* __restrict__ shift) {
   __shared__ double red[2][2][32][33];
   // torch's num_batches_tracked += 1 per forward call; the G groups are G calls (one lane of the launch)
-  if (num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0) *num_batches_tracked += G;
+  // (an integer atomic: two views of a step may run as parallel branches and count on the same module)
+  if (num_batches_tracked != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+    atomicAdd(reinterpret_cast<unsigned long long*>(num_batches_tracked), (unsigned long long)G);
   const int bl = threadIdx.x >> 5, cl = threadIdx.x & 31;
   const int c = blockIdx.x * 32 + cl;
   const bool owner = bl == 0 && c < C;
@@ -738,7 +740,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_col_fwd(const uint16_t* __restr
                                                          float* __restrict__ save_mean, float* __restrict__ save_invstd,
                                                          uint16_t* __restrict__ out) {
   const int c = blockIdx.x * BN_THREADS + threadIdx.x;
-  if (training && num_batches_tracked != nullptr && c == 0) *num_batches_tracked += G;
+  if (training && num_batches_tracked != nullptr && c == 0)
+    atomicAdd(reinterpret_cast<unsigned long long*>(num_batches_tracked), (unsigned long long)G);
   if (c >= C) return;
   const float ga = gamma ? gamma[c] : 1.f, be = beta ? beta[c] : 0.f;
   for (int g = 0; g < G; ++g) {

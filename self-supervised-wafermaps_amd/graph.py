@@ -94,12 +94,28 @@ class GraphedTrainStep:
             loss = self.model.training_step((views, None), 0)
         return loss, cuts
 
+    @staticmethod
+    def _cut_groups(cuts):
+        """The recorded cut points in backward order, one group per boundary: [(name, [(x, leaf), ...])].  A model that
+        runs its two views as parallel branches (nn.ViewBranches) passes every boundary twice, second view first in
+        backward order: a stage continues BOTH chains (two backward calls inside one stage graph, each on its branch's
+        stream; the gradient slots receive the second view's sums first, then the first view's -- the order of the
+        unstaged pass)."""
+        order, groups = [], {}
+        for name, x, leaf in reversed(cuts):
+            if name not in groups:
+                groups[name] = []
+                order.append(name)
+            groups[name].append((x, leaf))
+        return [(n, groups[n]) for n in order]
+
     def _body(self):
         """The whole step eagerly (warm-up; also the unstaged graph's body)."""
         loss, cuts = self._forward()
         self._backward(loss)
-        for _, x, leaf in reversed(cuts):
-            x.backward(leaf.grad)
+        for _, group in self._cut_groups(cuts):
+            for x, leaf in group:
+                x.backward(leaf.grad)
         return loss
 
     def _backward(self, loss):
@@ -119,7 +135,7 @@ class GraphedTrainStep:
         ps = [p for g in self.opt.param_groups for p in g["params"] if p.requires_grad]
         off = {id(p): o for p, o in zip(ps, arena.offsets)}
         bounds = []
-        for name, _, _ in cuts:
+        for name in dict.fromkeys(name for name, _, _ in cuts):   # (each boundary once, in forward order)
             first = [off[id(p)] for n, p in self.model.named_parameters()
                      if p.requires_grad and id(p) in off and (n.startswith(name + ".") or ("." + name + ".") in n)]
             if not first:
@@ -135,8 +151,9 @@ class GraphedTrainStep:
         loss.backward()
         lows = list(reversed(bounds))
         ok = float(g[: lows[0]].abs().max()) == 0.0
-        for k, (_, x, leaf) in enumerate(reversed(cuts)):
-            x.backward(leaf.grad)
+        for k, (_, group) in enumerate(self._cut_groups(cuts)):
+            for x, leaf in group:
+                x.backward(leaf.grad)
             if k + 1 < len(lows):
                 ok = ok and float(g[: lows[k + 1]].abs().max()) == 0.0
         return ok
@@ -198,10 +215,11 @@ class GraphedTrainStep:
                     self._backward(self.loss)
                 self.graphs = [g0]
                 self._cuts = cuts   # keeps the stage-boundary activations and their gradients alive in the pool
-                for _, x, leaf in reversed(cuts):
+                for _, group in self._cut_groups(cuts):
                     gk = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(gk, pool=g0.pool(), capture_error_mode="thread_local"):
-                        x.backward(leaf.grad)
+                        for x, leaf in group:
+                            x.backward(leaf.grad)
                     self.graphs.append(gk)
         finally:
             ops.TIMER = old_timer

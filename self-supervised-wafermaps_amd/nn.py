@@ -63,6 +63,8 @@ class _BatchNorm(nn.Module):
         """The StatSlots object (ops) of this BatchNorm for sums produced in a convolution's epilogue: the producing
         convolution's forward (batch statistics) or, `which="_stat_buf_bwd"`, the consuming convolution's dgrad
         (backward sums).  Per-tile slots written with plain stores, summed in order by the finalize kernels."""
+        if ops.current_branch():   # a second view's pass running beside the first on its own stream: its own slots
+            which = f"{which}_b{ops.current_branch()}"
         slots = getattr(self, which, None)
         if slots is None:
             slots = ops.StatSlots(self.num_features)
@@ -79,9 +81,23 @@ class _BatchNorm(nn.Module):
         bwd = None
         if self.training and relu and x.dim() == 4 and torch.is_grad_enabled():
             bwd = self.stats_buffer(ops.current_bn_groups(), "_stat_buf_bwd")
-        return ops.batch_norm(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                              residual=residual, relu=relu, eps=self.eps, momentum=self.momentum, stats=stats,
+        rm, rv, mom = self._running()
+        return ops.batch_norm(x, self.weight, self.bias, rm, rv, self.training,
+                              residual=residual, relu=relu, eps=self.eps, momentum=mom, stats=stats,
                               num_batches_tracked=self.num_batches_tracked, bwd_stats=bwd)
+
+    def _running(self):
+        """(running_mean, running_var, momentum) this pass updates.  On a side branch (ops.branch: the second view of a
+        siamese step running beside the first on its own stream) the launch must not read-modify-write the buffers the main
+        branch updates at the same time: it stores its batch statistics (momentum 1) into the module's branch buffers, and
+        ViewBranches.merge() folds them into the running statistics behind the join -- in the order of the reference's two
+        forward calls (first view, then second)."""
+        if ops.current_branch() and self.training:
+            br = getattr(self, "_branch_running", None)
+            if br is None:
+                raise RuntimeError("BatchNorm on a side branch without branch buffers: build nn.ViewBranches(model) first")
+            return br[0], br[1], 1.0
+        return self.running_mean, self.running_var, self.momentum
 
 
 class BatchNorm2d(_BatchNorm):
@@ -89,13 +105,85 @@ class BatchNorm2d(_BatchNorm):
         """maxpool3x3s2(relu(self(x))) fused (ResNet stem)."""
         if self._synced():  # the statistics need the exchange between the two halves of the fused kernel pair
             return ops.max_pool3x3s2(self.forward(x, relu=True, stats=stats))
-        return ops.bn_relu_maxpool(x, self.weight, self.bias, self.running_mean, self.running_var, self.training,
-                                   eps=self.eps, momentum=self.momentum, stats=stats,
+        rm, rv, mom = self._running()
+        return ops.bn_relu_maxpool(x, self.weight, self.bias, rm, rv, self.training,
+                                   eps=self.eps, momentum=mom, stats=stats,
                                    num_batches_tracked=self.num_batches_tracked)
 
 
 class BatchNorm1d(_BatchNorm):
     pass
+
+
+class ViewBranches:
+    """The two views of a siamese training step through `root` (a backbone) as two PARALLEL BRANCHES: the first view on
+    the caller's stream, the second on a side stream (inside a hipGraph capture: two branches of the graph), joined
+    before whatever consumes both outputs.  Both views used to go through every kernel as one batch with per-view
+    BatchNorm statistics; as branches, one view's HBM-bound BatchNorm / pooling passes meet the other view's MFMA-bound
+    convolutions on the chip (tools/probes/overlap_probe.py: a convolution and a BatchNorm pass of equal length on two
+    streams take 0.76 of their sum).  Same arithmetic per view.  What a module caches for "its" launches is kept per
+    branch (statistics slots: stats_buffer; scratch: per stream), parameter gradients of the side branch join the pass's
+    ordered fold instead of adding into the slots directly (ops._BatchNorm.backward), and the side branch's batch
+    statistics reach the running statistics through merge().
+
+    The BatchNorm layers' running statistics are moved into ONE flat buffer (the modules' buffers become views of it),
+    with a second flat buffer of the same layout for the side branch's batch statistics: merge() is one launch."""
+
+    _ALIGN = 64
+
+    def __init__(self, root: nn.Module):
+        bns = [m for m in root.modules() if isinstance(m, _BatchNorm) and m.running_mean is not None]
+        if not bns:
+            raise ValueError("ViewBranches: no BatchNorm layers")
+        moms = {m.momentum for m in bns}
+        if len(moms) != 1 or None in moms:
+            raise ValueError("ViewBranches: the BatchNorm layers must share one momentum")
+        self.momentum = float(moms.pop())
+        dev = bns[0].running_mean.device
+        offs, total = [], 0
+        for m in bns:
+            for _ in range(2):
+                offs.append(total)
+                total += (m.num_features + self._ALIGN - 1) // self._ALIGN * self._ALIGN
+        self.real = torch.zeros(total, dtype=torch.float32, device=dev)
+        self.tmp = torch.zeros(total, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for i, m in enumerate(bns):
+                c = m.num_features
+                om, ov = offs[2 * i], offs[2 * i + 1]
+                self.real[om:om + c].copy_(m.running_mean)
+                self.real[ov:ov + c].copy_(m.running_var)
+                m.running_mean.data = self.real[om:om + c]
+                m.running_var.data = self.real[ov:ov + c]
+                m._branch_running = (self.tmp[om:om + c], self.tmp[ov:ov + c])
+        self.n = total
+        self.side = torch.cuda.Stream(device=dev)
+        self.modules = bns
+        self.convs = [m for m in root.modules() if isinstance(m, Conv2d)]
+
+    def prepare(self) -> None:
+        """Before the fork, on the main stream: every bf16 kernel layout of the root's weights that is rebuilt lazily at
+        its first use after an update (the stem's space-to-depth form; everything, in the very first step).  Left to the
+        branches, one would launch the rebuild on its stream and the other read the buffer without waiting for it."""
+        for m in self.convs:
+            if isinstance(m, StemConv):
+                ops._WCACHE.get(m.weight, kind="stem")
+            else:
+                ops._WCACHE.get(m.weight, need_crsk=True)
+
+    def valid(self) -> bool:
+        """The modules' buffers are still the views made here (a .to() / load of new tensors would replace them)."""
+        m = self.modules[0]
+        return m.running_mean.data_ptr() == self.real.data_ptr() and m.running_mean.device == self.real.device
+
+    def merge(self) -> None:
+        """running <- (1 - momentum) * running + momentum * (side branch's batch statistics), all layers in one launch;
+        call on the main stream behind the join."""
+        from . import _lib
+        from ._lib import check, stream_ptr
+
+        check(_lib.load().wm_ema_update(self.real.data_ptr(), self.tmp.data_ptr(), self.n, 1.0 - self.momentum, stream_ptr()),
+              "wm_ema_update(bn running statistics)")
 
 
 def convert_sync_batchnorm(module: nn.Module, process_group=None) -> nn.Module:

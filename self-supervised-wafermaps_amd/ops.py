@@ -132,6 +132,71 @@ def bn_groups(g: int):
         _BN_GROUPS = old
 
 
+# ---- parallel branches of one step (the two views of a siamese step as two streams): objects that a module caches for
+# "its" launches -- statistics slots -- are kept per branch
+_BRANCH = 0
+
+
+@contextlib.contextmanager
+def branch(i: int):
+    global _BRANCH
+    old, _BRANCH = _BRANCH, int(i)
+    try:
+        yield
+    finally:
+        _BRANCH = old
+
+
+def current_branch() -> int:
+    return _BRANCH
+
+
+def _bn_fold_buffers(gamma: torch.Tensor, c: int, device):
+    """Persistent (dgamma, dbeta) buffers of a BatchNorm whose backward runs on a side branch: stable addresses (the
+    fold's descriptor table is cached by them, and a captured graph bakes them in), one pair per use in a pass."""
+    idx = getattr(gamma, "_hip_pending", 0)
+    bufs = getattr(gamma, "_hip_bn_fold", None)
+    if bufs is None:
+        bufs = gamma._hip_bn_fold = []
+    while len(bufs) <= idx:
+        bufs.append(None)
+    b = bufs[idx]
+    if b is None or b.numel() != 2 * c or b.device != device:
+        b = bufs[idx] = torch.empty(2 * c, dtype=torch.float32, device=device)
+    return b[:c], b[c:]
+
+
+def _flat_fold_buffer(owner: torch.Tensor, numel: int, device) -> torch.Tensor:
+    """A persistent f32 buffer of `owner` for a gradient that joins the fold as one flat row (see _bn_fold_buffers)."""
+    b = getattr(owner, "_hip_flat_fold", None)
+    if b is None or b.numel() != numel or b.device != device:
+        b = owner._hip_flat_fold = torch.empty(numel, dtype=torch.float32, device=device)
+    return b
+
+
+class _StackRows(torch.autograd.Function):
+    """[a; b] for two row blocks of one shape (the outputs of two branches): two device copies into one buffer; the
+    gradient is handed back as the two halves (views) of the incoming one."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        if a.shape != b.shape or a.dtype != b.dtype or a.dim() != 2:
+            raise ValueError(f"stack_rows: {tuple(a.shape)} {a.dtype} vs {tuple(b.shape)} {b.dtype}")
+        out = torch.empty((2 * a.shape[0], a.shape[1]), dtype=a.dtype, device=a.device)
+        out[: a.shape[0]].copy_(a)
+        out[a.shape[0]:].copy_(b)
+        ctx.n = a.shape[0]
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        return dout[: ctx.n], dout[ctx.n:]
+
+
+def stack_rows(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    return _StackRows.apply(a.contiguous(), b.contiguous())
+
+
 def current_bn_groups() -> int:
     return _BN_GROUPS
 
@@ -380,6 +445,7 @@ def _slab_buffers(owner: torch.Tensor, nsplit: int, numel: int, bias_k: int = 0)
 # CU slots and L2 from the chain's kernels; the chain is the critical path and gets slower by more than the weight
 # gradients cost when run in line.
 _SIDE = {"stream": None, "dirty": False, "keep": []}
+_WGRAD_STREAMS = set()
 _SIDE_ON = os.environ.get("WM_WGRAD_SIDE_STREAM", "0") == "1"
 
 
@@ -407,6 +473,8 @@ def wgrad(dy, x, owner, n, h, w, c, k, r, s, p, q, stride, pad, bias_k: int = 0,
     ns = wgrad_splits(n, h, w, c, k, r, s, p, q, stride, pad)
     slabs, bslabs = _slab_buffers(owner, ns, k * r * s * c, bias_k)
     lib = _lib.load()
+    if dy.is_cuda:
+        _WGRAD_STREAMS.add(torch.cuda.current_stream(dy.device))   # the fold waits for every stream that wrote slabs
     # the side stream only where the batched fold (which joins) consumes the slabs; wgrad_deliver joins otherwise
     side = _SIDE_ON and dy.is_cuda and _arena_grad(owner) is not None
     ctx = torch.cuda.stream(_side_fork(dy, x, slabs)) if side else contextlib.nullcontext()
@@ -490,6 +558,12 @@ def fold_wgrads() -> None:
     global _FOLD_QUEUED
     _FOLD_QUEUED = False
     side_join()
+    if _WGRAD_STREAMS:
+        cur = torch.cuda.current_stream()
+        for st in _WGRAD_STREAMS:
+            if st != cur and st.device == cur.device:
+                cur.wait_stream(st)
+        _WGRAD_STREAMS.clear()
     if not _PENDING_FOLDS:
         return
     try:
@@ -734,6 +808,7 @@ class _StemConv(torch.autograd.Function):
         ctx.save_for_backward(xs)
         ctx.weight = weight
         ctx.geom = (n, h2, w2, k)
+        ctx.branch = current_branch()
         return y
 
     @staticmethod
@@ -745,6 +820,13 @@ class _StemConv(torch.autograd.Function):
         slabs, _, ns = wgrad(dy, xs, ctx.weight, n, h2, w2, 16, k, 4, 4, h2, w2, 1, 2)
         side_join()   # the finalize below reads the slabs on this stream (the stem is the last layer of the pass anyway)
         slot = _arena_grad(ctx.weight)
+        if slot is not None and ctx.branch != 0:
+            # a side branch must not add into the slot beside the main branch: its gradient goes into a buffer of its own and
+            # joins the pass's ordered fold as one flat row
+            tmp = _flat_fold_buffer(ctx.weight, k * 147, dy.device)
+            check(lib.wm_stem_wgrad_finalize(ptr(slabs), ns, k, ptr(tmp), 0, stream_ptr()), "wm_stem_wgrad_finalize")
+            _queue_fold(ctx.weight, tmp, 1, slot, 1, k * 147, 1)
+            return None, None, None, None
         if slot is not None:
             check(lib.wm_stem_wgrad_finalize(ptr(slabs), ns, k, ptr(slot), 1, stream_ptr()), "wm_stem_wgrad_finalize")
             return None, None, None, None
@@ -840,6 +922,7 @@ class _BatchNorm(torch.autograd.Function):
             ctx.save_for_backward(y, out if (relu and not mask_from_y) else None, mean, invstd)
             ctx.affine = (gamma, beta)
             ctx.meta = (rows, c, groups, relu, residual is not None, mask_from_y)
+            ctx.branch = current_branch()
             if will_link:
                 ctx.link = BnLink(y, mean, invstd, gamma, beta, groups, residual is not None, bwd_stats, mask)
         else:
@@ -861,8 +944,15 @@ class _BatchNorm(torch.autograd.Function):
         dy = torch.empty_like(y)
         sg, sb = _arena_grad(gamma), _arena_grad(beta)
         direct = sg is not None and sb is not None
-        dgamma = sg if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
-        dbeta = sb if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
+        # a side branch (the second view's pass on its own stream) must not read-modify-write the gradient slots the main
+        # branch adds into at the same time: its sums go into their own buffers and join the pass's ordered fold
+        via_fold = direct and getattr(ctx, "branch", 0) != 0 and c % 4 == 0
+        if via_fold:
+            direct = False
+            dgamma, dbeta = _bn_fold_buffers(gamma, c, y.device)
+        else:
+            dgamma = sg if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
+            dbeta = sb if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
         ws = _bn_workspace(rows, c, groups, y.device)
         link = ctx.link
         fused = False
@@ -889,6 +979,10 @@ class _BatchNorm(torch.autograd.Function):
                                       int(mask_from_y), ptr(gamma), ptr(beta), ptr(mean), ptr(invstd), rows, c, groups,
                                       ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(), dz.data_ptr() if has_res else 0,
                                       ptr(ws), ws.numel(), stream_ptr()), "wm_bn_train_bwd")
+        if via_fold:
+            _queue_fold(gamma, dgamma, 1, sg, 1, c, 1)
+            _queue_fold(beta, dbeta, 1, sb, 1, c, 1)
+            return (dy, dz) + (None,) * 12
         if direct:
             return (dy, dz) + (None,) * 12
         return (dy, dz, dgamma, dbeta) + (None,) * 10
@@ -1041,6 +1135,7 @@ class _BnReluMaxPool(torch.autograd.Function):
         ctx.ysel = ysel
         ctx.affine = (gamma, beta)
         ctx.meta = (n, c, h, w, g)
+        ctx.branch = current_branch()
         return out
 
     @staticmethod
@@ -1056,13 +1151,22 @@ class _BnReluMaxPool(torch.autograd.Function):
         dy = torch.empty_like(y)
         sg, sb = _arena_grad(gamma), _arena_grad(beta)
         direct = sg is not None and sb is not None
-        dgamma = sg if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
-        dbeta = sb if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
+        via_fold = direct and getattr(ctx, "branch", 0) != 0 and c % 4 == 0   # (as _BatchNorm.backward)
+        if via_fold:
+            direct = False
+            dgamma, dbeta = _bn_fold_buffers(gamma, c, y.device)
+        else:
+            dgamma = sg if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
+            dbeta = sb if direct else torch.empty((c,), dtype=torch.float32, device=y.device)
         ws = _bn_workspace(rows, c, g, y.device)
         # the pooled gradient is scattered back inside the two BN backward passes (no 112x112 dout tensor)
         check(lib.wm_bn_relu_maxpool_bwd(y.data_ptr(), ptr(ctx.ysel), dpooled.data_ptr(), ptr(ctx.idx), n, h, w, c, ptr(gamma), ptr(beta),
                                          ptr(mean), ptr(invstd), g, ptr(dgamma), ptr(dbeta), int(direct), dy.data_ptr(),
                                          ptr(ws), ws.numel(), stream_ptr()), "wm_bn_relu_maxpool_bwd")
+        if via_fold:
+            _queue_fold(gamma, dgamma, 1, sg, 1, c, 1)
+            _queue_fold(beta, dbeta, 1, sb, 1, c, 1)
+            return dy, None, None, None, None, None, None, None, None, None, None
         if direct:
             return dy, None, None, None, None, None, None, None, None, None, None
         return dy, dgamma, dbeta, None, None, None, None, None, None, None, None
