@@ -572,17 +572,32 @@ def fold_wgrads() -> None:
         # shared weights) has two entries for one slot: the second goes into a second launch behind the first (in order
         # of use: the sums stay reproducible).
         waves = []
+        first = {}   # gradient slot -> (wave index, row index) of its first entry without bias slabs
         for _, sl, ns, slot, k, c, rs, bs, bg in _PENDING_FOLDS:
             row = (bs.data_ptr() if bs is not None else 0, bg.data_ptr() if bg is not None else 0, 0, sl.data_ptr(),
                    slot.data_ptr(), k, c, rs, ns)
             targets = {slot.data_ptr()} | ({bg.data_ptr()} if bg is not None else set())
-            for wave in waves:
+            # the second use of a parameter with slabs of the same shape (the two views of a step as parallel branches):
+            # it rides in the first entry's descriptor as its second slab set -- grad = (grad + set 0) + set 1, to the
+            # bit what a second launch behind the first computes
+            prev = first.get(slot.data_ptr()) if bs is None else None
+            if prev is not None:
+                wi, ri = prev
+                r0 = waves[wi][0][ri]
+                if r0[2] == 0 and r0[5:] == row[5:]:
+                    waves[wi][0][ri] = r0[:2] + (sl.data_ptr(),) + r0[3:]
+                    continue
+            for wi, wave in enumerate(waves):
                 if not (wave[1] & targets):
                     wave[0].append(row)
                     wave[1] |= targets
+                    if bs is None and slot.data_ptr() not in first:
+                        first[slot.data_ptr()] = (wi, len(wave[0]) - 1)
                     break
             else:
                 waves.append([[row], set(targets)])
+                if bs is None and slot.data_ptr() not in first:
+                    first[slot.data_ptr()] = (len(waves) - 1, 0)
         dev = _PENDING_FOLDS[0][1].device
     finally:
         for ent in _PENDING_FOLDS:
