@@ -701,12 +701,30 @@ def main():
                     roof = None
             if roof is None:
                 # (b) eager steps with one bracket per launch; for the transformer steps (~400 launches of 10 - 60 us) the
-                # bracket's own cost is calibrated on a dependent chain of two GEMMs of the block's MLP shapes and taken out
+                # bracket's own cost is calibrated on a dependent chain of two GEMMs of the block's MLP shapes and taken out.
+                # The timed region runs independent parts of the step as parallel branches (SimCLR: the two views through
+                # the backbone; DINO: the teacher beside the student): a bracket around a launch that shares the chip with
+                # another branch's launches measures the contention, not the kernel.  The brackets are therefore taken
+                # with the branches switched off -- every launch alone on the device, as in the rocprofv3 tables under
+                # profiles/ (same switches) -- and `timing` says so.
+                branches = getattr(model, "view_branches", None)
+                teacher_env = os.environ.get("WM_DINO_TEACHER_STREAM")
+                if branches:
+                    model.view_branches = False
+                os.environ["WM_DINO_TEACHER_STREAM"] = "0"
                 timer = ops.KernelTimer()
                 ops.TIMER = timer
-                for j in range(roof_steps):
-                    check_finite(eager_step(warmup + steps + j))
-                ops.TIMER = None
+                try:
+                    for j in range(roof_steps):
+                        check_finite(eager_step(warmup + steps + j))
+                finally:
+                    ops.TIMER = None
+                    if branches:
+                        model.view_branches = True
+                    if teacher_env is None:
+                        os.environ.pop("WM_DINO_TEACHER_STREAM", None)
+                    else:
+                        os.environ["WM_DINO_TEACHER_STREAM"] = teacher_env
                 torch.cuda.synchronize()
                 over = 0.0
                 if not simclr:
@@ -725,7 +743,8 @@ def main():
                     with torch.no_grad():
                         over = ops.KernelTimer.bracket_overhead_ms([fc1, fc2])
                 roof = roofline_from(timer, roof_steps, kl, tkey, overhead_ms=over)
-                timing = "one HIP-event bracket per launch on eager steps"
+                timing = ("one HIP-event bracket per launch on eager steps, every launch alone on the device (the parallel "
+                          "branches of the timed region switched off for these steps)")
             roof["timing"] = timing
         imgs = B * world * steps
         value = imgs / dt
@@ -736,6 +755,11 @@ def main():
             "config": {"workload": label, "per_gpu_batch": B, "global_batch": B * world, "parallelism": f"dp{world}",
                        "hip_graph": graphed is not None,
                        "backward_stage_graphs": len(graphed.graphs) if graphed is not None else 0,
+                       # independent parts of the step on parallel branches of the graph (two streams)
+                       "parallel_branches": ("two views through the backbone" if getattr(model, "view_branches", False)
+                                             and os.environ.get("WM_VIEW_BRANCHES", "1") != "0" else
+                                             "teacher beside student" if (hasattr(model, "teacher_backbone")
+                                             and os.environ.get("WM_DINO_TEACHER_STREAM", "1") != "0") else "none"),
                        "model_tflop_per_step_per_gpu": round(gflop * B / 1e3, 3),
                        "model_mfma_frac": round(value / world * gflop / 1e3 / MFMA_BF16_PEAK_TFLOPS, 4)},
             "final_loss": round(final_loss, 4),

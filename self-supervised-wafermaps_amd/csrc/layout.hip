@@ -233,60 +233,47 @@ __device__ __forceinline__ float4 fold_range(const float* src, size_t slab, int 
   return v;
 }
 
-// A descriptor may carry a SECOND slab set of the same shape (d.crsk, unused by the fold otherwise): the same parameter's
-// weight gradient from the second of two parallel branches of the pass (nn.ViewBranches).  The sets are summed one after
-// the other, grad = (grad + sum of set 0) + sum of set 1 -- to the bit what two fold launches in a row compute.
 template <int RS>
-__device__ __forceinline__ void fold_tile(const WmLayoutDesc& d, int tk, int tc, int rs, float4 (*part)[64]) {
+__device__ __forceinline__ void fold_tile(const WmLayoutDesc& d, const float* __restrict__ slabs, int tk, int tc, int rs,
+                                          float4 (*part)[64]) {
   const int K = d.K, C = d.C, ns = d.nsplit;
   const size_t slab = (size_t)K * RS * C;
   const int tid = (int)threadIdx.x;
-  const int nsets = d.crsk != nullptr ? 2 : 1;
   if (ns <= FB_SPLIT_MIN) {
     // all RS taps of (k, four channels) in one thread: its 4 * RS gradient values are CONTIGUOUS in OIHW
     // (offset j * RS + rs), i.e. RS aligned float4 read-modify-writes instead of 4 * RS scattered words
     const int k = tk * 8 + (tid >> 5), c = tc * 128 + (tid & 31) * 4;
     if (k >= K || c >= C) return;
-    float4* g = reinterpret_cast<float4*>(d.grad + ((size_t)k * C + c) * RS);  // 16-byte aligned: c % 4 == 0
-    float4 cur[RS];
+    float o[4 * RS];
 #pragma unroll
-    for (int i = 0; i < RS; ++i) cur[i] = g[i];
-    for (int set = 0; set < nsets; ++set) {
-      const float* src = set == 0 ? d.ws : reinterpret_cast<const float*>(d.crsk);
-      float o[4 * RS];
-#pragma unroll
-      for (int t = 0; t < RS; ++t) {
-        const float4 v = fold_range(src + ((size_t)k * RS + t) * C + c, slab, 0, ns);
-        o[t] = v.x; o[RS + t] = v.y; o[2 * RS + t] = v.z; o[3 * RS + t] = v.w;
-      }
-#pragma unroll
-      for (int i = 0; i < RS; ++i) {
-        cur[i].x += o[4 * i]; cur[i].y += o[4 * i + 1]; cur[i].z += o[4 * i + 2]; cur[i].w += o[4 * i + 3];
-      }
+    for (int t = 0; t < RS; ++t) {
+      const float4 v = fold_range(slabs + ((size_t)k * RS + t) * C + c, slab, 0, ns);
+      o[t] = v.x; o[RS + t] = v.y; o[2 * RS + t] = v.z; o[3 * RS + t] = v.w;
     }
+    float4* g = reinterpret_cast<float4*>(d.grad + ((size_t)k * C + c) * RS);  // 16-byte aligned: c % 4 == 0
 #pragma unroll
-    for (int i = 0; i < RS; ++i) g[i] = cur[i];
+    for (int i = 0; i < RS; ++i) {
+      float4 cur = g[i];
+      cur.x += o[4 * i]; cur.y += o[4 * i + 1]; cur.z += o[4 * i + 2]; cur.w += o[4 * i + 3];
+      g[i] = cur;
+    }
     return;
   }
   const int q = tid >> 6, e = tid & 63;                       // quarter of the slab range, element of the 4 x 64 tile
   const int k = tk * 4 + (e >> 4), c = tc * 64 + (e & 15) * 4;
   const bool on = k < K && c < C;
   const int per = (ns + 3) >> 2;
-  for (int set = 0; set < nsets; ++set) {
-    const float* src = set == 0 ? d.ws : reinterpret_cast<const float*>(d.crsk);
-    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (on) v = fold_range(src + ((size_t)k * RS + rs) * C + c, slab, q * per, min(ns, (q + 1) * per));
-    if (set > 0) __syncthreads();   // the quarters of the previous set have been read
-    part[q][e] = v;
-    __syncthreads();
-    if (q == 0 && on) {
-      const float4 a = part[0][e], b = part[1][e], cc = part[2][e], dd = part[3][e];
-      float* g = d.grad + ((size_t)k * C + c) * RS + rs;
-      g[0] += ((a.x + b.x) + cc.x) + dd.x;
-      g[RS] += ((a.y + b.y) + cc.y) + dd.y;
-      g[2 * RS] += ((a.z + b.z) + cc.z) + dd.z;
-      g[3 * RS] += ((a.w + b.w) + cc.w) + dd.w;
-    }
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (on) v = fold_range(slabs + ((size_t)k * RS + rs) * C + c, slab, q * per, min(ns, (q + 1) * per));
+  part[q][e] = v;
+  __syncthreads();
+  if (q == 0 && on) {
+    const float4 a = part[0][e], b = part[1][e], cc = part[2][e], dd = part[3][e];
+    float* g = d.grad + ((size_t)k * C + c) * RS + rs;
+    g[0] += ((a.x + b.x) + cc.x) + dd.x;
+    g[RS] += ((a.y + b.y) + cc.y) + dd.y;
+    g[2 * RS] += ((a.z + b.z) + cc.z) + dd.z;
+    g[3 * RS] += ((a.w + b.w) + cc.w) + dd.w;
   }
 }
 
@@ -304,8 +291,17 @@ __global__ __launch_bounds__(LT_THREADS) void wgrad_fold_batched(const WmLayoutD
     t /= d.RS;
   }
   const int tk = t / d.tiles_c, tc = t - tk * d.tiles_c;
-  if (d.RS == 9) fold_tile<9>(d, tk, tc, rs, part);
-  else fold_tile<1>(d, tk, tc, rs, part);
+  if (d.RS == 9) fold_tile<9>(d, d.ws, tk, tc, rs, part);
+  else fold_tile<1>(d, d.ws, tk, tc, rs, part);
+  if (d.crsk != nullptr) {
+    // a SECOND slab set of the same shape (the field is unused by the fold otherwise): the parameter's weight gradient from
+    // the second of two parallel branches of the pass (nn.ViewBranches), folded behind the first by the same threads --
+    // grad = (grad + set 0) + set 1, to the bit what a second fold launch would compute
+    __syncthreads();
+    const float* second = reinterpret_cast<const float*>(d.crsk);
+    if (d.RS == 9) fold_tile<9>(d, second, tk, tc, rs, part);
+    else fold_tile<1>(d, second, tk, tc, rs, part);
+  }
   const int kt = d.nsplit <= FB_SPLIT_MIN ? 8 : 4;
   if (d.w != nullptr && tc == 0 && rs == 0) {  // bias slabs [nsplit][K] -> bias gradient
     const int k = tk * kt + (int)threadIdx.x;

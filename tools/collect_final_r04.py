@@ -16,7 +16,8 @@ stamp = f"End of round 4, commit {h}, one MI355X (gpurun), tools/final_profiles_
 for w in ("default", "dino_vit_tiny", "dino_vit_small", "mae_vit_small_16", "mae_vit_b_32", "knn_allpairs", "knn_allpairs_b64"):
     if (g / f"final_bench_{w}.json").exists():
         shutil.copy(g / f"final_bench_{w}.json", p / f"r04_bench_{w}.json")
-for src, dst in [(f"final_trace_{w}.md", f"r04_bench_{w}_trace.md") for w in ("simclr_r18", "dino_vit_tiny", "mae_vit_small_16")] + \
+for src, dst in [(f"final_trace_{w}.md", f"r04_bench_{w}_trace.md") for w in ("simclr_r18", "dino_vit_tiny", "mae_vit_small_16",
+                                                                                "simclr_r18_branches", "dino_vit_tiny_branches")] + \
         [("final_trace_knn_b64.md", "r04_knn_b64_trace.md"), ("final_trace_knn_pipelined.md", "r04_knn_pipelined_trace.md")]:
     if (g / src).exists():
         lines = (g / src).read_text().split("\n")

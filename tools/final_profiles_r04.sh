@@ -4,9 +4,14 @@
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$root"
 python bench.py > gpurun_out/final_bench_default.json 2> gpurun_out/final_bench_default.err
-WM_PROFILE_MARKER=sgd_step bash tools/profile_bench.sh final_trace_simclr_r18 10 14 --no-kernel-timer
-WM_PROFILE_MARKER=adamw_kernel bash tools/profile_bench.sh final_trace_dino_vit_tiny 10 14 --workload dino_vit_tiny --no-kernel-timer
+# kernel tables: every launch alone on the device (the parallel branches of the step switched off -- rocprofv3 serialises
+# overlapping launches anyway, and a launch that shares the chip is not a measurement of the kernel)
+WM_VIEW_BRANCHES=0 WM_DINO_TEACHER_STREAM=0 WM_PROFILE_MARKER=sgd_step bash tools/profile_bench.sh final_trace_simclr_r18 10 14 --no-kernel-timer
+WM_VIEW_BRANCHES=0 WM_DINO_TEACHER_STREAM=0 WM_PROFILE_MARKER=adamw_kernel bash tools/profile_bench.sh final_trace_dino_vit_tiny 10 14 --workload dino_vit_tiny --no-kernel-timer
 WM_PROFILE_MARKER=adamw_kernel bash tools/profile_bench.sh final_trace_mae_vit_small_16 10 14 --workload mae_vit_small_16 --no-kernel-timer
+# the same two steps as the timed region runs them (branches on), for the record of what the profiler does to them
+WM_PROFILE_MARKER=sgd_step bash tools/profile_bench.sh final_trace_simclr_r18_branches 10 14 --no-kernel-timer
+WM_PROFILE_MARKER=adamw_kernel bash tools/profile_bench.sh final_trace_dino_vit_tiny_branches 10 14 --workload dino_vit_tiny --no-kernel-timer
 for w in dino_vit_tiny dino_vit_small mae_vit_small_16 mae_vit_b_32; do
   python bench.py --workload $w --steps 30 --warmup 5 --no-cpu-baseline > gpurun_out/final_bench_$w.json 2>/dev/null
 done
