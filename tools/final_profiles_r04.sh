@@ -24,9 +24,10 @@ python3 tools/summarize_profile.py gpurun_out/final_trace_knn gpurun_out/final_t
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/final_trace_knn_pipe -o p -- python3 tools/knn_pipelined_trace.py > /dev/null 2>&1
 python3 tools/summarize_knn_trace.py gpurun_out/final_trace_knn_pipe gpurun_out/final_trace_knn_pipelined.md > /dev/null
 rm -rf gpurun_out/final_trace_knn gpurun_out/final_trace_knn_pipe
-# HBM traffic (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, eager steps)
-bash tools/pmc_bench.sh final_hbm_simclr_r18 sgd_step "python bench.py --no-graph --steps 3 --warmup 1 (SimCLR ResNet-18, bs 256), eager steps" --steps 3 --warmup 1
-bash tools/pmc_bench.sh final_hbm_dino_vit_tiny adamw_kernel "python bench.py --workload dino_vit_tiny --no-graph --steps 3 --warmup 1, eager steps" --workload dino_vit_tiny --steps 3 --warmup 1
+# HBM traffic (rocprofv3 --pmc, separate FETCH_SIZE / WRITE_SIZE passes, eager steps; the launches of the roofline brackets:
+# both views in one stream)
+WM_VIEW_BRANCHES=0 bash tools/pmc_bench.sh final_hbm_simclr_r18 sgd_step "python bench.py --no-graph --steps 3 --warmup 1 (SimCLR ResNet-18, bs 256), eager steps" --steps 3 --warmup 1
+WM_DINO_TEACHER_STREAM=0 bash tools/pmc_bench.sh final_hbm_dino_vit_tiny adamw_kernel "python bench.py --workload dino_vit_tiny --no-graph --steps 3 --warmup 1, eager steps" --workload dino_vit_tiny --steps 3 --warmup 1
 bash tools/pmc_bench.sh final_hbm_mae_vit_small_16 adamw_kernel "python bench.py --workload mae_vit_small_16 --no-graph --steps 3 --warmup 1, eager steps" --workload mae_vit_small_16 --steps 3 --warmup 1
 bash tools/pmc_knn.sh final_hbm_knn_b64 "python tools/knn_one.py 64 bf16 (5 calls of wm_knn_topk, 64 bf16 queries x 811 457 x 128)" 64 bf16
 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > gpurun_out/final_smoke.txt 2>&1
