@@ -171,6 +171,11 @@ class ViewBranches:
             else:
                 ops._WCACHE.get(m.weight, need_crsk=True)
 
+    def __deepcopy__(self, memo):
+        # a copy of the model gets no branch state (streams are not copyable; the copy's BatchNorm buffers are its own
+        # tensors): it builds its own at its first branched step
+        return None
+
     def valid(self) -> bool:
         """The modules' buffers are still the views made here (a .to() / load of new tensors would replace them)."""
         m = self.modules[0]

@@ -213,6 +213,55 @@ def test_bs256_step_is_bit_reproducible():
         assert le == lg and torch.equal(ge, gg) and torch.equal(pe, pg)
 
 
+def test_view_branches_compute_the_single_stream_step(monkeypatch):
+    """SimCLR's two views as two parallel branches (nn.ViewBranches, the default) against both views batched through one
+    stream (WM_VIEW_BRANCHES=0), same weights, wafers and decisions, two optimiser steps at bs 128: the per-view arithmetic is
+    the same, so the loss is bit-identical in the first step and the step-1 gradients differ only by the order in which the
+    two views' float32 sums meet (<= 1e-5 relative); from the second step on the bf16 roundings downstream of those last
+    bits move the loss in its 5th digit (measured 1.3e-5; bound 1e-4, the distance of two bf16 runs that differ in one
+    rounding); parameters and BatchNorm running statistics after two steps <= 1e-4; the batch counters agree exactly (they
+    count forward calls: two per step)."""
+    B = 128
+
+    def run(mode: str):
+        monkeypatch.setenv("WM_VIEW_BRANCHES", mode)
+        ds, model, opt = _setup(B, 512)
+        rng = np.random.default_rng(11)
+        losses = []
+        for i in range(2):
+            batch = ds.get_batch((np.arange(B) + i * B) % len(ds), rng, fmt="s2d_bf16")
+            opt.zero_grad()
+            loss = model.training_step(batch, i)
+            loss.backward()
+            if i == 0:
+                grads = opt.grad_arenas[0].clone()
+            opt.step()
+            losses.append(float(loss.detach()))
+        torch.cuda.synchronize()
+        assert (getattr(model, "_branches", None) is not None) == (mode == "1")
+        params = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
+        bn = [m for m in model.backbone.modules() if hasattr(m, "running_mean") and m.running_mean is not None]
+        stats = torch.cat([torch.cat([m.running_mean.reshape(-1), m.running_var.reshape(-1)]) for m in bn])
+        counts = [int(m.num_batches_tracked) for m in bn]
+        return losses, grads, params, stats, counts
+
+    one, two = run("0"), run("1")
+    assert one[0][0] == two[0][0], (one[0], two[0])
+    assert abs(one[0][1] - two[0][1]) <= 1e-4 * abs(one[0][1]), (one[0], two[0])
+
+    def rel(a, b):
+        return float((a - b).norm() / b.norm())
+
+    from parity_log import parity
+
+    parity("SimCLR bs 128, views as parallel branches vs one stream: step-1 gradients (relative L2)", rel(two[1], one[1]), 1e-5)
+    parity("SimCLR bs 128, views as parallel branches vs one stream: parameters after two steps (relative L2)",
+           rel(two[2], one[2]), 1e-4)
+    parity("SimCLR bs 128, views as parallel branches vs one stream: BatchNorm running statistics after two steps (relative L2)",
+           rel(two[3], one[3]), 1e-4)
+    assert one[4] == two[4] and set(one[4]) == {4}, (one[4][:4], two[4][:4])
+
+
 @pytest.mark.parametrize("which", ["dino_vit_tiny", "mae_vit_small_16"])
 def test_transformer_steps_are_bit_reproducible_in_their_gradients(which):
     """Round 3, second half: the transformer steps' parameter gradients no longer pass through f32 atomics either
