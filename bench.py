@@ -707,10 +707,8 @@ def main():
                 # another branch's launches measures the contention, not the kernel.  The brackets are therefore taken
                 # with the branches switched off -- every launch alone on the device, as in the rocprofv3 tables under
                 # profiles/ (same switches) -- and `timing` says so.
-                branches = getattr(model, "view_branches", None)
-                teacher_env = os.environ.get("WM_DINO_TEACHER_STREAM")
-                if branches:
-                    model.view_branches = False
+                saved_env = {k: os.environ.get(k) for k in ("WM_VIEW_BRANCHES", "WM_DINO_TEACHER_STREAM")}
+                os.environ["WM_VIEW_BRANCHES"] = "0"        # (both switches are read per call)
                 os.environ["WM_DINO_TEACHER_STREAM"] = "0"
                 timer = ops.KernelTimer()
                 ops.TIMER = timer
@@ -719,12 +717,11 @@ def main():
                         check_finite(eager_step(warmup + steps + j))
                 finally:
                     ops.TIMER = None
-                    if branches:
-                        model.view_branches = True
-                    if teacher_env is None:
-                        os.environ.pop("WM_DINO_TEACHER_STREAM", None)
-                    else:
-                        os.environ["WM_DINO_TEACHER_STREAM"] = teacher_env
+                    for k, v in saved_env.items():
+                        if v is None:
+                            os.environ.pop(k, None)
+                        else:
+                            os.environ[k] = v
                 torch.cuda.synchronize()
                 over = 0.0
                 if not simclr:
@@ -756,7 +753,8 @@ def main():
                        "hip_graph": graphed is not None,
                        "backward_stage_graphs": len(graphed.graphs) if graphed is not None else 0,
                        # independent parts of the step on parallel branches of the graph (two streams)
-                       "parallel_branches": ("two views through the backbone" if getattr(model, "view_branches", False)
+                       "parallel_branches": ("two views through the backbone"
+                                             if getattr(getattr(model, "backbone", None), "_branches", None) is not None
                                              and os.environ.get("WM_VIEW_BRANCHES", "1") != "0" else
                                              "teacher beside student" if (hasattr(model, "teacher_backbone")
                                              and os.environ.get("WM_DINO_TEACHER_STREAM", "1") != "0") else "none"),

@@ -3,6 +3,8 @@
 conv1, bn1, layer{1-4}.{0,1}.{conv1,bn1,conv2,bn2}, layer{2-4}.0.downsample.{0,1}; output [N, 512]."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -88,8 +90,44 @@ class ResNet18(nn.Module):
         x = self.layer3(ops.cut_point(x, "layer3"))
         return self.layer4(ops.cut_point(x, "layer4"))
 
+    view_branches = True   # WM_VIEW_BRANCHES=0 (read per call) or this attribute: both statistic groups in one stream
+
     def forward(self, x):
+        if self._branch_ok(x):
+            return self._forward_branches(x)
         return ops.global_avg_pool(self.forward_features(x))
+
+    def _branch_ok(self, x) -> bool:
+        """A training-mode pass over TWO statistic groups (ops.bn_groups(2): the two views of a siamese step, which the
+        reference runs as forward(x0); forward(x1)) goes through the network as two parallel branches (nn.ViewBranches):
+        on the GPU, in the bf16 preset, not already inside a branch."""
+        from .. import precision
+
+        if not (self.view_branches and self.training and x.is_cuda and ops.current_bn_groups() == 2
+                and x.shape[0] % 2 == 0 and ops.current_branch() == 0):
+            return False
+        if os.environ.get("WM_VIEW_BRANCHES", "1") == "0" or precision.is_f32():
+            return False
+        vb = getattr(self, "_branches", None)
+        if vb is None or not vb.valid():
+            if torch.cuda.is_current_stream_capturing():
+                return False   # (built by the eager warm-up steps that precede every capture)
+            self._branches = hnn.ViewBranches(self)
+        return True
+
+    def _forward_branches(self, x):
+        vb = self._branches
+        b = x.shape[0] // 2
+        cur = torch.cuda.current_stream(x.device)
+        vb.prepare()
+        vb.side.wait_stream(cur)
+        with ops.bn_groups(1):
+            f0 = ops.global_avg_pool(self.forward_features(x[:b]))
+            with torch.cuda.stream(vb.side), ops.branch(1):
+                f1 = ops.global_avg_pool(self.forward_features(x[b:]))
+        cur.wait_stream(vb.side)
+        vb.merge()
+        return ops.stack_rows(f0.flatten(start_dim=1), f1.flatten(start_dim=1))
 
 
 def create_model(name: str, num_classes: int = 0, pretrained: bool = False, **kw):

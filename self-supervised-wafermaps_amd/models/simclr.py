@@ -38,25 +38,6 @@ class SimCLR(KNNBenchmarkModule):
                 self.log("rep_std", debug.std_of_l2_normalized(part))
         return z
 
-    view_branches = True     # graph.GraphedTrainStep switches them off for staged (data-parallel) backward graphs
-
-    def _use_view_branches(self, x) -> bool:
-        """Two views as two parallel branches (nn.ViewBranches): on the GPU, in training, in the bf16 preset, unless
-        switched off (WM_VIEW_BRANCHES=0, or the step's backward is cut into stage graphs)."""
-        from .. import nn as hnn
-        from .. import precision
-
-        if not (x.is_cuda and self.training and self.view_branches and torch.is_grad_enabled()):
-            return False
-        if os.environ.get("WM_VIEW_BRANCHES", "1") == "0" or precision.is_f32():
-            return False
-        vb = getattr(self, "_branches", None)
-        if vb is None or not vb.valid():
-            if torch.cuda.is_current_stream_capturing():
-                return False   # (built by the eager warm-up steps that precede every capture)
-            vb = self._branches = hnn.ViewBranches(self.backbone)
-        return True
-
     def training_step(self, batch, batch_index):
         (x0, x1), _ = batch[0], batch[1]
         views = batch[0]
@@ -64,30 +45,8 @@ class SimCLR(KNNBenchmarkModule):
         if stacked is None:
             stacked = torch.cat([x0, x1], dim=0)
         b = x0.shape[0]
-        if self._use_view_branches(stacked):
-            # the reference's z0 = forward(x0); z1 = forward(x1) as two parallel branches through the backbone
-            # (nn.ViewBranches); the head and the loss see the stacked features as before
-            vb = self._branches
-            cur = torch.cuda.current_stream(stacked.device)
-            vb.prepare()
-            vb.side.wait_stream(cur)
-            with ops.bn_groups(1):
-                f0 = self.backbone(stacked[:b]).flatten(start_dim=1)
-                with torch.cuda.stream(vb.side), ops.branch(1):
-                    f1 = self.backbone(stacked[b:]).flatten(start_dim=1)
-            cur.wait_stream(vb.side)
-            vb.merge()
-            f = ops.stack_rows(f0, f1)
-            if self.log_rep_std:
-                for part in (f0, f1):
-                    self.log("rep_std", debug.std_of_l2_normalized(part.detach()))
-            with ops.bn_groups(2):
-                z = self.projection_head(f)
-            loss = self.criterion(*stacked_views(z, b))
-            self.log("train_loss_ssl", loss)
-            return loss
-        # one pass over both views; BatchNorm statistics per view, exactly as the reference's
-        # z0 = forward(x0); z1 = forward(x1)
+        # both views in one call; BatchNorm statistics per view, exactly as the reference's z0 = forward(x0);
+        # z1 = forward(x1) -- which the backbone runs as two parallel branches (models/resnet.py, nn.ViewBranches)
         with ops.bn_groups(2):
             z = self.forward(stacked)
         loss = self.criterion(*stacked_views(z, b))

@@ -238,7 +238,7 @@ def test_view_branches_compute_the_single_stream_step(monkeypatch):
             opt.step()
             losses.append(float(loss.detach()))
         torch.cuda.synchronize()
-        assert (getattr(model, "_branches", None) is not None) == (mode == "1")
+        assert (getattr(model.backbone, "_branches", None) is not None) == (mode == "1")
         params = torch.cat([p.detach().reshape(-1) for p in model.parameters()])
         bn = [m for m in model.backbone.modules() if hasattr(m, "running_mean") and m.running_mean is not None]
         stats = torch.cat([torch.cat([m.running_mean.reshape(-1), m.running_var.reshape(-1)]) for m in bn])
