@@ -112,8 +112,10 @@ class ResNet18(nn.Module):
         if vb is None or not vb.valid():
             if torch.cuda.is_current_stream_capturing():
                 return False   # (built by the eager warm-up steps that precede every capture)
-            self._branches = hnn.ViewBranches(self)
-        return True
+            vb = self._branches = hnn.ViewBranches(self)
+        # synchronised BatchNorm exchanges statistics between the ranks inside every layer: two branches would issue those
+        # collectives from two streams, in an order that may differ from rank to rank
+        return not any(m._synced() for m in vb.modules)
 
     def _forward_branches(self, x):
         vb = self._branches
