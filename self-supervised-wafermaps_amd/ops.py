@@ -567,45 +567,53 @@ def fold_wgrads() -> None:
     if not _PENDING_FOLDS:
         return
     try:
-        # One launch folds every entry whose gradient slot is distinct: its blocks read-modify-write the slots
-        # concurrently.  A parameter used TWICE in the pass (the patch-embedding bias of a multi-resolution forward,
-        # shared weights) has two entries for one slot: the second goes into a second launch behind the first (in order
-        # of use: the sums stay reproducible).
-        waves = []
-        first = {}   # gradient slot -> (wave index, row index) of its first entry without bias slabs
-        for _, sl, ns, slot, k, c, rs, bs, bg in _PENDING_FOLDS:
-            row = (bs.data_ptr() if bs is not None else 0, bg.data_ptr() if bg is not None else 0, 0, sl.data_ptr(),
-                   slot.data_ptr(), k, c, rs, ns)
-            targets = {slot.data_ptr()} | ({bg.data_ptr()} if bg is not None else set())
-            # the second use of a parameter with slabs of the same shape (the two views of a step as parallel branches):
-            # it rides in the first entry's descriptor as its second slab set -- grad = (grad + set 0) + set 1, to the
-            # bit what a second launch behind the first computes
-            prev = first.get(slot.data_ptr()) if bs is None else None
-            if prev is not None:
-                wi, ri = prev
-                r0 = waves[wi][0][ri]
-                if r0[2] == 0 and r0[5:] == row[5:]:
-                    waves[wi][0][ri] = r0[:2] + (sl.data_ptr(),) + r0[3:]
-                    continue
-            for wi, wave in enumerate(waves):
-                if not (wave[1] & targets):
-                    wave[0].append(row)
-                    wave[1] |= targets
-                    if bs is None and slot.data_ptr() not in first:
-                        first[slot.data_ptr()] = (wi, len(wave[0]) - 1)
-                    break
-            else:
-                waves.append([[row], set(targets)])
-                if bs is None and slot.data_ptr() not in first:
-                    first[slot.data_ptr()] = (len(waves) - 1, 0)
+        waves = _plan_fold([(sl.data_ptr(), ns, slot.data_ptr(), k, c, rs, bs.data_ptr() if bs is not None else 0,
+                             bg.data_ptr() if bg is not None else 0) for _, sl, ns, slot, k, c, rs, bs, bg in _PENDING_FOLDS])
         dev = _PENDING_FOLDS[0][1].device
     finally:
         for ent in _PENDING_FOLDS:
             ent[0]._hip_pending = 0
         _PENDING_FOLDS.clear()
-    for rows, _ in waves:
+    for rows in waves:
         tab, n, tiles = _desc_table(tuple(rows), dev, per_tap=True)
         check(_lib.load().wm_wgrad_fold(ptr(tab), n, tiles, stream_ptr()), "wm_wgrad_fold")
+
+
+def _plan_fold(entries):
+    """Pending fold entries (slabs address, nsplit, gradient-slot address, K, C, RS, bias-slabs address or 0, bias-gradient
+    address or 0), in order of use -> the launches of the fold: a list of waves, each a list of descriptor rows
+    (bias slabs, bias gradient, SECOND slab set or 0, slabs, gradient slot, K, C, RS, nsplit).
+    One launch folds every entry whose gradient slot is distinct: its blocks read-modify-write the slots concurrently.  A
+    parameter used TWICE in the pass has two entries for one slot:
+      * slabs of the same shape and no bias slabs (the two views of a step as parallel branches, nn.ViewBranches): the
+        second rides in the first entry's descriptor as its second slab set -- grad = (grad + set 0) + set 1, to the bit
+        what a second launch behind the first computes;
+      * anything else (the patch-embedding bias of a multi-resolution forward, a third use): a later launch, in order of
+        use, so the sums stay reproducible."""
+    waves, targets_of, first = [], [], {}
+    for sl, ns, slot, k, c, rs, bs, bg in entries:
+        row = (bs, bg, 0, sl, slot, k, c, rs, ns)
+        targets = {slot} | ({bg} if bg else set())
+        prev = first.get(slot) if not bs else None
+        if prev is not None:
+            wi, ri = prev
+            r0 = waves[wi][ri]
+            if r0[2] == 0 and r0[5:] == row[5:]:
+                waves[wi][ri] = r0[:2] + (sl,) + r0[3:]
+                continue
+        for wi, wave in enumerate(waves):
+            if not (targets_of[wi] & targets):
+                wave.append(row)
+                targets_of[wi] |= targets
+                if not bs and slot not in first:
+                    first[slot] = (wi, len(wave) - 1)
+                break
+        else:
+            waves.append([row])
+            targets_of.append(set(targets))
+            if not bs and slot not in first:
+                first[slot] = (len(waves) - 1, 0)
+    return waves
 
 
 def _arena_grad(p: torch.Tensor):

@@ -266,3 +266,45 @@ def test_multiply_high_division_identity():
         assert np.array_equal(q, xs // np.uint64(d)), d
         hi_e = (edge * np.uint64(m)) >> np.uint64(32)
         assert np.array_equal(((hi_e + edge) & np.uint64(0xFFFFFFFF)) >> np.uint64(l), edge // np.uint64(d)), d
+
+
+def test_fold_plan_merges_the_second_branch_and_orders_everything_else():
+    """ops._plan_fold (host logic of the weight-gradient fold): entries with distinct gradient slots share one launch; the
+    second use of a parameter with slabs of the same shape -- the second of two parallel branches (nn.ViewBranches) -- rides
+    in the first entry's descriptor as its second slab set; a different slab count, a third use or bias slabs go into a
+    later launch, in order of use."""
+    from ssl_wafermap_amd import ops
+
+    plan = ops._plan_fold
+    # (slabs, nsplit, slot, K, C, RS, bias slabs, bias gradient)
+    assert plan([(100, 8, 1, 64, 64, 9, 0, 0), (200, 8, 2, 64, 64, 9, 0, 0)]) == \
+        [[(0, 0, 0, 100, 1, 64, 64, 9, 8), (0, 0, 0, 200, 2, 64, 64, 9, 8)]]
+    assert plan([(100, 8, 1, 64, 64, 9, 0, 0), (200, 8, 1, 64, 64, 9, 0, 0)]) == [[(0, 0, 200, 100, 1, 64, 64, 9, 8)]]
+    assert plan([(100, 8, 1, 64, 64, 9, 0, 0), (200, 4, 1, 64, 64, 9, 0, 0)]) == \
+        [[(0, 0, 0, 100, 1, 64, 64, 9, 8)], [(0, 0, 0, 200, 1, 64, 64, 9, 4)]]
+    third = plan([(100, 8, 1, 64, 64, 9, 0, 0), (200, 8, 1, 64, 64, 9, 0, 0), (300, 8, 1, 64, 64, 9, 0, 0)])
+    assert third == [[(0, 0, 200, 100, 1, 64, 64, 9, 8)], [(0, 0, 0, 300, 1, 64, 64, 9, 8)]]
+    biased = plan([(100, 8, 1, 64, 64, 1, 500, 9), (200, 8, 1, 64, 64, 1, 600, 9)])
+    assert biased == [[(500, 9, 0, 100, 1, 64, 64, 1, 8)], [(600, 9, 0, 200, 1, 64, 64, 1, 8)]]
+    # the order of use survives interleaving: two parameters, each used by both branches
+    both = plan([(10, 4, 1, 8, 8, 1, 0, 0), (20, 4, 2, 8, 8, 1, 0, 0), (11, 4, 1, 8, 8, 1, 0, 0), (21, 4, 2, 8, 8, 1, 0, 0)])
+    assert both == [[(0, 0, 11, 10, 1, 8, 8, 1, 4), (0, 0, 21, 20, 2, 8, 8, 1, 4)]]
+
+
+def test_view_branches_and_parallel_branch_switches_fail_loudly_without_a_gpu():
+    """nn.ViewBranches is GPU state (a side stream, flat device buffers): a CPU model keeps the single-stream path, and the
+    ResNet-18 backbone's branch test is False off the GPU (no silent CPU emulation of the branches)."""
+    import torch
+
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models.resnet import create_model
+
+    m = create_model("resnet18").train()
+    x = torch.zeros(4, 3, 32, 32)
+    with ops.bn_groups(2):
+        assert m._branch_ok(x) is False
+    assert getattr(m, "_branches", None) is None
+    assert ops.current_branch() == 0
+    with ops.branch(1):
+        assert ops.current_branch() == 1
+    assert ops.current_branch() == 0
