@@ -1,6 +1,6 @@
 #!/bin/bash
 # End-of-round evidence on one MI355X -> gpurun_out/final_*  (python tools/collect_final_r04.py copies it into profiles/r04_*).
-#   tools/final_profiles_r04.sh            (~12 min of GPU time)
+#   tools/final_profiles_r04.sh            (~3 min of GPU time)
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$root"
 python bench.py > gpurun_out/final_bench_default.json 2> gpurun_out/final_bench_default.err
