@@ -113,7 +113,11 @@ class ResNet18(nn.Module):
             if getattr(self, "_branches", None) is None or not self._branches.valid():
                 if torch.cuda.is_current_stream_capturing():
                     return False
-                self._branches = hnn.ViewBranches(self)
+                try:
+                    self._branches = hnn.ViewBranches(self)
+                except ValueError:
+                    self.view_branches = False
+                    return False
             return True
         if not (self.view_branches and self.training and x.is_cuda and ops.current_bn_groups() == 2
                 and x.shape[0] % 2 == 0 and ops.current_branch() == 0):
@@ -124,7 +128,11 @@ class ResNet18(nn.Module):
         if vb is None or not vb.valid():
             if torch.cuda.is_current_stream_capturing():
                 return False   # (built by the eager warm-up steps that precede every capture)
-            vb = self._branches = hnn.ViewBranches(self)
+            try:
+                vb = self._branches = hnn.ViewBranches(self)
+            except ValueError:   # (layers without running statistics or with differing momenta: one stream)
+                self.view_branches = False
+                return False
         # synchronised BatchNorm exchanges statistics between the ranks inside every layer: two branches would issue those
         # collectives from two streams, in an order that may differ from rank to rank
         return not any(m._synced() for m in vb.modules)
