@@ -635,3 +635,30 @@ def test_conv_bn_backward_is_bit_reproducible():
     assert torch.equal(oa, ob)
     for u, v in zip(a, b):
         assert torch.equal(u, v), u.shape
+
+
+def test_inference_pass_as_two_half_batch_branches_is_bit_identical(monkeypatch):
+    """Eval-mode ResNet-18 (embedding dump, kNN bank build / validation): an even batch of >= 64 images runs as two half-batch
+    branches on two streams (models/resnet.py); no statistics and no gradients are involved, so the features equal the
+    single-stream pass (WM_EVAL_BRANCHES=0) to the last bit -- eagerly and replayed from a hipGraph."""
+    from ssl_wafermap_amd import ops
+    from ssl_wafermap_amd.models.resnet import create_model
+
+    torch.manual_seed(0)
+    m = create_model("resnet18").to(DEV).eval()
+    x = ops.to_nhwc_bf16(torch.randn(128, 3, 96, 96, device=DEV))
+    outs = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("WM_EVAL_BRANCHES", mode)
+        with torch.no_grad():
+            y = m(x)
+            torch.cuda.synchronize()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                yg = m(x)
+            g.replay()
+            torch.cuda.synchronize()
+        outs[mode] = (y.float().clone(), yg.float().clone())
+    assert (getattr(m, "_branches", None) is not None)
+    assert torch.equal(outs["0"][0], outs["1"][0]) and torch.equal(outs["0"][1], outs["1"][1])
+    assert torch.equal(outs["1"][0], outs["1"][1])
