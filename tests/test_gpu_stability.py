@@ -217,7 +217,8 @@ def test_view_branches_compute_the_single_stream_step(monkeypatch):
     """SimCLR's two views as two parallel branches (nn.ViewBranches, the default) against both views batched through one
     stream (WM_VIEW_BRANCHES=0), same weights, wafers and decisions, two optimiser steps at bs 128: the per-view arithmetic is
     the same, so the loss is bit-identical in the first step and the step-1 gradients differ only by the order in which the
-    two views' float32 sums meet (<= 1e-5 relative); from the second step on the bf16 roundings downstream of those last
+    two views' float32 sums meet (6.8e-6 relative, bound 2e-5: the per-view launches split their pixel ranges differently from
+    the batched one); from the second step on the bf16 roundings downstream of those last
     bits move the loss in its 5th digit (measured 1.3e-5; bound 1e-4, the distance of two bf16 runs that differ in one
     rounding); parameters and BatchNorm running statistics after two steps <= 1e-4; the batch counters agree exactly (they
     count forward calls: two per step)."""
@@ -254,7 +255,7 @@ def test_view_branches_compute_the_single_stream_step(monkeypatch):
 
     from parity_log import parity
 
-    parity("SimCLR bs 128, views as parallel branches vs one stream: step-1 gradients (relative L2)", rel(two[1], one[1]), 1e-5)
+    parity("SimCLR bs 128, views as parallel branches vs one stream: step-1 gradients (relative L2)", rel(two[1], one[1]), 2e-5)  # measured 6.8e-6
     parity("SimCLR bs 128, views as parallel branches vs one stream: parameters after two steps (relative L2)",
            rel(two[2], one[2]), 1e-4)
     parity("SimCLR bs 128, views as parallel branches vs one stream: BatchNorm running statistics after two steps (relative L2)",
